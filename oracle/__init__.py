@@ -1,0 +1,30 @@
+"""CPU oracle for the style-transfer inner loop -- TEST INFRASTRUCTURE ONLY.
+
+This package is a from-scratch CPU restatement (numpy + a small C file) of the
+hot path of crowsonkb/style_transfer2 (``worker.py:32-315``, ``optimizers.py:7-125``,
+``utils.py:29-69,232-304``, ``models/vgg19.prototxt``).  It exists so that the HIP
+path can be checked against something that runs anywhere.
+
+Rules (enforced by tests/test_layout.py):
+  * only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+    ``bench.py`` may import it -- and only as the checker, never as the product;
+  * nothing under ``style_transfer2_amd/``, ``worker.py`` or ``messages.py`` imports it;
+  * the product path has no CPU fallback: it fails loudly without the HIP library.
+
+Pinning status
+  * everything above the network (Gram, content/style/deep-dream terms, TV, p-norm,
+    trace, Adam, L-BFGS, state machine) is pinned against the reference itself:
+    ``tests/golden/make_golden.py`` imports the reference's own ``worker.StyleTransfer``,
+    ``optimizers`` and ``utils`` in the build container and stores their outputs as
+    ``tests/golden/*.npz`` (the reference never travels; the fixtures do);
+  * the network arithmetic (Caffe conv / in-place ReLU / ceil-mode max-pool and the
+    ranged backward of ``worker.py:88-106``) has NO runnable reference here (pycaffe
+    and the weights are absent, the reference has no tests): **parity unpinned at the
+    Caffe boundary**.  It is pinned instead against torch CPU conv2d / max_pool2d
+    (ceil_mode) / conv2d_input and hand-computed cases (tests/test_oracle_net.py).
+"""
+
+from .caffe_net import NetOracle, VGG19_TOPOLOGY, tiny_topology, he_init_weights  # noqa: F401
+from .objective import TransferOracle, gram  # noqa: F401
+from .image_norms import tv_term, p_term  # noqa: F401
+from .descent import AdamOracle, LBFGSOracle, EmaBiasCorrected  # noqa: F401
