@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Benchmark of the style-transfer inner loop on MI355X (BASELINE.json: iterations/sec @1024px VGG19).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--optimizer adam]
+
+One "step" = one ``StyleTransfer.step()`` = forward to conv5_1, 1 content + 5 style loss terms,
+ranged backward, fused TV/p-norm/Adam pass (reference worker.py:303-310).  Inputs are synthetic
+(seeded He-normal VGG19 weights, uniform-noise uint8 images: SURVEY section 8d) and resident in HBM
+before the timed region; nothing is read back inside it.  With N > 1 (launched by torch.distributed.run,
+one rank per GPU) every rank runs an independent job -- jobs are the unit the reference scales by
+(one worker per GPU, no collective) -- so `value` is the aggregate it/s and scaling is weak.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the conv3x3 MFMA implicit GEMM,
+forward + data-gradient launches) from HIP events on the engine's own stream; `cpu_baseline` is the
+CPU oracle (kind "port") timed on this host on a bounded sample, N = 1 only.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import style_transfer2_amd as st2                      # noqa: E402
+from style_transfer2_amd import weights as st2_weights  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+WEIGHTS = {'content': {'conv4_2': 0.08},
+           'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
+           'deepdream': {}}
+PARAMS = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+ITERS_PER_IMAGE = 500
+
+
+def images(size):
+    rs = np.random.RandomState
+    shape = (size, size, 3)
+    return (rs(1).randint(0, 256, shape).astype(np.uint8), rs(2).randint(0, 256, shape).astype(np.uint8),
+            rs(3).randint(0, 256, shape).astype(np.uint8))
+
+
+def make_job(size, optimizer, device):
+    content, style, init = images(size)
+    model = st2.HipModel(st2_weights.he_normal(st2.VGG19_TOPOLOGY, seed=0), device=device)
+    job = st2.StyleTransfer(model)
+    job.set_input(init)
+    job.set_content(content)
+    job.set_style(style)
+    job.set_weights(WEIGHTS, PARAMS)
+    job.optimizer_cls = {'adam': st2.AdamOptimizer, 'lbfgs': st2.LBFGSOptimizer}[optimizer]
+    job.set_step_size({'adam': 10, 'lbfgs': 1}[optimizer])
+    job.reset()
+    assert job.start()
+    return job
+
+
+def cpu_baseline(size, optimizer):
+    """The CPU oracle ("port") on this host: setup, one untimed step (norm capture), one timed step."""
+    import oracle
+    from threadpoolctl import threadpool_info
+    content, style, init = images(size)
+    topo = oracle.VGG19_TOPOLOGY
+    job = oracle.TransferOracle(oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False))
+    job.set_input(init)
+    job.set_content(content)
+    job.set_style(style)
+    job.reset()
+    job.set_weights(WEIGHTS, PARAMS)
+    job.set_optimizer(optimizer, {'adam': 10, 'lbfgs': 1}[optimizer])
+    job.start()
+    job.step()
+    t0 = time.perf_counter()
+    job.step()
+    dt = time.perf_counter() - t0
+    threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
+    return {'value': 1.0 / dt, 'unit': 'it/s', 'cores': threads, 'host_cpus': os.cpu_count(), 'kind': 'port',
+            'sample': '1 %s iteration at %dx%d (after 1 untimed), numpy+OpenBLAS oracle, forward stops at conv5_1'
+                      % (optimizer, size, size)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--optimizer', default='adam', choices=['adam', 'lbfgs'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-size', type=int, default=0, help='image size of the CPU sample (default: --size)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    job = make_job(args.size, args.optimizer, local_rank)
+    for _ in range(args.warmup):
+        job.step_async()
+    job.engine.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.step_async()
+    job.engine.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel-class HIP-event timing of the same steps (separate leg so `value` carries no event overhead)
+    prof_steps = max(3, min(10, args.steps))
+    job.engine.profile_enable(True)
+    for _ in range(prof_steps):
+        job.step_async()
+    prof = job.engine.profile_read()
+    job.engine.profile_enable(False)
+
+    if rank == 0:
+        its = world * args.steps / elapsed
+        conv = [prof.get('conv3x3_fwd_mfma_f32'), prof.get('conv3x3_dgrad_mfma_f32')]
+        conv = [c for c in conv if c]
+        flops = sum(c['flops'] for c in conv)
+        ms = sum(c['ms'] for c in conv)
+        launches = sum(c['launches'] for c in conv)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms else 0.0
+        total_ms = sum(v['ms'] for v in prof.values())
+        out = {
+            'metric': 'style-transfer iters/sec @1024px VGG19',
+            'value': its, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'images_per_hour': its * 3600.0 / ITERS_PER_IMAGE,
+            'config': {'workload': 'configs[1]: %dx%d single image per GPU, VGG19 to conv5_1, content conv4_2 + 5 style '
+                                   'layers, %s fp32, %d iterations per image' % (args.size, args.size, args.optimizer,
+                                                                                  ITERS_PER_IMAGE),
+                       'jobs': world, 'parallelism': 'independent jobs, 1 per GPU, no collective'},
+            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_mfma_f32 (forward + dgrad launches)',
+                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'flops_per_launch': flops / launches if launches else 0.0,
+                         'avg_launch_ms': ms / launches if launches else 0.0,
+                         'share_of_step': ms / total_ms if total_ms else 0.0},
+            'kernel_ms_per_step': {k: round(v['ms'] / prof_steps, 4) for k, v in sorted(prof.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_size or args.size, args.optimizer)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

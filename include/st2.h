@@ -1,0 +1,110 @@
+/* st2.h -- C ABI of libst2_hip.so: the MI355X-resident style-transfer inner loop.
+ *
+ * The reference (crowsonkb/style_transfer2) has no FFI of its own: the hot path sits behind two
+ * Python duck types inside worker.py -- the model (``CaffeModel``, worker.py:32-106) and the
+ * objective/optimizer pair (``StyleTransfer`` worker.py:117-315, optimizers.py:7-125).  Each entry
+ * point below names the reference interface it replaces.  The reference-side binding (a ctypes
+ * stub that drops into worker.py) is shown in INTEGRATION.md; this repo's own host mirror is
+ * style_transfer2_amd/engine.py.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a non-zero
+ * code on failure with a message available from st_last_error(); host buffers are caller-owned
+ * and are fully consumed/produced before the call returns; all device state is owned by the
+ * handle; one handle is driven by one host thread.  Images cross the boundary as HxWx3 RGB
+ * (uint8 or float32) exactly as in messages.py:89-110; tensors as contiguous NCHW float32.
+ */
+#ifndef ST2_H
+#define ST2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct st_ctx st_ctx;
+
+enum { ST_OK = 0, ST_ERR_ARG = 1, ST_ERR_STATE = 2, ST_ERR_HIP = 3 };
+enum { ST_OPT_NONE = 0, ST_OPT_ADAM = 1, ST_OPT_LBFGS = 2 };
+enum { ST_LAYER_CONV = 0, ST_LAYER_POOL = 1 };
+
+/* One layer of a VGG-shaped topology: Conv3x3(pad 1)+ReLU, or MaxPool 2x2/2 (Caffe ceil mode). */
+typedef struct st_layer_desc {
+    int kind;            /* ST_LAYER_CONV | ST_LAYER_POOL */
+    const char* name;    /* blob/layer name, e.g. "conv1_1" */
+    int cin, cout;       /* conv only */
+} st_layer_desc;
+
+const char* st_last_error(void);
+
+/* ---- model: replaces CaffeModel.__init__/reload_net (worker.py:36-61) ------------------------- */
+/* n_layers == 0 selects models/vgg19.prototxt (16 conv + 5 pool). device_id follows the `gpu`
+ * config key (worker.py:328): it is passed to hipSetDevice. */
+int st_create(st_ctx** out, int device_id, const st_layer_desc* layers, int n_layers);
+int st_destroy(st_ctx* ctx);
+/* weights of one conv layer, Caffe layout (Cout, Cin, 3, 3) + bias (Cout)  [caffe.Net(weights=)] */
+int st_load_conv_weights(st_ctx* ctx, const char* layer, const float* w, const float* bias);
+/* CaffeModel.layers (worker.py:73-75): blob names in network order, "data" first */
+int st_num_blobs(st_ctx* ctx);
+const char* st_blob_name(st_ctx* ctx, int index);
+int st_blob_shape(st_ctx* ctx, int index, int H, int W, int* c, int* h, int* w);
+
+/* ---- model test hooks: CaffeModel.forward / backward (worker.py:77-106) ----------------------- */
+/* runs the net on a preprocessed (1,3,H,W) image up to blob `last_blob` (-1: whole net) */
+int st_forward(st_ctx* ctx, const float* x_nchw, int H, int W, int last_blob);
+int st_get_blob(st_ctx* ctx, int index, float* out_chw);
+/* ranged backward with per-blob diff injection after st_forward; diffs[i] is (C,h,w) of blob
+ * blob_index[i]; writes d/d(data) as (3,H,W) */
+int st_backward(st_ctx* ctx, int n, const int* blob_index, const float* const* diffs, float* out_grad);
+/* gram_matrix (worker.py:109-114) of a blob of the last st_forward: out is C*C */
+int st_gram(st_ctx* ctx, int index, float* out);
+
+/* ---- image slots: StyleTransfer.set_input / set_content / set_style (worker.py:191-218) ------- */
+/* preprocess (worker.py:63-66) + upload.  is_u8: 1 = uint8 HWC, 0 = float32 HWC. */
+int st_set_input(st_ctx* ctx, const void* hwc, int H, int W, int is_u8);
+int st_set_content(st_ctx* ctx, const void* hwc, int H, int W, int is_u8);   /* + full forward, keeps all blobs */
+int st_set_style(st_ctx* ctx, const void* hwc, int H, int W, int is_u8);     /* + full forward, Gram of every blob */
+/* already-preprocessed NCHW variants (resample paths, worker.py:154-170) */
+int st_set_input_nchw(st_ctx* ctx, const float* x, int H, int W);
+int st_set_content_nchw(st_ctx* ctx, const float* x, int H, int W);
+int st_get_input_nchw(st_ctx* ctx, float* out);          /* current x, (3,H,W) */
+int st_input_shape(st_ctx* ctx, int* H, int* W);
+
+/* ---- objective: StyleTransfer.set_weights / reset / opfunc (worker.py:172-175,226-301) -------- */
+/* rows in DataFrame order; NaN cells allowed (treated as zero, worker.py:234). params = tv,
+ * tv_power, p, p_power (messages.py:147). */
+int st_set_weights(st_ctx* ctx, int n_rows, const int* blob_index, const float* content,
+                   const float* style, const float* deepdream, const double params[4]);
+int st_clear_norms(st_ctx* ctx);                          /* the `norms` half of reset() */
+/* number of trace scalars an evaluation produces: 6 per active layer + 8 */
+int st_trace_len(st_ctx* ctx);
+/* evaluates opfunc at the current input; out_grad (3,H,W) may be NULL (return_grad=False) */
+int st_opfunc(st_ctx* ctx, float* out_loss, float* out_grad, double* trace);
+
+/* ---- optimizers: optimizers.py:7-125 ------------------------------------------------------------ */
+int st_optimizer_reset(st_ctx* ctx, int kind, double step_size);   /* new optimizer instance */
+int st_optimizer_set_step(st_ctx* ctx, double step_size);
+int st_optimizer_kind(st_ctx* ctx);
+int st_objective_changed(st_ctx* ctx);
+/* Adam state for the host-side resample path (optimizers.py:29-40); arrays are (3,H,W) */
+int st_adam_get_state(st_ctx* ctx, float* m, float* v, int* items1, int* items2);
+int st_adam_set_state(st_ctx* ctx, const float* m, const float* v, int items1, int items2);
+/* one StyleTransfer.step (worker.py:303-310): optimizer step + deprocess.
+ * out_hwc (H,W,3 float32) and trace may be NULL: then nothing is copied back and the call does not
+ * synchronise (device-resident loop). */
+int st_step(st_ctx* ctx, float* out_hwc, double* trace, float* out_loss);
+int st_sync(st_ctx* ctx);
+
+/* ---- measurement ----------------------------------------------------------------------------------- */
+/* per-kernel-class HIP-event timing on the engine's own stream */
+int st_profile_enable(st_ctx* ctx, int on);
+int st_profile_num_classes(void);
+const char* st_profile_class_name(int cls);
+/* sums since the last call: launches, milliseconds, algorithmic FLOPs and bytes per class */
+int st_profile_read(st_ctx* ctx, long long* launches, double* ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ST2_H */

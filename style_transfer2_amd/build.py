@@ -1,0 +1,77 @@
+"""Builds libst2_hip.so (hand-written gfx950 kernels + engine + C ABI) in-tree with hipcc.
+
+The .so is git-ignored but travels to the GPU box with the repo snapshot.  hipcc cross-compiles
+for gfx950 without a GPU, so this also runs in the build container.
+"""
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(CSRC, '_obj')
+LIB = os.path.join(HERE, 'lib', 'libst2_hip.so')
+ARCH = 'gfx950'
+
+# (source, extra flags)
+SOURCES = (
+    ('conv3x3_mfma.hip', ()),
+    ('gram.hip', ()),
+    ('passes.hip', ('-ffp-contract=off',)),      # NumPy-like one-rounding-per-operation arithmetic
+    ('engine.cpp', ('-x', 'hip')),
+)
+HEADERS = ('st2_kernels.h', 'reduce.cuh', os.path.join('..', '..', 'include', 'st2.h'))
+
+
+def _hipcc():
+    path = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(path):
+        raise RuntimeError('hipcc not found: the HIP library cannot be built')
+    return path
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs, objs = [], []
+    for src, extra in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + '.o')
+        objs.append(o)
+        if force or _stale(o, [s] + headers + [os.path.abspath(__file__)]):
+            cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC',
+                   '-Wall', '-Wno-unused-result'] + list(extra) + ['-c', s, '-o', o]
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n%s\n%s' % (' '.join(cmd), r.stderr))
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for err in ex.map(run, jobs):
+            if verbose and err:
+                print(err, file=sys.stderr)
+    if jobs or force or _stale(LIB, objs):
+        run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_lib(force='--force' in sys.argv, verbose=True))

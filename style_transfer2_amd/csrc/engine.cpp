@@ -1,0 +1,1021 @@
+// The device-resident style-transfer engine behind include/st2.h.
+//
+// One st_ctx == one reference worker's model + StyleTransfer + optimizer (worker.py:32-315,
+// optimizers.py:7-125) with all tensors living in HBM.  The host only sequences launches on one
+// HIP stream; nothing crosses PCIe inside an iteration unless the caller asks for the iterate.
+#include "../../include/st2.h"
+#include "st2_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+using namespace st2;
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess)                                                                       \
+            return fail(ST_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define ST_TRY(expr)                    \
+    do {                                \
+        int r_ = (expr);                \
+        if (r_ != ST_OK) return r_;     \
+    } while (0)
+
+extern "C" const char* st_last_error(void) { return g_err; }
+
+// --------------------------------------------------------------------------------------- profiling
+enum ProfClass { P_CONV_FWD, P_CONV_DGRAD, P_POOL_FWD, P_POOL_BWD, P_GRAM, P_GRAM_REDUCE, P_STYLE_GRAD,
+                 P_LAYER_ELEM, P_IMAGE_PASS, P_FINALIZE, P_VECTOR, P_MISC, P_COUNT };
+static const char* kProfNames[P_COUNT] = {"conv3x3_fwd_mfma_f32", "conv3x3_dgrad_mfma_f32", "maxpool_fwd", "maxpool_bwd",
+                                          "gram_partial_mfma_f32", "gram_reduce", "style_grad_mfma_f32", "layer_elem",
+                                          "image_pass", "finalize", "vector_ops", "misc"};
+struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
+
+// ------------------------------------------------------------------------------------------- types
+struct Layer {
+    bool is_conv = false;
+    std::string name;
+    int cin = 0, cout = 0;
+    float *w_fwd = nullptr, *w_bwd = nullptr, *w_raw = nullptr, *bias = nullptr;
+    bool loaded = false;
+};
+
+struct ActSet {                    // activations of one forward geometry
+    int H = 0, W = 0;
+    std::vector<int> C, h, w;
+    std::vector<float*> data;      // data[0] is borrowed (the image itself)
+    int valid_to = -1;
+};
+
+struct ActiveLayer { int blob; float cw, sw, dw; bool c, s, d; };
+
+static const struct { int kind; const char* name; int cin, cout; } kVgg19[] = {
+    {0, "conv1_1", 3, 64}, {0, "conv1_2", 64, 64}, {1, "pool1", 0, 0},
+    {0, "conv2_1", 64, 128}, {0, "conv2_2", 128, 128}, {1, "pool2", 0, 0},
+    {0, "conv3_1", 128, 256}, {0, "conv3_2", 256, 256}, {0, "conv3_3", 256, 256}, {0, "conv3_4", 256, 256}, {1, "pool3", 0, 0},
+    {0, "conv4_1", 256, 512}, {0, "conv4_2", 512, 512}, {0, "conv4_3", 512, 512}, {0, "conv4_4", 512, 512}, {1, "pool4", 0, 0},
+    {0, "conv5_1", 512, 512}, {0, "conv5_2", 512, 512}, {0, "conv5_3", 512, 512}, {0, "conv5_4", 512, 512}, {1, "pool5", 0, 0},
+};
+
+static bool nonzero(float w) { return fabsf(w) > 1e-15f; }   // NaN compares false: worker.py:234
+
+struct st_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<Layer> topo;
+    std::vector<std::string> blob_names;
+    int nb = 0;                                    // number of blobs (= layers + 1)
+
+    ActSet act;                                    // geometry of input/content
+    // image state
+    int H = 0, W = 0;                              // input geometry (0 = no input)
+    float* x[2] = {nullptr, nullptr};
+    int cur = 0;
+    float* grad = nullptr;                         // combined gradient (opfunc / L-BFGS)
+    // content / style
+    int cH = 0, cW = 0;
+    std::vector<float*> content_feat;              // per blob
+    std::vector<float*> style_gram;                // per blob, C*C
+    bool have_content = false, have_style = false;
+    // objective
+    std::vector<ActiveLayer> rows;                 // every row of the weights table, in order
+    std::vector<ActiveLayer> active;               // rows with any non-zero weight
+    float tv_w = 1, tv_pow = 1, p_w = 1, p_pow = 1;   // worker.py:133 defaults
+    float* norms = nullptr;                        // [nb][3] on device
+    std::vector<char> norm_valid;                  // [nb*3]
+    // work buffers (input geometry)
+    std::vector<float*> inject;
+    float *diffA = nullptr, *diffB = nullptr, *stmp = nullptr;
+    size_t max_blob = 0;
+    float *gram_slabs = nullptr, *dbuf = nullptr;
+    size_t gram_slab_cap = 0;
+    std::vector<float*> layer_part;                // per blob: 5 * kMaxPartials
+    std::vector<float*> s2_part;                   // per blob: style-grad partial sums
+    std::vector<int> s2_cap;
+    std::vector<int> cnt;                          // per blob * 6 partial counts
+    float* image_part = nullptr;                   // 6 * kMaxPartials
+    int image_cnt = 0;
+    float* trace_dev = nullptr;
+    float* trace_host = nullptr;                   // pinned
+    int trace_len_last = 8;
+    float* hwc_dev = nullptr;
+    void* stage_dev = nullptr; size_t stage_cap = 0;
+    // optimizer
+    int opt_kind = ST_OPT_NONE;
+    double step_size = 1.0;
+    float *m = nullptr, *v = nullptr;
+    int items1 = 0, items2 = 0;
+    bool m_zero = true, v_zero = true;
+    // L-BFGS
+    static const int kCorr = 10;
+    float* hs[kCorr + 1] = {nullptr};              // ring of s vectors (+1 scratch slot)
+    float* hy[kCorr + 1] = {nullptr};
+    std::vector<int> order;                        // slot ids, oldest first
+    float* g_cur = nullptr; float* pvec = nullptr;
+    bool have_cur = false;
+    float* scal = nullptr;                         // device scalars: sy[11], alpha[11], tmp[8]
+    float* dot_part = nullptr;
+    float last_loss = 0.f;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+
+    int blob_c(int i) const { return act.C[i]; }
+};
+
+// ---------------------------------------------------------------------------------------- helpers
+static int dmalloc(float** p, size_t nfloats)
+{
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(nfloats, 1) * sizeof(float));
+    if (e != hipSuccess) return fail(ST_ERR_HIP, "hipMalloc(%zu floats): %s", nfloats, hipGetErrorString(e));
+    *p = (float*)q;
+    return ST_OK;
+}
+static void dfree(float*& p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+struct ProfScope {
+    st_ctx* c; int idx = -1;
+    ProfScope(st_ctx* ctx, int cls, double flops, double bytes) : c(ctx)
+    {
+        if (!c->prof_on) return;
+        auto get = [&]() {
+            if (c->ev_used == c->ev_pool.size()) {
+                hipEvent_t e;
+                (void)hipEventCreate(&e);
+                c->ev_pool.push_back(e);
+            }
+            return c->ev_pool[c->ev_used++];
+        };
+        ProfRec r{cls, get(), get(), flops, bytes};
+        (void)hipEventRecord(r.a, c->stream);
+        c->prof.push_back(r);
+        idx = (int)c->prof.size() - 1;
+    }
+    ~ProfScope()
+    {
+        if (idx >= 0) (void)hipEventRecord(c->prof[idx].b, c->stream);
+    }
+};
+
+static void shapes_for(const st_ctx* c, int H, int W, std::vector<int>& C, std::vector<int>& h, std::vector<int>& w)
+{
+    C.assign(c->nb, 0); h.assign(c->nb, 0); w.assign(c->nb, 0);
+    C[0] = 3; h[0] = H; w[0] = W;
+    for (int i = 1; i < c->nb; ++i) {
+        const Layer& L = c->topo[i - 1];
+        if (L.is_conv) { C[i] = L.cout; h[i] = h[i - 1]; w[i] = w[i - 1]; }
+        else { C[i] = C[i - 1]; h[i] = pooled_size(h[i - 1]); w[i] = pooled_size(w[i - 1]); }
+    }
+}
+
+static void act_free(ActSet& a)
+{
+    for (size_t i = 1; i < a.data.size(); ++i) dfree(a.data[i]);
+    a.data.clear();
+    a.H = a.W = 0;
+    a.valid_to = -1;
+}
+
+static int act_ensure(st_ctx* c, ActSet& a, int H, int W)
+{
+    if (a.H == H && a.W == W && !a.data.empty()) return ST_OK;
+    act_free(a);
+    shapes_for(c, H, W, a.C, a.h, a.w);
+    a.data.assign(c->nb, nullptr);
+    for (int i = 1; i < c->nb; ++i) ST_TRY(dmalloc(&a.data[i], (size_t)a.C[i] * a.h[i] * a.w[i]));
+    a.H = H; a.W = W;
+    return ST_OK;
+}
+
+static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
+{
+    a.data[0] = const_cast<float*>(x);
+    for (int i = 1; i <= last; ++i) {
+        const Layer& L = c->topo[i - 1];
+        if (L.is_conv) {
+            if (!L.loaded) return fail(ST_ERR_STATE, "weights of %s were never loaded", L.name.c_str());
+            ConvProblem p{};
+            p.in = a.data[i - 1]; p.wpack = L.w_fwd; p.bias = L.bias; p.out = a.data[i];
+            p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
+            const double px = (double)a.h[i] * a.w[i];
+            ProfScope ps(c, P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
+            HIP_TRY(launch_conv3x3(p, c->stream));
+        } else {
+            const double n_in = (double)a.C[i - 1] * a.h[i - 1] * a.w[i - 1];
+            ProfScope ps(c, P_POOL_FWD, 0, 4.0 * n_in * 1.25);
+            HIP_TRY(launch_maxpool_fwd(a.data[i - 1], a.data[i], a.C[i - 1], a.h[i - 1], a.w[i - 1], c->stream));
+        }
+    }
+    a.valid_to = last;
+    return ST_OK;
+}
+
+static int ensure_gram_bufs(st_ctx* c, int C, int hw, GramPlan& pl)
+{
+    pl = gram_plan(C, hw);
+    if (pl.slab_floats > c->gram_slab_cap) {
+        dfree(c->gram_slabs);
+        ST_TRY(dmalloc(&c->gram_slabs, pl.slab_floats));
+        c->gram_slab_cap = pl.slab_floats;
+    }
+    return ST_OK;
+}
+
+// G (or G - target) of blob data F -> out (C*C); optional sum-of-squares partials
+static int gram_into(st_ctx* c, const float* F, int C, int hw, const float* target, float* out, float* partial, int* n_partial)
+{
+    GramPlan pl;
+    ST_TRY(ensure_gram_bufs(c, C, hw, pl));
+    {
+        ProfScope ps(c, P_GRAM, 2.0 * C * C * (double)hw, 4.0 * C * (double)hw);
+        HIP_TRY(launch_gram_partial(F, c->gram_slabs, C, hw, pl, c->stream));
+    }
+    {
+        ProfScope ps(c, P_GRAM_REDUCE, 0, 4.0 * (double)pl.slab_floats);
+        HIP_TRY(launch_gram_reduce(c->gram_slabs, target, out, partial, n_partial, C, hw, pl, c->stream));
+    }
+    return ST_OK;
+}
+
+// backward chain from blob `top` whose diff is `cur` down to data; returns pointer in *out
+static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<const float*>& inj, const float** out)
+{
+    const ActSet& a = c->act;
+    const float* cur = top_diff;
+    for (int i = top; i >= 1; --i) {
+        const Layer& L = c->topo[i - 1];
+        const int below = i - 1;
+        float* dst = (cur == c->diffA) ? c->diffB : c->diffA;
+        const bool below_is_conv = below >= 1 && c->topo[below - 1].is_conv;
+        const float* mask_src = below_is_conv ? a.data[below] : nullptr;
+        const float* inject = inj[below];
+        if (L.is_conv) {
+            const double px = (double)a.h[i] * a.w[i];
+            ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
+            if (L.cin <= 4 && !mask_src) {
+                HIP_TRY(launch_conv3x3_dgrad_smallM(cur, L.w_raw, dst, inject, L.cout, L.cin, a.h[i], a.w[i], c->stream));
+            } else {
+                ConvProblem p{};
+                p.in = cur; p.wpack = L.w_bwd; p.bias = nullptr; p.out = dst;
+                p.mask_src = mask_src; p.inject = inject;
+                p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
+                HIP_TRY(launch_conv3x3(p, c->stream));
+            }
+        } else {
+            const double n_in = (double)a.C[below] * a.h[below] * a.w[below];
+            ProfScope ps(c, P_POOL_BWD, 0, 4.0 * n_in * 2.25);
+            HIP_TRY(launch_maxpool_bwd(cur, a.data[below], dst, inject, mask_src != nullptr, a.C[below], a.h[below], a.w[below], c->stream));
+        }
+        cur = dst;
+    }
+    *out = cur;
+    return ST_OK;
+}
+
+static int ensure_input_buffers(st_ctx* c, int H, int W)
+{
+    if (c->H == H && c->W == W && c->x[0]) return ST_OK;
+    const size_t n3 = (size_t)3 * H * W;
+    for (int i = 0; i < 2; ++i) { dfree(c->x[i]); ST_TRY(dmalloc(&c->x[i], n3)); }
+    dfree(c->grad); ST_TRY(dmalloc(&c->grad, n3));
+    dfree(c->m); dfree(c->v);
+    ST_TRY(dmalloc(&c->m, n3)); ST_TRY(dmalloc(&c->v, n3));
+    dfree(c->g_cur); dfree(c->pvec);
+    for (int i = 0; i <= st_ctx::kCorr; ++i) { dfree(c->hs[i]); dfree(c->hy[i]); }
+    dfree(c->hwc_dev); ST_TRY(dmalloc(&c->hwc_dev, n3));
+    c->H = H; c->W = W; c->cur = 0;
+    // work buffers that follow the input geometry
+    for (auto& p : c->inject) dfree(p);
+    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp);
+    std::vector<int> C, h, w;
+    shapes_for(c, H, W, C, h, w);
+    c->max_blob = 0;
+    for (int i = 0; i < c->nb; ++i) c->max_blob = std::max(c->max_blob, (size_t)C[i] * h[i] * w[i]);
+    return ST_OK;
+}
+
+static int stage_upload(st_ctx* c, const void* host, size_t bytes)
+{
+    if (bytes > c->stage_cap) {
+        if (c->stage_dev) (void)hipFree(c->stage_dev);
+        c->stage_dev = nullptr;
+        HIP_TRY(hipMalloc(&c->stage_dev, bytes));
+        c->stage_cap = bytes;
+    }
+    HIP_TRY(hipMemcpyAsync(c->stage_dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+    return ST_OK;
+}
+
+static int preprocess_into(st_ctx* c, const void* hwc, int H, int W, int is_u8, float* dst)
+{
+    if (!hwc || H <= 0 || W <= 0) return fail(ST_ERR_ARG, "bad image (%p, %d x %d)", hwc, H, W);
+    const size_t n = (size_t)H * W * 3;
+    ST_TRY(stage_upload(c, hwc, n * (is_u8 ? 1 : 4)));
+    ProfScope ps(c, P_MISC, 0, 0);
+    if (is_u8) HIP_TRY(launch_preprocess_u8((const uint8_t*)c->stage_dev, dst, H, W, c->stream));
+    else HIP_TRY(launch_preprocess_f32((const float*)c->stage_dev, dst, H, W, c->stream));
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------------ the objective
+static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad_out, bool adam, float* x_next)
+{
+    if (!c->x[0]) return fail(ST_ERR_STATE, "no input image");
+    ST_TRY(act_ensure(c, c->act, c->H, c->W));
+    ActSet& a = c->act;
+    int last = 0;
+    for (const ActiveLayer& al : c->active) last = std::max(last, al.blob);
+    for (const ActiveLayer& al : c->active) {
+        if (al.c && (!c->have_content || c->cH != c->H || c->cW != c->W))
+            return fail(ST_ERR_STATE, "content features missing or of a different size than the input");
+        if (al.s && !c->have_style) return fail(ST_ERR_STATE, "style Gram matrices missing");
+    }
+    ST_TRY(forward_range(c, a, x, last));
+
+    std::vector<const float*> inj(c->nb, nullptr);
+    std::fill(c->cnt.begin(), c->cnt.end(), 0);
+    for (const ActiveLayer& al : c->active) {
+        const int b = al.blob;
+        const int C = a.C[b], hw = a.h[b] * a.w[b];
+        const size_t n = (size_t)C * hw;
+        if (!c->inject[b]) ST_TRY(dmalloc(&c->inject[b], n));
+        if (!c->layer_part[b]) ST_TRY(dmalloc(&c->layer_part[b], 5 * kMaxPartials));
+        float* part = c->layer_part[b];
+        float* nrm = c->norms + b * 3;
+        int* cnt = &c->cnt[b * 6];
+        bool wrote = false;
+        if (al.c || al.d) {
+            LayerElemArgs e{};
+            e.feat = a.data[b]; e.target = al.c ? c->content_feat[b] : nullptr; e.inject = c->inject[b];
+            e.n = n; e.cn_coef = (float)(2.0 / (double)n); e.dn_coef = (float)(-2.0 / (double)n);
+            e.cw = al.cw; e.dw = al.dw; e.content = al.c; e.deepdream = al.d;
+            e.norm_c = nrm + 0; e.norm_d = nrm + 2;
+            e.part_d2 = part; e.part_gc2 = part + kMaxPartials; e.part_f2 = part + 2 * kMaxPartials; e.part_gd2 = part + 3 * kMaxPartials;
+            const bool need_norm = (al.c && !c->norm_valid[b * 3 + 0]) || (al.d && !c->norm_valid[b * 3 + 2]);
+            int np = 0;
+            if (need_norm) {      // first evaluation after reset(): norms are captured (worker.py:253-254,274-275)
+                e.write = 0;
+                { ProfScope ps(c, P_LAYER_ELEM, 0, 4.0 * n * (al.c ? 2 : 1)); HIP_TRY(launch_layer_elem(e, &np, c->stream)); }
+                ProfScope ps(c, P_FINALIZE, 0, 0);
+                if (al.c && !c->norm_valid[b * 3 + 0]) { HIP_TRY(launch_finalize_norm(e.part_gc2, np, (double)n, nrm + 0, c->stream)); c->norm_valid[b * 3 + 0] = 1; }
+                if (al.d && !c->norm_valid[b * 3 + 2]) { HIP_TRY(launch_finalize_norm(e.part_gd2, np, (double)n, nrm + 2, c->stream)); c->norm_valid[b * 3 + 2] = 1; }
+            }
+            e.write = 1;
+            { ProfScope ps(c, P_LAYER_ELEM, 0, 4.0 * n * (al.c ? 3 : 2)); HIP_TRY(launch_layer_elem(e, &np, c->stream)); }
+            cnt[0] = cnt[1] = cnt[2] = cnt[3] = np;
+            wrote = true;
+        }
+        if (al.s) {
+            if (!c->dbuf) ST_TRY(dmalloc(&c->dbuf, 1));
+            ST_TRY(gram_into(c, a.data[b], C, hw, c->style_gram[b], c->dbuf, part + 4 * kMaxPartials, &cnt[4]));
+            const float c2 = (float)(2.0 / ((double)C * C * (double)n));
+            const int ptiles = (hw + 255) / 256, nmt = C > 64 ? (C + 127) / 128 : 1;
+            const int need = ptiles * nmt;
+            if (c->s2_cap[b] < need) { dfree(c->s2_part[b]); ST_TRY(dmalloc(&c->s2_part[b], need)); c->s2_cap[b] = need; }
+            const double fl = 2.0 * C * C * (double)hw;
+            if (c->norm_valid[b * 3 + 1]) {
+                ProfScope ps(c, P_STYLE_GRAD, fl, 4.0 * n * 2);
+                HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->inject[b], c2, 1, al.sw, nrm + 1, wrote, c->s2_part[b], &cnt[5], C, hw, c->stream));
+            } else {              // first evaluation: S unscaled -> norm -> saxpy (worker.py:265-269)
+                if (!c->stmp) ST_TRY(dmalloc(&c->stmp, c->max_blob));
+                { ProfScope ps(c, P_STYLE_GRAD, fl, 4.0 * n * 2);
+                  HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->stmp, c2, 0, al.sw, nrm + 1, 0, c->s2_part[b], &cnt[5], C, hw, c->stream)); }
+                { ProfScope ps(c, P_FINALIZE, 0, 0);
+                  HIP_TRY(launch_finalize_norm(c->s2_part[b], cnt[5], (double)n, nrm + 1, c->stream)); }
+                c->norm_valid[b * 3 + 1] = 1;
+                ProfScope ps(c, P_VECTOR, 0, 4.0 * n * 3);
+                HIP_TRY(launch_scaled_accumulate(c->stmp, c->inject[b], al.sw, nrm + 1, wrote, n, c->stream));
+            }
+        }
+        inj[b] = c->inject[b];
+    }
+
+    const float* scd = nullptr;
+    if (want_grad && !c->active.empty()) {
+        if (!c->diffA) { ST_TRY(dmalloc(&c->diffA, c->max_blob)); ST_TRY(dmalloc(&c->diffB, c->max_blob)); }
+        if (last == 0) scd = inj[0];
+        else {
+            std::vector<const float*> below = inj;
+            ST_TRY(backward_chain(c, last, inj[last], below, &scd));
+        }
+    }
+
+    {
+        ImagePassArgs ip{};
+        ip.x = x; ip.scd = scd; ip.grad = want_grad ? grad_out : nullptr;
+        ip.C = 3; ip.H = c->H; ip.W = c->W;
+        ip.tv_w = c->tv_w; ip.tv_beta = c->tv_pow; ip.p_w = c->p_w; ip.p_pow = c->p_pow;
+        ip.partial = c->image_part;
+        if (adam) {
+            // utils.py:58-64: python doubles are rounded to fp32 when they meet the fp32 arrays
+            ip.x_out = x_next; ip.m = c->m; ip.v = c->v;
+            ip.d1 = (float)0.9; ip.c1 = (float)(1 - 0.9); ip.d2 = (float)0.999; ip.c2 = (float)(1 - 0.999);
+            ip.corr1 = (float)(1 - pow(0.9, c->items1)); ip.corr2 = (float)(1 - pow(0.999, c->items2));
+            ip.step = (float)c->step_size;
+            ip.m_is_zero = c->m_zero; ip.v_is_zero = c->v_zero;
+        }
+        const double n3 = 3.0 * c->H * c->W;
+        ProfScope ps(c, P_IMAGE_PASS, 0, 4.0 * n3 * (adam ? 7 : 3));
+        HIP_TRY(launch_image_pass(ip, &c->image_cnt, c->stream));
+    }
+
+    {
+        TraceArgs t{};
+        t.n_layers = (int)c->active.size();
+        for (int l = 0; l < t.n_layers; ++l) {
+            const ActiveLayer& al = c->active[l];
+            const int b = al.blob;
+            TraceLayer& L = t.layer[l];
+            L.content = al.c; L.style = al.s; L.deepdream = al.d;
+            L.cw = al.cw; L.sw = al.sw; L.dw = al.dw;
+            L.n = (double)a.C[b] * a.h[b] * a.w[b];
+            L.gram_n = (double)a.C[b] * a.C[b];
+            for (int k = 0; k < 5; ++k) { L.part[k] = c->layer_part[b] + k * kMaxPartials; L.count[k] = c->cnt[b * 6 + k]; }
+            L.part[5] = c->s2_part[b]; L.count[5] = c->cnt[b * 6 + 5];
+            L.norm = c->norms + b * 3;
+        }
+        t.image_part = c->image_part; t.image_count = c->image_cnt; t.image_n = 3.0 * c->H * c->W;
+        t.tv_w = c->tv_w; t.p_w = c->p_w; t.p_pow = c->p_pow; t.have_grad = want_grad;
+        t.out = c->trace_dev;
+        c->trace_len_last = t.n_layers * 6 + 8;
+        ProfScope ps(c, P_FINALIZE, 0, 0);
+        HIP_TRY(launch_finalize_trace(t, c->stream));
+    }
+    return ST_OK;
+}
+
+static int read_trace(st_ctx* c, double* trace, float* loss)
+{
+    const int n = c->trace_len_last;
+    HIP_TRY(hipMemcpyAsync(c->trace_host, c->trace_dev, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (trace) for (int i = 0; i < n; ++i) trace[i] = c->trace_host[i];
+    c->last_loss = c->trace_host[n - 2];
+    if (loss) *loss = c->last_loss;
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------------------ L-BFGS
+static int lbfgs_alloc(st_ctx* c)
+{
+    const size_t n3 = (size_t)3 * c->H * c->W;
+    if (!c->g_cur) ST_TRY(dmalloc(&c->g_cur, n3));
+    if (!c->pvec) ST_TRY(dmalloc(&c->pvec, n3));
+    for (int i = 0; i <= st_ctx::kCorr; ++i) {
+        if (!c->hs[i]) ST_TRY(dmalloc(&c->hs[i], n3));
+        if (!c->hy[i]) ST_TRY(dmalloc(&c->hy[i], n3));
+    }
+    return ST_OK;
+}
+
+static int lbfgs_step(st_ctx* c)
+{
+    ST_TRY(lbfgs_alloc(c));
+    const size_t n = (size_t)3 * c->H * c->W;
+    float* x = c->x[c->cur];
+    float* sy = c->scal;            // [11] by slot
+    float* alpha = c->scal + 16;    // [11] by slot
+    float* tmp = c->scal + 32;      // scratch scalars
+    hipStream_t s = c->stream;
+    if (!c->have_cur) {             // optimizers.py:64-65
+        ST_TRY(eval_objective(c, x, true, c->g_cur, false, nullptr));
+        c->have_cur = true;
+    }
+    ProfScope* ps = new ProfScope(c, P_VECTOR, 0, 0);
+    // p = inv_hv(grad): optimizers.py:89-108
+    HIP_TRY(hipMemcpyAsync(c->pvec, c->g_cur, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int k = (int)c->order.size() - 1; k >= 0; --k) {
+        const int slot = c->order[k];
+        HIP_TRY(launch_dot(c->hs[slot], c->pvec, n, c->dot_part, tmp, s));
+        HIP_TRY(launch_scalar_op(kOpDiv, tmp, sy + slot, nullptr, 0.f, alpha + slot, s));
+        HIP_TRY(launch_axpy_dev(alpha + slot, -1.f, c->hy[slot], c->pvec, n, s));
+    }
+    if (!c->order.empty()) {
+        const int slot = c->order.back();
+        HIP_TRY(launch_dot(c->hy[slot], c->hy[slot], n, c->dot_part, tmp, s));
+        HIP_TRY(launch_scalar_op(kOpDivInv, sy + slot, tmp, nullptr, 0.f, tmp + 1, s));
+        HIP_TRY(launch_scale_dev(tmp + 1, 1.f, c->pvec, c->pvec, n, s));
+    } else {
+        HIP_TRY(launch_dot(c->pvec, c->pvec, n, c->dot_part, tmp, s));
+        HIP_TRY(launch_scalar_op(kOpRsqrtMean, tmp, nullptr, nullptr, (float)n, tmp + 1, s));
+        HIP_TRY(launch_scale_dev(tmp + 1, -1.f, c->pvec, c->pvec, n, s));
+    }
+    for (size_t k = 0; k < c->order.size(); ++k) {
+        const int slot = c->order[k];
+        HIP_TRY(launch_dot(c->hy[slot], c->pvec, n, c->dot_part, tmp, s));
+        HIP_TRY(launch_scalar_op(kOpSubDiv, tmp, sy + slot, alpha + slot, 0.f, tmp + 1, s));
+        HIP_TRY(launch_axpy_dev(tmp + 1, 1.f, c->hs[slot], c->pvec, n, s));
+    }
+    // free slot for the new pair
+    int slot = -1;
+    for (int i = 0; i <= st_ctx::kCorr && slot < 0; ++i)
+        if (std::find(c->order.begin(), c->order.end(), i) == c->order.end()) slot = i;
+    // s = -step * p ; x += s
+    HIP_TRY(launch_lincomb((float)(-c->step_size), c->pvec, 0.f, nullptr, c->hs[slot], n, s));
+    HIP_TRY(launch_lincomb(1.f, x, 1.f, c->hs[slot], x, n, s));
+    delete ps;
+    // new loss / grad
+    ST_TRY(eval_objective(c, x, true, c->grad, false, nullptr));
+    ps = new ProfScope(c, P_VECTOR, 0, 0);
+    HIP_TRY(launch_lincomb(1.f, c->grad, -1.f, c->g_cur, c->hy[slot], n, s));       // y = grad - self.grad
+    HIP_TRY(launch_dot(c->hs[slot], c->hy[slot], n, c->dot_part, sy + slot, s));
+    std::swap(c->g_cur, c->grad);
+    delete ps;
+    float sy_host = 0.f;            // the only host decision of the step (optimizers.py:82)
+    HIP_TRY(hipMemcpyAsync(&sy_host, sy + slot, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (sy_host > 1e-10f) c->order.push_back(slot);
+    if ((int)c->order.size() > st_ctx::kCorr) c->order.erase(c->order.begin());
+    return ST_OK;
+}
+
+// ------------------------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int st_create(st_ctx** out, int device_id, const st_layer_desc* layers, int n_layers)
+{
+    if (!out) return fail(ST_ERR_ARG, "out is NULL");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(ST_ERR_HIP, "no HIP device visible");
+    if (device_id < 0 || device_id >= ndev) return fail(ST_ERR_ARG, "device %d out of range (%d visible)", device_id, ndev);
+    HIP_TRY(hipSetDevice(device_id));
+    st_ctx* c = new st_ctx();
+    c->device = device_id;
+    if (n_layers <= 0) {
+        for (const auto& l : kVgg19) {
+            Layer L; L.is_conv = l.kind == 0; L.name = l.name; L.cin = l.cin; L.cout = l.cout;
+            c->topo.push_back(L);
+        }
+    } else {
+        int cprev = 3;
+        for (int i = 0; i < n_layers; ++i) {
+            Layer L; L.is_conv = layers[i].kind == ST_LAYER_CONV; L.name = layers[i].name ? layers[i].name : "";
+            if (L.is_conv) {
+                L.cin = layers[i].cin; L.cout = layers[i].cout;
+                if (L.cin != cprev || L.cout <= 0) { delete c; return fail(ST_ERR_ARG, "layer %s: cin %d does not follow %d", L.name.c_str(), L.cin, cprev); }
+                cprev = L.cout;
+            }
+            c->topo.push_back(L);
+        }
+    }
+    if ((int)c->topo.size() + 1 > kMaxTraceLayers) { delete c; return fail(ST_ERR_ARG, "too many layers"); }
+    c->blob_names.push_back("data");
+    for (const Layer& L : c->topo) c->blob_names.push_back(L.name);
+    c->nb = (int)c->blob_names.size();
+    HIP_TRY(hipStreamCreate(&c->stream));
+    c->content_feat.assign(c->nb, nullptr);
+    c->style_gram.assign(c->nb, nullptr);
+    c->inject.assign(c->nb, nullptr);
+    c->layer_part.assign(c->nb, nullptr);
+    c->s2_part.assign(c->nb, nullptr);
+    c->s2_cap.assign(c->nb, 0);
+    c->cnt.assign(c->nb * 6, 0);
+    c->norm_valid.assign(c->nb * 3, 0);
+    ST_TRY(dmalloc(&c->norms, c->nb * 3));
+    ST_TRY(dmalloc(&c->image_part, 6 * kMaxPartials));
+    ST_TRY(dmalloc(&c->trace_dev, kMaxTraceLayers * 6 + 8));
+    ST_TRY(dmalloc(&c->scal, 64));
+    ST_TRY(dmalloc(&c->dot_part, kMaxPartials));
+    HIP_TRY(hipHostMalloc((void**)&c->trace_host, (kMaxTraceLayers * 6 + 8) * sizeof(float), 0));
+    // worker.py:129-133: all-ones weights over every blob until SetWeights arrives
+    for (int b = 0; b < c->nb; ++b) c->rows.push_back(ActiveLayer{b, 1.f, 1.f, 1.f, true, true, true});
+    c->active = c->rows;
+    *out = c;
+    return ST_OK;
+}
+
+int st_destroy(st_ctx* c)
+{
+    if (!c) return ST_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); }
+    act_free(c->act);
+    for (int i = 0; i < 2; ++i) dfree(c->x[i]);
+    dfree(c->grad); dfree(c->m); dfree(c->v); dfree(c->g_cur); dfree(c->pvec);
+    for (int i = 0; i <= st_ctx::kCorr; ++i) { dfree(c->hs[i]); dfree(c->hy[i]); }
+    for (auto& p : c->content_feat) dfree(p);
+    for (auto& p : c->style_gram) dfree(p);
+    for (auto& p : c->inject) dfree(p);
+    for (auto& p : c->layer_part) dfree(p);
+    for (auto& p : c->s2_part) dfree(p);
+    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->dbuf);
+    dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->scal); dfree(c->dot_part); dfree(c->hwc_dev);
+    if (c->stage_dev) (void)hipFree(c->stage_dev);
+    if (c->trace_host) (void)hipHostFree(c->trace_host);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return ST_OK;
+}
+
+int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const float* bias)
+{
+    if (!c || !layer || !w) return fail(ST_ERR_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    for (Layer& L : c->topo) {
+        if (!L.is_conv || L.name != layer) continue;
+        const size_t nf = conv_pack_floats(L.cin, L.cout), nb = conv_pack_floats(L.cout, L.cin);
+        std::vector<float> pf(nf), pb(nb), bp(conv_mpad(L.cout), 0.f);
+        pack_conv_weights_fwd(w, L.cout, L.cin, pf.data());
+        pack_conv_weights_dgrad(w, L.cout, L.cin, pb.data());
+        if (bias) memcpy(bp.data(), bias, L.cout * sizeof(float));
+        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias);
+        ST_TRY(dmalloc(&L.w_fwd, nf)); ST_TRY(dmalloc(&L.w_bwd, nb));
+        ST_TRY(dmalloc(&L.w_raw, (size_t)L.cout * L.cin * 9)); ST_TRY(dmalloc(&L.bias, bp.size()));
+        HIP_TRY(hipMemcpy(L.w_fwd, pf.data(), nf * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(L.w_bwd, pb.data(), nb * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(L.w_raw, w, (size_t)L.cout * L.cin * 9 * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(L.bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+        L.loaded = true;
+        return ST_OK;
+    }
+    return fail(ST_ERR_ARG, "no conv layer named %s", layer);
+}
+
+int st_num_blobs(st_ctx* c) { return c ? c->nb : 0; }
+const char* st_blob_name(st_ctx* c, int i) { return (c && i >= 0 && i < c->nb) ? c->blob_names[i].c_str() : nullptr; }
+
+int st_blob_shape(st_ctx* c, int index, int H, int W, int* oc, int* oh, int* ow)
+{
+    if (!c || index < 0 || index >= c->nb) return fail(ST_ERR_ARG, "bad blob index %d", index);
+    std::vector<int> C, h, w;
+    shapes_for(c, H, W, C, h, w);
+    if (oc) *oc = C[index];
+    if (oh) *oh = h[index];
+    if (ow) *ow = w[index];
+    return ST_OK;
+}
+
+// ---- model test hooks
+int st_forward(st_ctx* c, const float* x_nchw, int H, int W, int last_blob)
+{
+    if (!c || !x_nchw || H <= 0 || W <= 0) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    ST_TRY(ensure_input_buffers(c, H, W));
+    ST_TRY(act_ensure(c, c->act, H, W));
+    HIP_TRY(hipMemcpyAsync(c->x[c->cur], x_nchw, (size_t)3 * H * W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    if (last_blob < 0 || last_blob >= c->nb) last_blob = c->nb - 1;
+    ST_TRY(forward_range(c, c->act, c->x[c->cur], last_blob));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
+int st_get_blob(st_ctx* c, int index, float* out)
+{
+    if (!c || index < 0 || index >= c->nb || !out) return fail(ST_ERR_ARG, "bad argument");
+    if (index > c->act.valid_to) return fail(ST_ERR_STATE, "blob %d was not computed by the last forward", index);
+    const size_t n = (size_t)c->act.C[index] * c->act.h[index] * c->act.w[index];
+    HIP_TRY(hipMemcpy(out, c->act.data[index], n * sizeof(float), hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int st_backward(st_ctx* c, int n, const int* blob_index, const float* const* diffs, float* out_grad)
+{
+    if (!c || !out_grad || n < 0) return fail(ST_ERR_ARG, "bad argument");
+    if (c->act.valid_to < 0) return fail(ST_ERR_STATE, "st_forward first");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n3 = (size_t)3 * c->H * c->W;
+    std::vector<const float*> inj(c->nb, nullptr);
+    int top = -1;
+    for (int i = 0; i < n; ++i) {
+        const int b = blob_index[i];
+        if (b < 0 || b > c->act.valid_to) return fail(ST_ERR_ARG, "diff for blob %d which the last forward did not reach", b);
+        const size_t nb = (size_t)c->act.C[b] * c->act.h[b] * c->act.w[b];
+        if (!c->inject[b]) ST_TRY(dmalloc(&c->inject[b], nb));
+        HIP_TRY(hipMemcpyAsync(c->inject[b], diffs[i], nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        inj[b] = c->inject[b];
+        top = std::max(top, b);
+    }
+    if (top < 0) { memset(out_grad, 0, n3 * sizeof(float)); return ST_OK; }
+    if (!c->diffA) { ST_TRY(dmalloc(&c->diffA, c->max_blob)); ST_TRY(dmalloc(&c->diffB, c->max_blob)); }
+    const float* g = inj[0];
+    if (top > 0) ST_TRY(backward_chain(c, top, inj[top], inj, &g));
+    HIP_TRY(hipMemcpyAsync(out_grad, g, n3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
+int st_gram(st_ctx* c, int index, float* out)
+{
+    if (!c || index < 0 || index >= c->nb || !out) return fail(ST_ERR_ARG, "bad argument");
+    if (index > c->act.valid_to) return fail(ST_ERR_STATE, "blob %d was not computed by the last forward", index);
+    HIP_TRY(hipSetDevice(c->device));
+    const int C = c->act.C[index], hw = c->act.h[index] * c->act.w[index];
+    float* g = nullptr;
+    ST_TRY(dmalloc(&g, (size_t)C * C));
+    int r = gram_into(c, c->act.data[index], C, hw, nullptr, g, nullptr, nullptr);
+    if (r == ST_OK) {
+        hipError_t e = hipMemcpyAsync(out, g, (size_t)C * C * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) r = fail(ST_ERR_HIP, "gram copy: %s", hipGetErrorString(e));
+    }
+    dfree(g);
+    return r;
+}
+
+// ---- image slots
+static int set_input_common(st_ctx* c, int H, int W)
+{
+    const bool reshaped = !(c->H == H && c->W == W && c->x[0]);
+    ST_TRY(ensure_input_buffers(c, H, W));
+    if (reshaped) {            // every size-dependent optimizer tensor starts from zero
+        c->m_zero = c->v_zero = true;
+        c->order.clear();
+        c->have_cur = false;
+    }
+    return ST_OK;
+}
+
+int st_set_input(st_ctx* c, const void* hwc, int H, int W, int is_u8)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    ST_TRY(set_input_common(c, H, W));
+    ST_TRY(preprocess_into(c, hwc, H, W, is_u8, c->x[c->cur]));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
+int st_set_input_nchw(st_ctx* c, const float* x, int H, int W)
+{
+    if (!c || !x || H <= 0 || W <= 0) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    ST_TRY(set_input_common(c, H, W));
+    HIP_TRY(hipMemcpy(c->x[c->cur], x, (size_t)3 * H * W * sizeof(float), hipMemcpyHostToDevice));
+    return ST_OK;
+}
+
+int st_get_input_nchw(st_ctx* c, float* out)
+{
+    if (!c || !out || !c->x[0]) return fail(ST_ERR_STATE, "no input image");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->x[c->cur], (size_t)3 * c->H * c->W * sizeof(float), hipMemcpyDeviceToHost));
+    return ST_OK;
+}
+
+int st_input_shape(st_ctx* c, int* H, int* W)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    if (H) *H = c->H;
+    if (W) *W = c->W;
+    return ST_OK;
+}
+
+static int content_from_device(st_ctx* c, const float* xdev, int H, int W)
+{
+    ST_TRY(act_ensure(c, c->act, H, W));
+    ST_TRY(forward_range(c, c->act, xdev, c->nb - 1));
+    for (int i = 0; i < c->nb; ++i) {
+        const size_t n = (size_t)c->act.C[i] * c->act.h[i] * c->act.w[i];
+        if (c->cH != H || c->cW != W || !c->content_feat[i]) { dfree(c->content_feat[i]); ST_TRY(dmalloc(&c->content_feat[i], n)); }
+        HIP_TRY(hipMemcpyAsync(c->content_feat[i], c->act.data[i], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->cH = H; c->cW = W;
+    c->have_content = true;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
+int st_set_content(st_ctx* c, const void* hwc, int H, int W, int is_u8)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    float* tmp = nullptr;
+    ST_TRY(dmalloc(&tmp, (size_t)3 * H * W));
+    int r = preprocess_into(c, hwc, H, W, is_u8, tmp);
+    if (r == ST_OK) r = content_from_device(c, tmp, H, W);
+    (void)hipStreamSynchronize(c->stream);
+    dfree(tmp);
+    return r;
+}
+
+int st_set_content_nchw(st_ctx* c, const float* x, int H, int W)
+{
+    if (!c || !x || H <= 0 || W <= 0) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    float* tmp = nullptr;
+    ST_TRY(dmalloc(&tmp, (size_t)3 * H * W));
+    int r = ST_OK;
+    if (hipMemcpy(tmp, x, (size_t)3 * H * W * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) r = fail(ST_ERR_HIP, "content upload failed");
+    if (r == ST_OK) r = content_from_device(c, tmp, H, W);
+    (void)hipStreamSynchronize(c->stream);
+    dfree(tmp);
+    return r;
+}
+
+int st_set_style(st_ctx* c, const void* hwc, int H, int W, int is_u8)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    float* tmp = nullptr;
+    ST_TRY(dmalloc(&tmp, (size_t)3 * H * W));
+    ActSet aux;
+    ActSet* a = &aux;
+    const bool same = c->act.H == H && c->act.W == W && !c->act.data.empty();
+    if (same) a = &c->act;
+    int r = preprocess_into(c, hwc, H, W, is_u8, tmp);
+    if (r == ST_OK) r = act_ensure(c, *a, H, W);
+    if (r == ST_OK) r = forward_range(c, *a, tmp, c->nb - 1);
+    for (int i = 0; i < c->nb && r == ST_OK; ++i) {
+        const int C = a->C[i], hw = a->h[i] * a->w[i];
+        if (!c->style_gram[i]) r = dmalloc(&c->style_gram[i], (size_t)C * C);
+        if (r == ST_OK) r = gram_into(c, a->data[i], C, hw, nullptr, c->style_gram[i], nullptr, nullptr);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    if (!same) act_free(aux);
+    else c->act.valid_to = -1;
+    dfree(tmp);
+    if (r == ST_OK) c->have_style = true;
+    return r;
+}
+
+// ---- objective
+int st_set_weights(st_ctx* c, int n_rows, const int* blob_index, const float* content, const float* style,
+                   const float* deepdream, const double params[4])
+{
+    if (!c || n_rows < 0 || (n_rows && (!blob_index || !content || !style || !deepdream)) || !params)
+        return fail(ST_ERR_ARG, "bad argument");
+    std::vector<ActiveLayer> rows;
+    for (int i = 0; i < n_rows; ++i) {
+        const int b = blob_index[i];
+        if (b < 0 || b >= c->nb) return fail(ST_ERR_ARG, "row %d names blob %d", i, b);
+        rows.push_back(ActiveLayer{b, content[i], style[i], deepdream[i], nonzero(content[i]), nonzero(style[i]), nonzero(deepdream[i])});
+    }
+    c->rows = rows;
+    c->active.clear();
+    for (const ActiveLayer& r : rows) if (r.c || r.s || r.d) c->active.push_back(r);
+    c->tv_w = (float)params[0]; c->tv_pow = (float)params[1]; c->p_w = (float)params[2]; c->p_pow = (float)params[3];
+    return ST_OK;
+}
+
+int st_clear_norms(st_ctx* c)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    std::fill(c->norm_valid.begin(), c->norm_valid.end(), 0);
+    return ST_OK;
+}
+
+int st_trace_len(st_ctx* c) { return c ? (int)c->active.size() * 6 + 8 : 0; }
+
+int st_opfunc(st_ctx* c, float* out_loss, float* out_grad, double* trace)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    ST_TRY(eval_objective(c, c->x[c->cur], out_grad != nullptr, c->grad, false, nullptr));
+    if (out_grad) HIP_TRY(hipMemcpyAsync(out_grad, c->grad, (size_t)3 * c->H * c->W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return read_trace(c, trace, out_loss);
+}
+
+// ---- optimizers
+int st_optimizer_reset(st_ctx* c, int kind, double step_size)
+{
+    if (!c || (kind != ST_OPT_ADAM && kind != ST_OPT_LBFGS)) return fail(ST_ERR_ARG, "bad optimizer kind %d", kind);
+    c->opt_kind = kind;
+    c->step_size = step_size;
+    c->items1 = c->items2 = 0;
+    c->m_zero = c->v_zero = true;
+    c->order.clear();
+    c->have_cur = false;
+    return ST_OK;
+}
+
+int st_optimizer_set_step(st_ctx* c, double step_size)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    c->step_size = step_size;
+    return ST_OK;
+}
+
+int st_optimizer_kind(st_ctx* c) { return c ? c->opt_kind : ST_OPT_NONE; }
+
+int st_objective_changed(st_ctx* c)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    if (c->opt_kind == ST_OPT_ADAM) {            // optimizers.py:42-46: t = 0, g1.clear(); g2 persists
+        c->items1 = 0;
+        c->m_zero = true;
+    } else if (c->opt_kind == ST_OPT_LBFGS) {    // optimizers.py:121-125
+        c->order.clear();
+        c->have_cur = false;
+    }
+    return ST_OK;
+}
+
+int st_adam_get_state(st_ctx* c, float* m, float* v, int* items1, int* items2)
+{
+    if (!c || !c->x[0]) return fail(ST_ERR_STATE, "no input image");
+    const size_t bytes = (size_t)3 * c->H * c->W * sizeof(float);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (m) { if (c->m_zero) memset(m, 0, bytes); else HIP_TRY(hipMemcpy(m, c->m, bytes, hipMemcpyDeviceToHost)); }
+    if (v) { if (c->v_zero) memset(v, 0, bytes); else HIP_TRY(hipMemcpy(v, c->v, bytes, hipMemcpyDeviceToHost)); }
+    if (items1) *items1 = c->items1;
+    if (items2) *items2 = c->items2;
+    return ST_OK;
+}
+
+int st_adam_set_state(st_ctx* c, const float* m, const float* v, int items1, int items2)
+{
+    if (!c || !c->x[0]) return fail(ST_ERR_STATE, "no input image");
+    const size_t bytes = (size_t)3 * c->H * c->W * sizeof(float);
+    if (m) { HIP_TRY(hipMemcpy(c->m, m, bytes, hipMemcpyHostToDevice)); c->m_zero = false; } else c->m_zero = true;
+    if (v) { HIP_TRY(hipMemcpy(c->v, v, bytes, hipMemcpyHostToDevice)); c->v_zero = false; } else c->v_zero = true;
+    c->items1 = items1; c->items2 = items2;
+    return ST_OK;
+}
+
+int st_step(st_ctx* c, float* out_hwc, double* trace, float* out_loss)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    if (!c->x[0]) return fail(ST_ERR_STATE, "no input image");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->opt_kind == ST_OPT_ADAM) {
+        c->items1 += 1; c->items2 += 1;          // DecayingMean.__call__(item), utils.py:58-61
+        ST_TRY(eval_objective(c, c->x[c->cur], true, nullptr, true, c->x[c->cur ^ 1]));
+        c->cur ^= 1;
+        c->m_zero = c->v_zero = false;
+    } else if (c->opt_kind == ST_OPT_LBFGS) {
+        ST_TRY(lbfgs_step(c));
+    } else {
+        return fail(ST_ERR_STATE, "no optimizer: call st_optimizer_reset first");
+    }
+    if (out_hwc) {
+        { ProfScope ps(c, P_MISC, 0, 0); HIP_TRY(launch_deprocess(c->x[c->cur], c->hwc_dev, c->H, c->W, c->stream)); }
+        HIP_TRY(hipMemcpyAsync(out_hwc, c->hwc_dev, (size_t)3 * c->H * c->W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    if (out_hwc || trace || out_loss) return read_trace(c, trace, out_loss);
+    return ST_OK;
+}
+
+int st_sync(st_ctx* c)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
+// ---- measurement
+int st_profile_enable(st_ctx* c, int on)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->prof_on = on != 0;
+    c->prof.clear();
+    c->ev_used = 0;
+    return ST_OK;
+}
+
+int st_profile_num_classes(void) { return P_COUNT; }
+const char* st_profile_class_name(int cls) { return (cls >= 0 && cls < P_COUNT) ? kProfNames[cls] : nullptr; }
+
+int st_profile_read(st_ctx* c, long long* launches, double* ms, double* flops, double* bytes)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < P_COUNT; ++i) {
+        if (launches) launches[i] = 0;
+        if (ms) ms[i] = 0;
+        if (flops) flops[i] = 0;
+        if (bytes) bytes[i] = 0;
+    }
+    for (const ProfRec& r : c->prof) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        if (launches) launches[r.cls] += 1;
+        if (ms) ms[r.cls] += t;
+        if (flops) flops[r.cls] += r.flops;
+        if (bytes) bytes[r.cls] += r.bytes;
+    }
+    c->prof.clear();
+    c->ev_used = 0;
+    return ST_OK;
+}
+
+}  // extern "C"

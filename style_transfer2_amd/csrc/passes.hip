@@ -1,0 +1,469 @@
+// HBM-bound passes of the style-transfer inner loop (everything that is not a GEMM).
+// Built with -ffp-contract=off so that the elementwise fp32 arithmetic rounds like the
+// reference's NumPy expressions (one IEEE operation per NumPy operation, same order).
+//
+//   max pool fwd/bwd            models/vgg19.prototxt:45-55 ...  (Caffe ceil mode, first max)
+//   content / deep-dream terms  worker.py:249-256, 271-277
+//   TV + p-norm + combine + Adam  utils.py:285-304, worker.py:279-297, optimizers.py:20-27
+//   pre / deprocess             worker.py:63-71
+//   trace scalars               worker.py:236-301, utils.py:257-282
+//   BLAS-1 for L-BFGS           utils.py:29-46, optimizers.py:62-108
+#include "st2_kernels.h"
+#include "reduce.cuh"
+#include <float.h>
+#include <math.h>
+
+namespace st2 {
+
+int pooled_size(int n)
+{
+    int q = (n - 2 + 1) / 2;
+    if (n - 2 < 0) q = 0;
+    return q + 1;
+}
+
+// ------------------------------------------------------------------------------------------ pool
+__global__ __launch_bounds__(256) void maxpool_fwd_k(const float* __restrict__ in, float* __restrict__ out,
+                                                     int C, int H, int W, int Ho, int Wo)
+{
+    const size_t total = (size_t)C * Ho * Wo;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int px = (int)(idx % Wo);
+        const int py = (int)((idx / Wo) % Ho);
+        const int c = (int)(idx / ((size_t)Wo * Ho));
+        const float* p = in + (size_t)c * H * W;
+        const int r0 = 2 * py, c0 = 2 * px;
+        float best = -FLT_MAX;
+#pragma unroll
+        for (int dr = 0; dr < 2; ++dr)
+#pragma unroll
+            for (int dc = 0; dc < 2; ++dc) {
+                const int r = r0 + dr, cc = c0 + dc;
+                if (r < H && cc < W) {
+                    const float v = p[(size_t)r * W + cc];
+                    if (v > best) best = v;
+                }
+            }
+        out[idx] = best;
+    }
+}
+
+hipError_t launch_maxpool_fwd(const float* in, float* out, int C, int H, int W, hipStream_t s)
+{
+    const int Ho = pooled_size(H), Wo = pooled_size(W);
+    const size_t total = (size_t)C * Ho * Wo;
+    maxpool_fwd_k<<<reduce_grid(total, 256, 65536), 256, 0, s>>>(in, out, C, H, W, Ho, Wo);
+    return hipGetLastError();
+}
+
+// One thread per 2x2 window: recompute the (first) arg-max from the input blob and route dy to it.
+__global__ __launch_bounds__(256) void maxpool_bwd_k(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     float* __restrict__ dx, const float* __restrict__ inject,
+                                                     int apply_mask, int C, int H, int W, int Ho, int Wo)
+{
+    const size_t total = (size_t)C * Ho * Wo;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int px = (int)(idx % Wo);
+        const int py = (int)((idx / Wo) % Ho);
+        const int c = (int)(idx / ((size_t)Wo * Ho));
+        const size_t base = (size_t)c * H * W;
+        const int r0 = 2 * py, c0 = 2 * px;
+        float best = -FLT_MAX;
+        int arg = -1;
+        float vals[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + (k >> 1), cc = c0 + (k & 1);
+            vals[k] = 0.f;
+            if (r < H && cc < W) {
+                vals[k] = x[base + (size_t)r * W + cc];
+                if (vals[k] > best) { best = vals[k]; arg = k; }
+            }
+        }
+        const float g = dy[idx];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + (k >> 1), cc = c0 + (k & 1);
+            if (r < H && cc < W) {
+                const size_t o = base + (size_t)r * W + cc;
+                float v = (k == arg) ? g : 0.f;
+                if (apply_mask) v = vals[k] > 0.f ? v : 0.f;
+                if (inject) v += inject[o];
+                dx[o] = v;
+            }
+        }
+    }
+}
+
+hipError_t launch_maxpool_bwd(const float* dy, const float* x, float* dx, const float* inject,
+                              int apply_mask, int C, int H, int W, hipStream_t s)
+{
+    const int Ho = pooled_size(H), Wo = pooled_size(W);
+    const size_t total = (size_t)C * Ho * Wo;
+    maxpool_bwd_k<<<reduce_grid(total, 256, 65536), 256, 0, s>>>(dy, x, dx, inject, apply_mask, C, H, W, Ho, Wo);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- content / deep-dream
+__global__ __launch_bounds__(256) void layer_elem_k(const LayerElemArgs a)
+{
+    __shared__ float scratch[16];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};   // d2, gc2, f2, gd2
+    float inv_c = 0.f, inv_d = 0.f;
+    if (a.write) {
+        if (a.content) inv_c = *a.norm_c;
+        if (a.deepdream) inv_d = *a.norm_d;
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        const float f = a.feat[i];
+        float out = 0.f;
+        if (a.content) {
+            const float d = f - a.target[i];
+            const float gc = a.cn_coef * d;               // (2 / n) * c_diff
+            acc[0] += d * d;
+            acc[1] += gc * gc;
+            if (a.write) out += (a.cw * gc) / inv_c;      // diffs += cw * c_grad / cn
+        }
+        if (a.deepdream) {
+            const float gd = a.dn_coef * f;               // (-2 / n) * F
+            acc[2] += f * f;
+            acc[3] += gd * gd;
+            if (a.write) out += (a.dw * gd) / inv_d;
+        }
+        if (a.write) a.inject[i] = out;
+    }
+    block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+        if (a.part_d2) a.part_d2[blockIdx.x] = acc[0];
+        if (a.part_gc2) a.part_gc2[blockIdx.x] = acc[1];
+        if (a.part_f2) a.part_f2[blockIdx.x] = acc[2];
+        if (a.part_gd2) a.part_gd2[blockIdx.x] = acc[3];
+    }
+}
+
+hipError_t launch_layer_elem(const LayerElemArgs& a, int* n_partial, hipStream_t s)
+{
+    const int grid = reduce_grid(a.n, 256 * 8, kMaxPartials);
+    *n_partial = grid;
+    layer_elem_k<<<grid, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void finalize_norm_k(const float* part, int n_part, double n, float* norm)
+{
+    __shared__ double scratch[256];
+    const double sum = sum_partials(part, n_part, scratch);
+    if (threadIdx.x == 0) *norm = sqrtf((float)(sum / n));
+}
+
+hipError_t launch_finalize_norm(const float* partial, int n_partial, double n, float* norm, hipStream_t s)
+{
+    finalize_norm_k<<<1, 256, 0, s>>>(partial, n_partial, n, norm);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void scaled_accumulate_k(const float* __restrict__ S, float* __restrict__ inject,
+                                                           float sw, const float* __restrict__ norm,
+                                                           int accumulate, size_t n)
+{
+    const float coef = sw / *norm;                         // sw / sn[layer]
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float base = accumulate ? inject[i] : 0.f;
+        inject[i] = coef * S[i] + base;                    // saxpy
+    }
+}
+
+hipError_t launch_scaled_accumulate(const float* S, float* inject, float sw, const float* norm,
+                                    int accumulate, size_t n, hipStream_t s)
+{
+    scaled_accumulate_k<<<reduce_grid(n, 256 * 4, 8192), 256, 0, s>>>(S, inject, sw, norm, accumulate, n);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------- TV + p-norm + combine (+ Adam)
+__device__ __forceinline__ float tv_k(float q, float half_beta, int beta_is_2)
+{
+    // (beta/2) * q^(beta/2 - 1);  q^0 == 1 exactly for beta == 2
+    return beta_is_2 ? 1.0f : half_beta * powf(q, half_beta - 1.0f);
+}
+
+__global__ __launch_bounds__(256) void image_pass_k(const ImagePassArgs a)
+{
+    __shared__ float scratch[32];
+    const int H = a.H, W = a.W;
+    const size_t plane = (size_t)H * W;
+    const size_t total = plane * a.C;
+    const float half_beta = a.tv_beta * 0.5f;
+    const int beta_is_2 = a.tv_beta == 2.0f;
+    const int do_tv = a.tv_w != 0.0f || true;   // value is traced even when the weight is zero
+    (void)do_tv;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        const float* p = a.x + (idx / plane) * plane;
+        const int xr = x + 1 == W ? 0 : x + 1, xl = x == 0 ? W - 1 : x - 1;
+        const int yd = y + 1 == H ? 0 : y + 1, yu = y == 0 ? H - 1 : y - 1;
+        const float xv = p[(size_t)y * W + x];
+        const float u = xv / 255.0f;
+        const float u_r = p[(size_t)y * W + xr] / 255.0f;
+        const float u_d = p[(size_t)yd * W + x] / 255.0f;
+        const float u_l = p[(size_t)y * W + xl] / 255.0f;
+        const float u_u = p[(size_t)yu * W + x] / 255.0f;
+        const float u_dl = p[(size_t)yd * W + xl] / 255.0f;
+        const float u_ur = p[(size_t)yu * W + xr] / 255.0f;
+        // this pixel
+        const float a0 = u - u_r, b0 = u - u_d;
+        const float q0 = (a0 * a0 + b0 * b0) + 1e-8f;
+        const float k0 = tv_k(q0, half_beta, beta_is_2);
+        const float da0 = (2.0f * a0) * k0, db0 = (2.0f * b0) * k0;
+        // left neighbour's x-difference, upper neighbour's y-difference
+        const float aL = u_l - u, bL = u_l - u_dl;
+        const float qL = (aL * aL + bL * bL) + 1e-8f;
+        const float daL = (2.0f * aL) * tv_k(qL, half_beta, beta_is_2);
+        const float aU = u_u - u_ur, bU = u_u - u;
+        const float qU = (aU * aU + bU * bU) + 1e-8f;
+        const float dbU = (2.0f * bU) * tv_k(qU, half_beta, beta_is_2);
+        float g_tv = da0 + db0;
+        g_tv -= daL;
+        g_tv -= dbU;
+        acc[0] += beta_is_2 ? q0 : powf(q0, half_beta);
+        // p-norm
+        const float mag = fabsf(u);
+        const float sgn = u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);
+        acc[1] += powf(mag, a.p_pow);
+        const float g_p = sgn * powf(mag, a.p_pow - 1.0f);
+        // combine
+        const float scd = a.scd ? a.scd[idx] : 0.f;
+        const float tg = a.tv_w * g_tv;
+        const float pg = a.p_w * g_p;
+        float g = scd + tg;
+        g += pg;
+        acc[2] += scd * scd;
+        acc[3] += tg * tg;
+        acc[4] += pg * pg;
+        acc[5] += g * g;
+        if (a.grad) a.grad[idx] = g;
+        if (a.x_out) {
+            const float m_old = a.m_is_zero ? 0.f : a.m[idx];
+            const float v_old = a.v_is_zero ? 0.f : a.v[idx];
+            const float m_new = a.d1 * m_old + a.c1 * g;
+            const float v_new = a.d2 * v_old + a.c2 * (g * g);
+            a.m[idx] = m_new;
+            a.v[idx] = v_new;
+            const float m_hat = m_new / a.corr1;
+            const float v_hat = v_new / a.corr2;
+            a.x_out[idx] = xv - (a.step * m_hat) / (sqrtf(v_hat) + 1e-8f);
+        }
+    }
+    block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.partial[i * kMaxPartials + blockIdx.x] = acc[i];
+    }
+}
+
+hipError_t launch_image_pass(const ImagePassArgs& a, int* n_partial, hipStream_t s)
+{
+    const size_t total = (size_t)a.C * a.H * a.W;
+    const int grid = reduce_grid(total, 256 * 4, kMaxPartials);
+    *n_partial = grid;
+    image_pass_k<<<grid, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------- pre / deprocess
+__constant__ float kMean[3] = {123.68f, 116.779f, 103.939f};   // worker.py:34
+
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_k(const T* __restrict__ hwc, float* __restrict__ nchw, int H, int W)
+{
+    const size_t plane = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane * 3; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i / plane);
+        const size_t p = i % plane;
+        nchw[i] = (float)hwc[p * 3 + c] - kMean[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void deprocess_k(const float* __restrict__ nchw, float* __restrict__ hwc, int H, int W)
+{
+    const size_t plane = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < plane * 3; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % 3);
+        const size_t p = i / 3;
+        hwc[i] = nchw[(size_t)c * plane + p] + kMean[c];
+    }
+}
+
+hipError_t launch_preprocess_u8(const uint8_t* hwc, float* nchw, int H, int W, hipStream_t s)
+{
+    preprocess_k<uint8_t><<<reduce_grid((size_t)H * W * 3, 1024, 8192), 256, 0, s>>>(hwc, nchw, H, W);
+    return hipGetLastError();
+}
+hipError_t launch_preprocess_f32(const float* hwc, float* nchw, int H, int W, hipStream_t s)
+{
+    preprocess_k<float><<<reduce_grid((size_t)H * W * 3, 1024, 8192), 256, 0, s>>>(hwc, nchw, H, W);
+    return hipGetLastError();
+}
+hipError_t launch_deprocess(const float* nchw, float* hwc, int H, int W, hipStream_t s)
+{
+    deprocess_k<<<reduce_grid((size_t)H * W * 3, 1024, 8192), 256, 0, s>>>(nchw, hwc, H, W);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------- trace scalars
+__global__ __launch_bounds__(256) void finalize_trace_k(const TraceArgs a)
+{
+    __shared__ double scratch[256];
+    __shared__ double sums[kMaxTraceLayers * kLayerSlots + kImageSlots];
+    for (int l = 0; l < a.n_layers; ++l)
+        for (int k = 0; k < kLayerSlots; ++k) {
+            double v = 0.0;
+            if (a.layer[l].part[k] && a.layer[l].count[k] > 0)
+                v = sum_partials(a.layer[l].part[k], a.layer[l].count[k], scratch);
+            if (threadIdx.x == 0) sums[l * kLayerSlots + k] = v;
+        }
+    for (int k = 0; k < kImageSlots; ++k) {
+        const double v = sum_partials(a.image_part + k * kMaxPartials, a.image_count, scratch);
+        if (threadIdx.x == 0) sums[a.n_layers * kLayerSlots + k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float loss = 0.f;
+    for (int l = 0; l < a.n_layers; ++l) {
+        const TraceLayer& L = a.layer[l];
+        const double* sm = sums + l * kLayerSlots;
+        float* o = a.out + l * 6;
+        for (int k = 0; k < 6; ++k) o[k] = 0.f;
+        if (L.content) {
+            const float nc = L.norm[0];
+            const float c_loss = (L.cw * (float)(sm[0] / L.n)) / nc;      // cw * mean(d^2) / cn
+            loss += c_loss;
+            o[0] = c_loss;
+            o[1] = (fabsf(L.cw) * sqrtf((float)(sm[1] / L.n))) / nc;      // rms(cw * c_grad / cn)
+        }
+        if (L.style) {
+            const float ns = L.norm[1];
+            const float s_loss = (L.sw * (float)(sm[4] / L.gram_n)) / ns; // sw * mean(D^2) / sn
+            loss += s_loss;
+            o[2] = s_loss;
+            o[3] = fabsf(L.sw / ns) * sqrtf((float)(sm[5] / L.n));        // rms(sw / sn * s_grad)
+        }
+        if (L.deepdream) {
+            const float nd = L.norm[2];
+            const float d_loss = (-L.dw * (float)(sm[2] / L.n)) / nd;     // -dw * mean(F^2) / dn
+            loss += d_loss;
+            o[4] = d_loss;
+            o[5] = (fabsf(L.dw) * sqrtf((float)(sm[3] / L.n))) / nd;
+        }
+    }
+    const double* im = sums + a.n_layers * kLayerSlots;
+    float* g = a.out + a.n_layers * 6;
+    g[0] = loss;                                               // scd_loss
+    const float t_loss = a.tv_w * (float)im[0];
+    loss += t_loss;
+    const float p_loss = a.p_w * ((float)im[1] / a.p_pow);
+    loss += p_loss;
+    g[1] = t_loss;
+    g[2] = p_loss;
+    g[3] = a.have_grad ? sqrtf((float)(im[2] / a.image_n)) : 0.f;
+    g[4] = a.have_grad ? sqrtf((float)(im[3] / a.image_n)) : 0.f;
+    g[5] = a.have_grad ? sqrtf((float)(im[4] / a.image_n)) : 0.f;
+    g[6] = loss;
+    g[7] = a.have_grad ? sqrtf((float)(im[5] / a.image_n)) : 0.f;
+}
+
+hipError_t launch_finalize_trace(const TraceArgs& a, hipStream_t s)
+{
+    finalize_trace_k<<<1, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------- BLAS-1 (L-BFGS)
+__global__ __launch_bounds__(256) void dot_partial_k(const float* __restrict__ x, const float* __restrict__ y,
+                                                     size_t n, float* __restrict__ part)
+{
+    __shared__ float scratch[4];
+    float acc[1] = {0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc[0] += x[i] * y[i];
+    block_sum(acc, scratch);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+
+__global__ __launch_bounds__(256) void dot_final_k(const float* part, int n_part, float* out)
+{
+    __shared__ double scratch[256];
+    const double sum = sum_partials(part, n_part, scratch);
+    if (threadIdx.x == 0) *out = (float)sum;
+}
+
+hipError_t launch_dot(const float* x, const float* y, size_t n, float* partial, float* out, hipStream_t s)
+{
+    const int grid = reduce_grid(n, 256 * 8, kMaxPartials);
+    dot_partial_k<<<grid, 256, 0, s>>>(x, y, n, partial);
+    dot_final_k<<<1, 256, 0, s>>>(partial, grid, out);
+    return hipGetLastError();
+}
+
+__global__ void scalar_op_k(int op, const float* a, const float* b, const float* c, float k, float* out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    switch (op) {
+    case kOpDiv: *out = *a / *b; break;                       // dot / sy
+    case kOpNegDiv: *out = -(*a / *b); break;
+    case kOpSubDiv: *out = *c - *a / *b; break;               // alpha - beta
+    case kOpRsqrtMean: *out = sqrtf(*a / k); break;           // sqrt(dot(p,p) / p.size)
+    case kOpDivInv: *out = *a / *b; break;                    // sy / dot(y,y)
+    }
+}
+
+hipError_t launch_scalar_op(int op, const float* a, const float* b, const float* c, float k, float* out, hipStream_t s)
+{
+    scalar_op_k<<<1, 64, 0, s>>>(op, a, b, c, k, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void axpy_dev_k(const float* coef, float sign, const float* __restrict__ x,
+                                                  float* __restrict__ y, size_t n)
+{
+    const float c = sign * *coef;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = c * x[i] + y[i];
+}
+
+hipError_t launch_axpy_dev(const float* coef, float coef_sign, const float* x, float* y, size_t n, hipStream_t s)
+{
+    axpy_dev_k<<<reduce_grid(n, 256 * 4, 8192), 256, 0, s>>>(coef, coef_sign, x, y, n);
+    return hipGetLastError();
+}
+
+// k > 0: y = x * (*coef) ; k < 0: y = x / (*coef)
+__global__ __launch_bounds__(256) void scale_dev_k(const float* coef, float k, const float* x, float* y, size_t n)
+{
+    const float c = *coef;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        y[i] = k > 0.f ? x[i] * c : x[i] / c;
+}
+
+hipError_t launch_scale_dev(const float* coef, float k, const float* x, float* y, size_t n, hipStream_t s)
+{
+    scale_dev_k<<<reduce_grid(n, 256 * 4, 8192), 256, 0, s>>>(coef, k, x, y, n);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void lincomb_k(float a, const float* x, float b, const float* y, float* z, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = a * x[i];
+        if (y) v += b * y[i];
+        z[i] = v;
+    }
+}
+
+hipError_t launch_lincomb(float a, const float* x, float b, const float* y, float* z, size_t n, hipStream_t s)
+{
+    lincomb_k<<<reduce_grid(n, 256 * 4, 8192), 256, 0, s>>>(a, x, b, y, z, n);
+    return hipGetLastError();
+}
+
+}  // namespace st2

@@ -1,0 +1,161 @@
+// Internal launch interface between the engine (engine.cpp) and the gfx950 kernels (*.hip).
+// Everything here is device-pointer based; all launches go to the stream given.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace st2 {
+
+constexpr int kMaxPartials = 1024;   // grid cap (= partial-sum slots) of every reducing kernel
+constexpr int kConvCC = 8;           // input-channel chunk staged in LDS by the conv kernel
+constexpr int kCoutQuantum = 64;     // conv weights are zero-padded to a multiple of this many outputs
+
+// ------------------------------------------------------------------------------------------
+// conv3x3 (pad 1, stride 1) as implicit GEMM on v_mfma_f32_32x32x2_f32.  NCHW fp32.
+//   forward : out = relu(conv(in, W) + bias)                         (prototxt Convolution+ReLU)
+//   dgrad   : out = mask(conv(in, W')) + inject   with W' = flipped/transposed W, where
+//             mask(v) = (mask_src > 0 ? v : 0) when mask_src != nullptr  (ReLU backward of the
+//             in-place blob below) and inject is the unmasked diff injected at that blob.
+// Weights are pre-packed by pack_conv_weights(): [ceil(K/CC)][9][CC][MPad].
+// ------------------------------------------------------------------------------------------
+struct ConvProblem {
+    const float* in;        // [K][H][W]   (K = input channels of this GEMM)
+    const float* wpack;     // packed weights
+    const float* bias;      // [MPad] or nullptr (forward only)
+    float* out;             // [M][H][W]
+    const float* mask_src;  // [M][H][W] or nullptr (dgrad only)
+    const float* inject;    // [M][H][W] or nullptr (dgrad only)
+    int K, M, MPad, H, W;
+    int relu;               // forward epilogue
+};
+size_t conv_pack_floats(int K, int M);                       // floats in a packed weight buffer
+int conv_mpad(int M);
+// host-side packers (plain CPU loops; weights arrive once per worker start)
+void pack_conv_weights_fwd(const float* w /*M=Cout,K=Cin,3,3*/, int Cout, int Cin, float* dst);
+void pack_conv_weights_dgrad(const float* w /*Cout,Cin,3,3*/, int Cout, int Cin, float* dst);
+hipError_t launch_conv3x3(const ConvProblem& p, hipStream_t s);
+// conv1_1-style dgrad (tiny M): direct VALU kernel, w is the ORIGINAL (Cout,Cin,3,3) layout
+hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
+                                       int Cout, int Cin, int H, int W, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// max pool 2x2 stride 2, Caffe ceil mode, first-max arg-max (recomputed in backward).
+// ------------------------------------------------------------------------------------------
+int pooled_size(int n);
+hipError_t launch_maxpool_fwd(const float* in, float* out, int C, int H, int W, hipStream_t s);
+// dx = mask(scatter(dy at argmax)) + inject ; x is the pool INPUT blob (also the mask source)
+hipError_t launch_maxpool_bwd(const float* dy, const float* x, float* dx, const float* inject,
+                              int apply_mask, int C, int H, int W, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// Gram matrix  G = F F^T / n  (F is [C][hw]) as split-K MFMA GEMM + deterministic slab reduce.
+// ------------------------------------------------------------------------------------------
+struct GramPlan { int bt, tiles, splits, kslab; size_t slab_floats; };
+GramPlan gram_plan(int C, int hw);
+hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s);
+// out[i][j] = sum_s slabs[s][i][j] / n  - (target ? target[i][j] : 0);  partial[blockIdx] = sum out^2
+hipError_t launch_gram_reduce(const float* slabs, const float* target, float* out, float* partial,
+                              int* n_partial, int C, int hw, const GramPlan& pl, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// Style gradient  S = c2 * (D @ F)  (D is C x C symmetric, F is [C][hw]) on MFMA.
+//   mode 0 (raw)  : tmp = S                      and partial += S^2   (first evaluation: norm unknown)
+//   mode 1 (fused): inject = (sw / *norm) * S + (accumulate ? inject : 0) ; partial += S^2
+// ------------------------------------------------------------------------------------------
+hipError_t launch_style_grad(const float* D, const float* F, float* dst, float c2, int mode,
+                             float sw, const float* norm, int accumulate, float* partial,
+                             int* n_partial, int C, int hw, hipStream_t s);
+// inject = (sw / *norm) * S + (accumulate ? inject : 0)
+hipError_t launch_scaled_accumulate(const float* S, float* inject, float sw, const float* norm,
+                                    int accumulate, size_t n, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// per-layer elementwise terms (content / deep-dream), worker.py:249-256,271-277
+// ------------------------------------------------------------------------------------------
+struct LayerElemArgs {
+    const float* feat;      // F
+    const float* target;    // F_c (content features) or nullptr
+    float* inject;          // written (overwritten) when write != 0
+    size_t n;
+    float cn_coef, dn_coef; // float(2/n), float(-2/n)
+    float cw, dw;
+    int content, deepdream, write;
+    const float* norm_c;    // device scalars (valid when write != 0)
+    const float* norm_d;
+    float* part_d2;         // sum (F-Fc)^2
+    float* part_gc2;        // sum (cn_coef (F-Fc))^2
+    float* part_f2;         // sum F^2
+    float* part_gd2;        // sum (dn_coef F)^2
+};
+hipError_t launch_layer_elem(const LayerElemArgs& a, int* n_partial, hipStream_t s);
+
+// norm = sqrt(float(sum(partials) / n))
+hipError_t launch_finalize_norm(const float* partial, int n_partial, double n, float* norm, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// image-space pass: TV + p-norm + combine (+ Adam), utils.py:285-304, worker.py:279-297,
+// optimizers.py:20-27.  x/x_out are (3,H,W); periodic borders.
+// ------------------------------------------------------------------------------------------
+struct ImagePassArgs {
+    const float* x;         // current image
+    const float* scd;       // dL/dx from the network (may be nullptr => zeros)
+    float* grad;            // combined gradient out (nullptr to skip)
+    int C, H, W;
+    float tv_w, tv_beta, p_w, p_pow;
+    // Adam (enabled when x_out != nullptr)
+    float* x_out; float* m; float* v;
+    float d1, c1, d2, c2, corr1, corr2, step;
+    int m_is_zero;          // m treated as 0 (after clear) without a memset
+    int v_is_zero;
+    float* partial;         // 6 rows of kMaxPartials: tv, p, scd^2, (tv_w g_tv)^2, (p_w g_p)^2, grad^2
+};
+hipError_t launch_image_pass(const ImagePassArgs& a, int* n_partial, hipStream_t s);
+
+// pre/deprocess, worker.py:63-71
+hipError_t launch_preprocess_u8(const uint8_t* hwc, float* nchw, int H, int W, hipStream_t s);
+hipError_t launch_preprocess_f32(const float* hwc, float* nchw, int H, int W, hipStream_t s);
+hipError_t launch_deprocess(const float* nchw, float* hwc, int H, int W, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// trace finalisation: one tiny kernel turns the partial sums of an opfunc into the trace scalars
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxTraceLayers = 24;
+constexpr int kLayerSlots = 6;       // d2, gc2, f2, gd2, D2, S2
+constexpr int kImageSlots = 6;
+struct TraceLayer {
+    int content, style, deepdream;
+    float cw, sw, dw;
+    double n;            // C*h*w
+    double gram_n;       // C*C
+    int count[kLayerSlots];
+    const float* part[kLayerSlots];
+    const float* norm;   // [3] c, s, d
+};
+struct TraceArgs {
+    int n_layers;
+    TraceLayer layer[kMaxTraceLayers];
+    const float* image_part;     // kImageSlots rows of kMaxPartials
+    int image_count;
+    double image_n;              // 3*H*W
+    float tv_w, p_w, p_pow;
+    int have_grad;
+    float* out;                  // [n_layers*6 + 8]
+};
+hipError_t launch_finalize_trace(const TraceArgs& a, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
+// BLAS-1 with device-resident scalars (L-BFGS two-loop), optimizers.py:62-108, utils.py:29-46
+// ------------------------------------------------------------------------------------------
+hipError_t launch_dot(const float* a, const float* b, size_t n, float* partial, float* out, hipStream_t s);
+enum ScalarOp { kOpDiv = 0, kOpNegDiv = 1, kOpSubDiv = 2, kOpRsqrtMean = 3, kOpDivInv = 4 };
+// tiny scalar kernel: out = f(op, a, b, c)
+hipError_t launch_scalar_op(int op, const float* a, const float* b, const float* c, float k, float* out, hipStream_t s);
+// y = coef_sign * (*coef) * x + y
+hipError_t launch_axpy_dev(const float* coef, float coef_sign, const float* x, float* y, size_t n, hipStream_t s);
+// y = (*coef) * k * x  (y may alias x)
+hipError_t launch_scale_dev(const float* coef, float k, const float* x, float* y, size_t n, hipStream_t s);
+// z = a*x + b*y  (host scalars)
+hipError_t launch_lincomb(float a, const float* x, float b, const float* y, float* z, size_t n, hipStream_t s);
+
+}  // namespace st2

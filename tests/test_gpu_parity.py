@@ -1,0 +1,249 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle and the committed golden vectors.
+
+Run on the GPU box with ``pytest -m gpu``.  Tolerances are stated per test: everything here is
+IEEE fp32 on both sides, differing only in summation order (MFMA k-chains vs BLAS), so the bars
+are rel-L2 <= 1e-5 for single layers and <= 1e-4 for whole-network gradients.
+"""
+import json
+
+import numpy as np
+import pytest
+
+import oracle
+import style_transfer2_amd as st2
+from helpers import load, rel_l2, tiny_setup, check_trace
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def make_models(topo, seed=0, bias_std=0.1):
+    params = oracle.he_init_weights(topo, seed=seed, bias_std=bias_std)
+    return oracle.NetOracle(topo, params), st2.HipModel(params, topology=topo)
+
+
+# ------------------------------------------------------------------------------------------ layers
+@pytest.mark.parametrize('cin,cout,h,w', [
+    (3, 64, 16, 32), (3, 8, 5, 7), (8, 16, 16, 20), (64, 64, 24, 40), (64, 128, 17, 33),
+    (128, 256, 12, 12), (256, 512, 8, 8), (512, 512, 9, 6), (6, 8, 9, 12), (16, 8, 31, 65),
+    (64, 64, 64, 96), (128, 128, 40, 70)])
+def test_single_conv_forward_and_dgrad(cin, cout, h, w):
+    """conv3x3+ReLU forward of one layer and its data gradient, odd sizes and every tile config."""
+    topo = (('conv', 'conv1_1', 3, cin), ('conv', 'conv1_2', cin, cout)) if cin != 3 else (('conv', 'conv1_1', 3, cout),)
+    cpu, gpu = make_models(topo, seed=cin + cout, bias_std=0.2)
+    rng = np.random.RandomState(h * w)
+    x = (rng.randn(1, 3, h, w) * 40).astype(F32)
+    last = topo[-1][1]
+    fc = cpu.forward(x, [last])[last]
+    fg = gpu.forward(x, [last])[last]
+    assert fg.shape == fc.shape
+    assert rel_l2(fg, fc) <= 1e-5
+    assert np.array_equal(fg == 0, fc == 0) or np.mean((fg == 0) != (fc == 0)) < 1e-4   # ReLU pattern
+    d = rng.randn(*fc.shape).astype(F32)
+    gc = cpu.backward({last: d})
+    gg = gpu.backward({last: d})
+    assert rel_l2(gg, gc) <= 2e-5
+
+
+def test_pool_ceil_mode_and_first_max():
+    topo = (('conv', 'conv1_1', 3, 8), ('pool', 'pool1'), ('conv', 'conv2_1', 8, 8), ('pool', 'pool2'))
+    cpu, gpu = make_models(topo, seed=3)
+    for h, w in ((9, 13), (8, 8), (1, 5), (7, 2), (33, 65)):
+        x = (np.random.RandomState(h).randn(1, 3, h, w) * 40).astype(F32)
+        x[0, :, : h // 2] = np.round(x[0, :, : h // 2] / 20) * 20        # plenty of exact ties / zeros
+        fc, fg = cpu.forward(x), gpu.forward(x)
+        for name in fc:
+            assert fg[name].shape == fc[name].shape, (name, h, w)
+            assert rel_l2(fg[name], fc[name]) <= 1e-5, (name, h, w)
+        d = {'pool2': np.random.RandomState(1).randn(*fc['pool2'].shape).astype(F32),
+             'pool1': np.random.RandomState(2).randn(*fc['pool1'].shape).astype(F32)}
+        assert rel_l2(gpu.backward(d), cpu.backward(d)) <= 2e-5, (h, w)
+
+
+def test_ranged_backward_injection_rules():
+    """worker.py:88-106: unmasked at the start blob, masked from above, pool and data blobs too."""
+    topo = oracle.tiny_topology((8, 16), (2, 2), final_pool=True)
+    cpu, gpu = make_models(topo, seed=5, bias_std=0.3)
+    rng = np.random.RandomState(1)
+    x = (rng.randn(1, 3, 18, 23) * 30).astype(F32)
+    fc, fg = cpu.forward(x), gpu.forward(x)
+    for name in fc:
+        assert rel_l2(fg[name], fc[name]) <= 1e-5, name
+    cases = (['pool2', 'conv2_1', 'conv1_2', 'pool1', 'data'], ['conv2_2'], ['conv1_1'], ['data'],
+             ['pool1', 'conv1_1'], ['conv2_2', 'data'])
+    for names in cases:
+        diffs = {n: rng.randn(*fc[n].shape).astype(F32) for n in names}
+        assert rel_l2(gpu.backward(diffs), cpu.backward(diffs)) <= 2e-5, names
+    assert np.array_equal(gpu.backward({}), np.zeros_like(x))
+
+
+def test_gram_matches_oracle():
+    topo = (('conv', 'conv1_1', 3, 64), ('conv', 'conv1_2', 64, 128), ('pool', 'pool1'), ('conv', 'conv2_1', 128, 200))
+    cpu, gpu = make_models(topo, seed=9)
+    x = (np.random.RandomState(4).randn(1, 3, 37, 50) * 40).astype(F32)
+    fc = cpu.forward(x)
+    gpu.forward(x)
+    for name in fc:
+        g = gpu.engine.gram(name)
+        ref = oracle.gram(fc[name])
+        assert rel_l2(g, ref) <= 1e-5, name
+        assert np.allclose(g, g.T, rtol=1e-5, atol=1e-7 * np.abs(g).max())
+
+
+# ------------------------------------------------- oracle objective on top of the HIP model (B2 seam)
+def test_oracle_objective_over_hip_model_matches_golden():
+    g = load('transfer_tiny.npz')
+    topo, params, weights, content, style, init = tiny_setup(g)
+    st = oracle.TransferOracle(st2.HipModel(params, topology=topo))
+    st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+    st.set_weights(weights, json.loads(str(g['params_json'])))
+    st.set_optimizer('adam', 10)
+    for ev in (1, 2):
+        loss, grad = st.opfunc(g['std_eval%d_x' % ev].copy())
+        assert rel_l2(grad, g['std_eval%d_grad' % ev]) <= 1e-4
+        assert np.isclose(loss, g['std_eval%d_loss' % ev], rtol=1e-4)
+
+
+# --------------------------------------------------------------- the engine path (product) vs golden
+def engine_transfer(g, kind, step, params):
+    topo, net_params, weights, content, style, init = tiny_setup(g)
+    st = st2.StyleTransfer(st2.HipModel(net_params, topology=topo))
+    st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+    st.set_weights(weights, params)
+    st.optimizer_cls = {'adam': st2.AdamOptimizer, 'lbfgs': st2.LBFGSOptimizer}[kind]
+    st.set_step_size(step)
+    st.reset()
+    assert st.start()
+    return st
+
+
+@pytest.mark.parametrize('tag', ['std', 'odd'])
+def test_engine_opfunc_two_evals_match_reference_vectors(tag):
+    """First evaluation captures the norms, the second uses them frozen (worker.py:253-275)."""
+    g = load('transfer_tiny.npz')
+    params = json.loads(str(g['params_json' if tag == 'std' else 'params_odd_json']))
+    st = engine_transfer(g, 'adam', 10, params)
+    for ev in (1, 2):
+        loss, grad = st.opfunc(g['%s_eval%d_x' % (tag, ev)])
+        assert rel_l2(grad, g['%s_eval%d_grad' % (tag, ev)]) <= 1e-4, ev
+        assert np.isclose(loss, g['%s_eval%d_loss' % (tag, ev)], rtol=1e-4), ev
+        check_trace(g['%s_eval%d_trace_keys' % (tag, ev)], g['%s_eval%d_trace_vals' % (tag, ev)],
+                    st.traces[-1].data, rtol=2e-4)
+    loss = st.opfunc(None, return_grad=False)
+    assert list(st.traces[-1].data)[-4:] == ['scd_loss', 't_loss', 'p_loss', 'loss']
+
+
+def test_engine_adam_trajectory_matches_reference_vectors():
+    """50 Adam steps.  Adam's first steps are sign-like (x -= 10 g/|g|), so pixels whose gradient is at
+    fp32 noise level may flip: tight bar on the per-step loss, loose bar on the image (MSE in 0-255
+    units <= 1.0 against an image that moves by hundreds of levels)."""
+    g = load('transfer_tiny.npz')
+    st = engine_transfer(g, 'adam', 10, json.loads(str(g['params_json'])))
+    losses, images = [], []
+    for i in range(50):
+        image, trace = st.step()
+        losses.append(trace['loss'])
+        if i in (0, 4, 49):
+            images.append(image)
+    assert np.allclose(losses, g['adam_losses'], rtol=5e-3)
+    assert np.isclose(losses[0], g['adam_losses'][0], rtol=1e-4)
+    for got, ref in zip(images, g['adam_images']):
+        assert np.mean((got - ref) ** 2) <= 1.0
+    assert trace['fevals'] == 50
+    assert list(trace) == [str(k) for k in g['adam_last_trace_keys']]
+
+
+def test_engine_lbfgs_trajectory_matches_reference_vectors():
+    g = load('transfer_tiny.npz')
+    st = engine_transfer(g, 'lbfgs', 1, json.loads(str(g['params_json'])))
+    losses, images = [], []
+    for i in range(20):
+        image, trace = st.step()
+        losses.append(trace['loss'])
+        if i in (0, 4, 19):
+            images.append(image)
+    assert np.allclose(losses[:5], g['lbfgs_losses'][:5], rtol=1e-3)
+    assert np.allclose(losses, g['lbfgs_losses'], rtol=5e-2)
+    assert np.mean((images[0] - g['lbfgs_images'][0]) ** 2) <= 1e-2
+    assert np.mean((images[-1] - g['lbfgs_images'][-1]) ** 2) <= 25.0
+    assert list(trace) == [str(k) for k in g['lbfgs_last_trace_keys']]
+
+
+def test_engine_objective_changed_and_same_shape_input_replacement():
+    """set_input with an equal shape keeps Adam's v, clears m (optimizers.py:42-46, worker.py:193-195)."""
+    g = load('transfer_tiny.npz')
+    topo, net_params, weights, content, style, init = tiny_setup(g)
+    params = json.loads(str(g['params_json']))
+    ora = oracle.TransferOracle(oracle.NetOracle(topo, net_params))
+    dev = engine_transfer(g, 'adam', 10, params)
+    ora.set_input(init); ora.set_content(content); ora.set_style(style); ora.reset()
+    ora.set_weights(weights, params); ora.set_optimizer('adam', 10); ora.start()
+    other = np.random.RandomState(7).randint(0, 256, init.shape).astype(np.uint8)
+    for i in range(6):
+        if i == 3:
+            ora.set_input(other)
+            dev.set_input(other)
+        io, to = ora.step()
+        idv, td = dev.step()
+        assert np.isclose(td['loss'], to['loss'], rtol=2e-3), i
+    assert np.mean((idv - io) ** 2) <= 1.0
+
+
+# ----------------------------------------------------------------------- full VGG19, small image
+def test_vgg19_gradient_matches_oracle_at_96x128():
+    topo = oracle.VGG19_TOPOLOGY
+    params = oracle.he_init_weights(topo, seed=0)
+    cpu = oracle.TransferOracle(oracle.NetOracle(topo, params, full_forward=False))
+    dev = st2.StyleTransfer(st2.HipModel(params))
+    rs = np.random.RandomState
+    content = rs(1).randint(0, 256, (96, 128, 3)).astype(np.uint8)
+    style = rs(2).randint(0, 256, (80, 112, 3)).astype(np.uint8)
+    init = rs(3).randint(0, 256, (96, 128, 3)).astype(np.uint8)
+    weights = {'content': {'conv4_2': 0.08},
+               'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
+               'deepdream': {}}
+    params4 = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+    for st in (cpu, dev):
+        st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+        st.set_weights(weights, params4)
+    lo, go = cpu.opfunc(cpu.input)
+    ld, gd = dev.opfunc()
+    assert rel_l2(gd, go) <= 1e-4
+    assert np.isclose(ld, lo, rtol=1e-4)
+    check_trace(list(cpu.traces[-1].data), list(cpu.traces[-1].data.values()), dev.traces[-1].data, rtol=1e-3)
+    # second evaluation with frozen norms, after moving the image
+    x2 = cpu.input + F32(2.0) * np.sign(go)
+    lo, go = cpu.opfunc(x2)
+    ld, gd = dev.opfunc(x2)
+    assert rel_l2(gd, go) <= 1e-4
+
+
+# ------------------------------------------------- full-size (1024^2) size-independent properties
+def test_full_size_1024_properties():
+    """At BASELINE.json's size the oracle is too slow for a full comparison; check properties that do
+    not depend on size: locality (a crop evaluated by the ORACLE equals the same window of the
+    full-size HIP blobs away from the crop border), linearity of the ranged backward, Gram trace."""
+    topo = oracle.VGG19_TOPOLOGY[:4]            # conv1_1, conv1_2, pool1, conv2_1 at full resolution
+    params = oracle.he_init_weights(topo, seed=0)
+    cpu, gpu = oracle.NetOracle(topo, params), st2.HipModel(params, topology=topo)
+    x = (np.random.RandomState(0).rand(1, 3, 1024, 1024) * 255 - 120).astype(F32)
+    fg = gpu.forward(x)
+    y0, x0, s = 384, 640, 64
+    crop = np.ascontiguousarray(x[:, :, y0:y0 + s, x0:x0 + s])
+    fc = cpu.forward(crop)
+    m = 4                                        # conv1_1+conv1_2(+conv2_1 at half res) receptive margin
+    assert rel_l2(fg['conv1_2'][0, :, y0 + m:y0 + s - m, x0 + m:x0 + s - m], fc['conv1_2'][0, :, m:-m, m:-m]) <= 1e-5
+    h0, hx = y0 // 2, x0 // 2
+    assert rel_l2(fg['conv2_1'][0, :, h0 + m:h0 + s // 2 - m, hx + m:hx + s // 2 - m], fc['conv2_1'][0, :, m:-m, m:-m]) <= 1e-5
+    # linearity of backward in the injected diffs
+    rng = np.random.RandomState(5)
+    d1 = {'conv2_1': rng.randn(*fg['conv2_1'].shape).astype(F32)}
+    d2 = {'conv2_1': rng.randn(*fg['conv2_1'].shape).astype(F32)}
+    b1, b2 = gpu.backward(d1), gpu.backward(d2)
+    b12 = gpu.backward({'conv2_1': F32(2) * d1['conv2_1'] - F32(0.5) * d2['conv2_1']})
+    assert rel_l2(b12, F32(2) * b1 - F32(0.5) * b2) <= 1e-5
+    # Gram: trace(G) * n == sum F^2
+    gpu.forward(x)
+    G = gpu.engine.gram('conv1_1')
+    F = fg['conv1_1'].astype(np.float64)
+    assert np.isclose(np.trace(G.astype(np.float64)) * F.size, (F ** 2).sum(), rtol=1e-5)
