@@ -296,12 +296,18 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_smallM(const float* __restr
         }
 }
 
+static size_t smallM_lds(int Cout, int Cin)
+{
+    return ((size_t)Cout * Cin * 9 + 8 * (SM_TY + 2) * (SM_TX + 2)) * sizeof(float);
+}
+
+bool conv_dgrad_smallM_ok(int Cout, int Cin) { return Cin <= SM_MAXM && smallM_lds(Cout, Cin) <= 64 * 1024; }
+
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
                                        int Cout, int Cin, int H, int W, hipStream_t s)
 {
-    if (Cin > SM_MAXM) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)Cout * Cin * 9 + 8 * (SM_TY + 2) * (SM_TX + 2)) * sizeof(float);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    if (!conv_dgrad_smallM_ok(Cout, Cin)) return hipErrorInvalidValue;
+    const size_t lds = smallM_lds(Cout, Cin);
     dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
     conv3x3_dgrad_smallM<<<grid, dim3(256), lds, s>>>(dy, w, dx, inject, Cout, Cin, H, W);
     return hipGetLastError();

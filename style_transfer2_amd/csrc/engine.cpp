@@ -278,7 +278,7 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
         if (L.is_conv) {
             const double px = (double)a.h[i] * a.w[i];
             ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
-            if (L.cin <= 4 && !mask_src) {
+            if (!mask_src && conv_dgrad_smallM_ok(L.cout, L.cin)) {
                 HIP_TRY(launch_conv3x3_dgrad_smallM(cur, L.w_raw, dst, inject, L.cout, L.cin, a.h[i], a.w[i], c->stream));
             } else {
                 ConvProblem p{};
@@ -392,7 +392,11 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
             wrote = true;
         }
         if (al.s) {
-            if (!c->dbuf) ST_TRY(dmalloc(&c->dbuf, 1));
+            if (!c->dbuf) {          // C x C scratch for (G - G_style), sized for the widest blob
+                size_t cc = 1;
+                for (int i = 0; i < c->nb; ++i) cc = std::max(cc, (size_t)a.C[i] * a.C[i]);
+                ST_TRY(dmalloc(&c->dbuf, cc));
+            }
             ST_TRY(gram_into(c, a.data[b], C, hw, c->style_gram[b], c->dbuf, part + 4 * kMaxPartials, &cnt[4]));
             const float c2 = (float)(2.0 / ((double)C * C * (double)n));
             const int ptiles = (hw + 255) / 256, nmt = C > 64 ? (C + 127) / 128 : 1;

@@ -36,6 +36,7 @@ void pack_conv_weights_fwd(const float* w /*M=Cout,K=Cin,3,3*/, int Cout, int Ci
 void pack_conv_weights_dgrad(const float* w /*Cout,Cin,3,3*/, int Cout, int Cin, float* dst);
 hipError_t launch_conv3x3(const ConvProblem& p, hipStream_t s);
 // conv1_1-style dgrad (tiny M): direct VALU kernel, w is the ORIGINAL (Cout,Cin,3,3) layout
+bool conv_dgrad_smallM_ok(int Cout, int Cin);
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
                                        int Cout, int Cin, int H, int W, hipStream_t s);
 
