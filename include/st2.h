@@ -104,6 +104,14 @@ const char* st_profile_class_name(int cls);
 /* sums since the last call: launches, milliseconds, algorithmic FLOPs and bytes per class */
 int st_profile_read(st_ctx* ctx, long long* launches, double* ms, double* flops, double* bytes);
 
+/* isolated timing of the conv3x3 MFMA kernel on one layer shape (K input channels, M output
+ * channels, HxW, random data).  cfg < 0: the engine's own tile choice (returned in *cfg_used).
+ * dgrad_epilogue != 0 adds the ReLU-mask + injected-diff epilogue of the backward pass. */
+int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_epilogue, int iters,
+                  double* avg_ms, int* cfg_used);
+int st_conv_num_configs(void);
+const char* st_conv_config_name(int cfg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1022,4 +1022,57 @@ int st_profile_read(st_ctx* c, long long* launches, double* ms, double* flops, d
     return ST_OK;
 }
 
+int st_conv_num_configs(void) { return conv_num_configs(); }
+const char* st_conv_config_name(int cfg) { return conv_config_name(cfg); }
+
+int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_epilogue, int iters,
+                  double* avg_ms, int* cfg_used)
+{
+    if (K <= 0 || M <= 0 || H <= 0 || W <= 0 || iters <= 0 || !avg_ms) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device_id));
+    const size_t n_in = (size_t)K * H * W, n_out = (size_t)M * H * W;
+    std::vector<float> w((size_t)M * K * 9), pk(conv_pack_floats(K, M)), hin(n_in), hb(conv_mpad(M), 0.1f);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& x : w) x = rnd() * 0.05f;
+    for (auto& x : hin) x = rnd();
+    pack_conv_weights_fwd(w.data(), M, K, pk.data());
+    float *din = nullptr, *dw = nullptr, *db = nullptr, *dout = nullptr, *dmask = nullptr, *dinj = nullptr;
+    ST_TRY(dmalloc(&din, n_in)); ST_TRY(dmalloc(&dw, pk.size())); ST_TRY(dmalloc(&db, hb.size())); ST_TRY(dmalloc(&dout, n_out));
+    HIP_TRY(hipMemcpy(din, hin.data(), n_in * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    if (dgrad_epilogue) {
+        ST_TRY(dmalloc(&dmask, n_out)); ST_TRY(dmalloc(&dinj, n_out));
+        for (size_t off = 0; off < n_out; off += n_in) {      // reuse the random input as mask / inject data
+            const size_t n = std::min(n_in, n_out - off);
+            HIP_TRY(hipMemcpy(dmask + off, din, n * 4, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(dinj + off, din, n * 4, hipMemcpyDeviceToDevice));
+        }
+    }
+    ConvProblem p{};
+    p.in = din; p.wpack = dw; p.bias = dgrad_epilogue ? nullptr : db; p.out = dout; p.mask_src = dmask; p.inject = dinj;
+    p.K = K; p.M = M; p.MPad = conv_mpad(M); p.H = H; p.W = W; p.relu = dgrad_epilogue ? 0 : 1;
+    if (cfg < 0) cfg = conv_pick_config(p);
+    if (cfg_used) *cfg_used = cfg;
+    hipStream_t s;
+    HIP_TRY(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int rc = ST_OK;
+    for (int i = 0; i < 2 && rc == ST_OK; ++i) if (launch_conv3x3_cfg(p, cfg, s) != hipSuccess) rc = fail(ST_ERR_HIP, "conv launch failed (cfg %d)", cfg);
+    if (rc == ST_OK) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) (void)launch_conv3x3_cfg(p, cfg, s);
+        (void)hipEventRecord(e1, s);
+        if (hipStreamSynchronize(s) != hipSuccess) rc = fail(ST_ERR_HIP, "conv bench sync failed");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_ms = ms / iters;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    dfree(din); dfree(dw); dfree(db); dfree(dout); dfree(dmask); dfree(dinj);
+    return rc;
+}
+
 }  // extern "C"

@@ -8,7 +8,7 @@
 namespace st2 {
 
 constexpr int kMaxPartials = 1024;   // grid cap (= partial-sum slots) of every reducing kernel
-constexpr int kConvCC = 8;           // input-channel chunk staged in LDS by the conv kernel
+constexpr int kConvCC = 4;           // K granularity of the packed conv weights (staged chunk = 4 or 8)
 constexpr int kCoutQuantum = 64;     // conv weights are zero-padded to a multiple of this many outputs
 
 // ------------------------------------------------------------------------------------------
@@ -35,6 +35,11 @@ int conv_mpad(int M);
 void pack_conv_weights_fwd(const float* w /*M=Cout,K=Cin,3,3*/, int Cout, int Cin, float* dst);
 void pack_conv_weights_dgrad(const float* w /*Cout,Cin,3,3*/, int Cout, int Cin, float* dst);
 hipError_t launch_conv3x3(const ConvProblem& p, hipStream_t s);
+// explicit tile configuration (measurement hook); cfg < 0 = heuristic
+int conv_num_configs();
+const char* conv_config_name(int cfg);
+int conv_pick_config(const ConvProblem& p);
+hipError_t launch_conv3x3_cfg(const ConvProblem& p, int cfg, hipStream_t s);
 // conv1_1-style dgrad (tiny M): direct VALU kernel, w is the ORIGINAL (Cout,Cin,3,3) layout
 bool conv_dgrad_smallM_ok(int Cout, int Cin);
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-layer view of one benchmark iteration from a rocprofv3 --kernel-trace CSV (1024^2 VGG19 workload)."""
+import csv
+import sys
+
+path = sys.argv[1]
+size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+rows = list(csv.DictReader(open(path)))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+idx = [i for i, r in enumerate(rows) if 'image_pass' in r['Kernel_Name']]
+which = int(sys.argv[3]) if len(sys.argv) > 3 else len(idx) // 2
+it = rows[idx[which - 1] + 1: idx[which] + 1]
+fw = [('conv1_1', 3, 64, 1), ('conv1_2', 64, 64, 1), ('conv2_1', 64, 128, 2), ('conv2_2', 128, 128, 2),
+      ('conv3_1', 128, 256, 4), ('conv3_2', 256, 256, 4), ('conv3_3', 256, 256, 4), ('conv3_4', 256, 256, 4),
+      ('conv4_1', 256, 512, 8), ('conv4_2', 512, 512, 8), ('conv4_3', 512, 512, 8), ('conv4_4', 512, 512, 8),
+      ('conv5_1', 512, 512, 16)]
+convs = [r for r in it if 'conv3x3' in r['Kernel_Name']]
+names = [f[0] + ' fwd' for f in fw] + [f[0] + ' bwd' for f in reversed(fw)]
+specs = fw + list(reversed(fw))
+tot = totf = 0
+for r, n, s in zip(convs, names, specs):
+    d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    px = (size // s[3]) ** 2
+    fl = 2 * 9 * s[1] * s[2] * px
+    tot += d
+    totf += fl
+    kn = r['Kernel_Name'].split('(')[0].replace('void st2::', '')[:34]
+    print('%-12s %-34s wgs=%-6d %8.1f us %6.1f TF/s  vgpr=%s+%s lds=%s' % (
+        n, kn, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), d, fl / d / 1e6, r['VGPR_Count'],
+        r['Accum_VGPR_Count'], r['LDS_Block_Size']))
+print('conv total %.1f us, %.1f TF/s' % (tot, totf / tot / 1e6))
+print('--- every kernel of the iteration (duration, gap to previous)')
+prev = None
+other = 0
+for r in it:
+    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    gap = (s - prev) / 1e3 if prev else 0
+    prev = e
+    if 'conv3x3_mfma' not in r['Kernel_Name']:
+        other += (e - s) / 1e3
+        print('%-44s %9.1f us gap %6.1f' % (r['Kernel_Name'].split('(')[0].replace('void st2::', '')[:44], (e - s) / 1e3, gap))
+print('non-conv-mfma kernels %.1f us; iteration span %.1f us' % (
+    other, (int(it[-1]['End_Timestamp']) - int(it[0]['Start_Timestamp'])) / 1e3))
