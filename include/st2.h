@@ -109,6 +109,9 @@ int st_profile_read(st_ctx* ctx, long long* launches, double* ms, double* flops,
  * dgrad_epilogue != 0 adds the ReLU-mask + injected-diff epilogue of the backward pass. */
 int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_epilogue, int iters,
                   double* avg_ms, int* cfg_used);
+/* matrix-pipe ceiling probe: variant 0 = register operands, 1 = + LDS operand reads; blocks_per_cu
+ * 256-thread workgroups per CU; returns sustained TFLOP/s of v_mfma_f32_32x32x2_f32 */
+int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops);
 int st_conv_num_configs(void);
 const char* st_conv_config_name(int cfg);
 

@@ -62,6 +62,7 @@ PROTOTYPES = {
     'st_profile_read': (c_int, [c_void_p, POINTER(c_longlong), POINTER(c_double), POINTER(c_double),
                                 POINTER(c_double)]),
     'st_bench_conv': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_int)]),
+    'st_bench_mfma': (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
     'st_conv_num_configs': (c_int, []),
     'st_conv_config_name': (c_char_p, [c_int]),
 }

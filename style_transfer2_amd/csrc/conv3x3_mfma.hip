@@ -23,7 +23,7 @@ namespace st2 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int CC = kConvCC;          // K granularity of the packed weights
-constexpr int IN_W = 34;
+constexpr int IN_W = 40;            // LDS activation row: pixels x0-4 .. x0+35 (10 aligned quads)
 constexpr int NTHREADS = 256;
 
 int conv_mpad(int M) { return (M + kCoutQuantum - 1) / kCoutQuantum * kCoutQuantum; }
@@ -62,19 +62,21 @@ struct ConvKArgs {
     const float* in; const float* wpack; const float* bias; float* out;
     const float* mask_src; const float* inject;
     int K, M, MPad, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
+    unsigned in_bytes, w_bytes;   // extents of `in` and `wpack` for the buffer descriptors
+    unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
 };
 
-// One zero word every out-of-image / out-of-range lane of an LDS-DMA points at.
-__device__ float g_zero_page[64];
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+constexpr unsigned kOOB = 0xffffffffu;       // a buffer voffset beyond num_records: the DMA writes zeros
 
-// Staging is done entirely by LDS-DMA (global_load_lds: no VGPR round trip, asynchronous), into a
-// double-buffered LDS image; one barrier per chunk:
-//     DMA(chunk c+1 -> buf[~c])  ||  MFMA(chunk c from buf[c])  ;  vmcnt(0) ; barrier
-template <int BM, int ROWS, int WAVES_M, int WAVES_N, int CCK>
-__global__ __launch_bounds__(NTHREADS) void conv3x3_mfma_f32(const ConvKArgs a)
+// Staging is done entirely by LDS-DMA (buffer_load ... lds: no VGPR round trip, asynchronous,
+// hardware zero-fill for out-of-range lanes = the conv's zero padding) into a double-buffered LDS
+// image.  Every per-lane offset is computed ONCE; per chunk only a scalar offset advances.
+//   ALIGNED (W % 4 == 0): an activation row is 10 aligned quads (x0-4 .. x0+35) -> dwordx4 DMA
+//   else                 : the same 40-float row image, one dword per lane
+// DIAG = 1 adds s_memtime/s_memrealtime stamps around the main loop (measurement builds only).
+template <int BM, int ROWS, int WAVES_M, int WAVES_N, int CCK, bool ALIGNED, int DIAG>
+__device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
 {
     constexpr int TM = BM / WAVES_M / 32;        // 32-row MFMA tiles per wave along M
     constexpr int TN = ROWS / WAVES_N;           // image rows (32-pixel MFMA tiles) per wave
@@ -84,14 +86,18 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_mfma_f32(const ConvKArgs a)
     constexpr int IN_ROWS = ROWS + 2;
     constexpr int IN_PLANE = IN_ROWS * IN_W;
     constexpr int N_IN = CCK * IN_PLANE;                      // floats in the activation tile
-    constexpr int N_IN_PAD = (N_IN + 63) / 64 * 64;
+    constexpr int I_LANE = ALIGNED ? 4 : 1;                   // floats per lane per DMA
+    constexpr int I_INSTR = (N_IN / I_LANE + 63) / 64;        // wave-DMAs per activation tile
+    constexpr int N_IN_PAD = I_INSTR * 64 * I_LANE;
     constexpr int W_FLOATS = 9 * CCK * BM;                    // floats in the weight slab
     constexpr int BUF = W_FLOATS + N_IN_PAD;
     constexpr int W_INSTR = W_FLOATS / 4 / 64;                // dwordx4 wave-DMAs per slab
-    constexpr int I_INSTR = N_IN_PAD / 64;                    // dword wave-DMAs per activation tile
     constexpr int W_PER_WAVE = (W_INSTR + 3) / 4;
     constexpr int I_PER_WAVE = (I_INSTR + 3) / 4;
+    constexpr int NPIECE = W_PER_WAVE + I_PER_WAVE;
+    constexpr int NSTEP = 9 * (CCK / 2);
     static_assert(W_FLOATS % 256 == 0, "weight slab is a whole number of 1-KiB DMA pieces");
+    static_assert(NPIECE <= NSTEP, "DMA pieces are issued one per k-step");
 
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
@@ -115,49 +121,53 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_mfma_f32(const ConvKArgs a)
     const int y0 = ty * ROWS;
     const int x0 = tx * 32;
 
-    const size_t plane = (size_t)a.H * a.W;
+    const unsigned plane = (unsigned)a.H * a.W;
 
-    // ---- per-lane DMA sources that do not change from chunk to chunk ----
-    int soff[I_PER_WAVE], scc[I_PER_WAVE];       // spatial offset (or -1) and channel-in-chunk
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+
+    // ---- per-lane DMA byte offsets, constant over the whole K loop ----
+    unsigned ioff[I_PER_WAVE];
+    int icc[I_PER_WAVE];                         // channel-in-chunk (for the ragged last chunk)
 #pragma unroll
     for (int t = 0; t < I_PER_WAVE; ++t) {
-        const int e = (wave + 4 * t) * 64 + lane;
+        const int e = ((wave + 4 * t) * 64 + lane) * I_LANE;      // first float of this lane in the tile image
         const int c = e / IN_PLANE;
         const int rem = e - c * IN_PLANE;
         const int rr = rem / IN_W;
         const int col = rem - rr * IN_W;
-        const int gy = y0 - 1 + rr, gx = x0 - 1 + col;
-        const bool ok = e < N_IN && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        soff[t] = ok ? gy * a.W + gx : -1;
-        scc[t] = c;
+        const int gy = y0 - 1 + rr, gx = x0 - 4 + col;
+        const bool ok = e < N_IN && gy >= 0 && gy < a.H && gx >= 0 && gx + (I_LANE - 1) < a.W;
+        ioff[t] = ok ? ((unsigned)c * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
+        icc[t] = c;
     }
-    int woff[W_PER_WAVE];                        // float offset of this lane's float4 inside a slab
+    unsigned woff[W_PER_WAVE];
 #pragma unroll
     for (int t = 0; t < W_PER_WAVE; ++t) {
         const int f = (wave + 4 * t) * 64 + lane;
         const int sub = f / (9 * CC * BM / 4);
         const int rem = f - sub * (9 * CC * BM / 4);
         const int row = rem / (BM / 4), qq = rem % (BM / 4);
-        woff[t] = (sub * 9 * CC + row) * a.MPad + qq * 4;
+        woff[t] = (unsigned)((sub * 9 * CC + row) * a.MPad + qq * 4) * 4u;
     }
 
-    auto dma_chunk = [&](int ch, int buf) {
+    // One DMA "piece" = one wave-instruction (1 KiB of weights; 64 quads/words of activations).
+    auto dma_piece = [&](int t, int ch, int buf) {
         float* dst = smem + buf * BUF;
-        const float* wsrc = a.wpack + (size_t)ch * NSUB * 9 * CC * a.MPad + m0;
-#pragma unroll
-        for (int t = 0; t < W_PER_WAVE; ++t) {
+        if (t < W_PER_WAVE) {
             const int i = wave + 4 * t;
-            if (W_INSTR % 4 == 0 || i < W_INSTR)
-                __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + woff[t]), (lptr_t)(dst + i * 256), 16, 0, 0);
-        }
-        const int k0 = ch * CCK;
-#pragma unroll
-        for (int t = 0; t < I_PER_WAVE; ++t) {
-            const int j = wave + 4 * t;
+            if (W_INSTR % 4 == 0 || i < W_INSTR) {
+                const unsigned soff = ((unsigned)ch * NSUB * 9 * CC * a.MPad + m0) * 4u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + i * 256), 16, woff[t], soff, 0, 0);
+            }
+        } else {
+            const int u = t - W_PER_WAVE;
+            const int j = wave + 4 * u;
             if (I_INSTR % 4 == 0 || j < I_INSTR) {
-                const int gk = k0 + scc[t];
-                const float* src = (soff[t] >= 0 && gk < a.K) ? a.in + (size_t)gk * plane + soff[t] : g_zero_page;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + W_FLOATS + j * 64), 4, 0, 0);
+                const unsigned soff = (unsigned)ch * CCK * plane * 4u;
+                const unsigned vo = (ch * CCK + icc[u] < a.K) ? ioff[u] : kOOB;
+                if (ALIGNED) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(dst + W_FLOATS + j * 256), 16, vo, soff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(dst + W_FLOATS + j * 64), 4, vo, soff, 0, 0);
             }
         }
     };
@@ -173,90 +183,134 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_mfma_f32(const ConvKArgs a)
     const int khalf = lane >> 5;             // which of the 2 k's of an MFMA this lane feeds
     const int l31 = lane & 31;
     const int a_off = khalf * BM + wave_m * (TM * 32) + l31;
-    const int b_off = W_FLOATS + khalf * IN_PLANE + (wave_n * TN) * IN_W + l31;
+    const int b_off = W_FLOATS + khalf * IN_PLANE + (wave_n * TN) * IN_W + l31 + 3;   // image col 3 = pixel x0-1
 
-    dma_chunk(0, 0);
+    // k-steps (tap-major inside a chunk) form one continuous stream across chunks.  Per step:
+    //   MFMA #0 | LDS reads of the NEXT step (second register set) | one DMA piece | MFMA #1..
+    // so LDS latency hides under >= 3 queued MFMAs and the DMA of chunk c+1 is spread over the first
+    // steps of chunk c.  The chunk boundary (own DMAs landed: vmcnt(0); all waves done with the
+    // buffer: barrier) sits inside the last step, between MFMA #0 and the first reads of the next chunk.
+    float av[2][TM], bv[2][TN];
+    auto fetch = [&](const float* a_base, const float* b_base, int s2, float (&ao)[TM], float (&bo)[TN]) {
+        const int tap = s2 / (CCK / 2), kk = s2 % (CCK / 2);
+        const int dy = tap / 3, dx = tap % 3;
+        const int c = 2 * kk;                           // + khalf (folded into the bases)
+        const int sub = c / CC, cc = c % CC;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ao[i] = a_base[(sub * 9 * CC + tap * CC + cc) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bo[j] = b_base[c * IN_PLANE + (j + dy) * IN_W + dx];
+    };
+
+#pragma unroll
+    for (int t = 0; t < NPIECE; ++t) dma_piece(t, 0, 0);
     __syncthreads();                         // vmcnt(0) + barrier: chunk 0 has landed for every wave
+    unsigned long long t0 = 0, r0 = 0;
+    if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    fetch(smem + a_off, smem + b_off, 0, av[0], bv[0]);
     for (int ch = 0; ch < a.nch; ++ch) {
         const int cur = ch & 1;
-        if (ch + 1 < a.nch) dma_chunk(ch + 1, cur ^ 1);     // lands while the MFMAs below run
+        const bool more = ch + 1 < a.nch;
         const float* a_base = smem + cur * BUF + a_off;
         const float* b_base = smem + cur * BUF + b_off;
+        const float* a_next = smem + (cur ^ 1) * BUF + a_off;
+        const float* b_next = smem + (cur ^ 1) * BUF + b_off;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap % 3;
+        for (int s2 = 0; s2 < NSTEP; ++s2) {
+            // NSTEP is even, so the register set of a step is (s2 & 1) in every chunk
 #pragma unroll
-            for (int kk = 0; kk < CCK / 2; ++kk) {
-                constexpr int dummy = 0; (void)dummy;
-                const int c = 2 * kk;                       // + khalf (folded into the bases)
-                const int sub = c / CC, cc = c % CC;
-                float av[TM], bv[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = a_base[(sub * 9 * CC + tap * CC + cc) * BM + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = b_base[c * IN_PLANE + (j + dy) * IN_W + dx];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            for (int ij = 0; ij < TM * TN; ++ij) {
+                const int i = ij / TN, j = ij % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2 & 1][i], bv[s2 & 1][j], acc[i][j], 0, 0, 0);
+                if (ij == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s2 + 1 < NSTEP) {
+                        fetch(a_base, b_base, s2 + 1, av[(s2 + 1) & 1], bv[(s2 + 1) & 1]);
+                        if (s2 < NPIECE && more) dma_piece(s2, ch + 1, cur ^ 1);
+                    } else if (more) {
+                        __syncthreads();
+                        fetch(a_next, b_next, 0, av[0], bv[0]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                     // own DMAs done (vmcnt 0), everyone done reading buf[cur]
     }
 
+    if (DIAG) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && a.stamps) { a.stamps[2 * blockIdx.x] = t1 - t0; a.stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    }
     // ---- epilogue: C/D map of the 32x32 MFMA: col = lane&31 (pixel), row = (e&3)+8*(e>>2)+4*(lane>>5).
     // Loads of one 32x32 tile (bias / ReLU-mask source / injected diff) are issued as a batch of 16
     // independent, unconditional loads (rows beyond M are clamped, their stores skipped).
+    // 32-bit element offsets from the (uniform) tensor bases: the tensors are < 4 GiB (checked at launch).
     const int gx = x0 + l31;
     const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int gy = y0 + wave_n * TN + j;
         if (gy >= a.H || gx >= a.W) continue;
-        const size_t pix = (size_t)gy * a.W + gx;
+        const unsigned pix = (unsigned)gy * a.W + gx;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf;
-            float v[16];
-            size_t idx[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mbase + (e & 3) + 8 * (e >> 2);
-                idx[e] = (size_t)(m < a.M ? m : a.M - 1) * plane + pix;
-                v[e] = acc[i][j][e];
+            for (int h = 0; h < 2; ++h) {            // two batches of 8 accumulator rows: fewer live registers
+                const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h;
+                float v[8];
+                unsigned off[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = mbase + (e & 3) + 8 * (e >> 2);
+                    off[e] = (unsigned)(m < a.M ? m : a.M - 1) * plane + pix;
+                    v[e] = acc[i][j][8 * h + e];
+                }
+                if (has_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += a.bias[mbase + (e & 3) + 8 * (e >> 2)];   // bias is MPad long
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                }
+                if (has_mask) {
+                    float mk[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mk[e] = a.mask_src[off[e]];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.0f ? v[e] : 0.0f;
+                }
+                if (has_inj) {
+                    float ij[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ij[e] = a.inject[off[e]];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += ij[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[e];
             }
-            if (has_bias) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] += a.bias[mbase + (e & 3) + 8 * (e >> 2)];   // bias is MPad long
-            }
-            if (a.relu) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
-            }
-            if (has_mask) {
-                float mk[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) mk[e] = a.mask_src[idx[e]];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = mk[e] > 0.0f ? v[e] : 0.0f;
-            }
-            if (has_inj) {
-                float ij[16];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) ij[e] = a.inject[idx[e]];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] += ij[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[idx[e]] = v[e];
         }
     }
 }
 
-template <int BM, int ROWS, int WAVES_M, int WAVES_N, int CCK>
-static hipError_t run(const ConvProblem& p, hipStream_t s)
+// Non-template kernel entry points (the waves-per-SIMD launch bound must be a literal).
+#define ST2_CONV_KERNEL(NAME, BM, ROWS, WM, WN, CCK, DIAG, WPE)                                          \
+    __global__ __launch_bounds__(NTHREADS, WPE) void NAME##_q(const ConvKArgs a) { conv3x3_body<BM, ROWS, WM, WN, CCK, true, DIAG>(a); } \
+    __global__ __launch_bounds__(NTHREADS, WPE) void NAME##_w(const ConvKArgs a) { conv3x3_body<BM, ROWS, WM, WN, CCK, false, DIAG>(a); }
+ST2_CONV_KERNEL(conv3x3_mfma_f32_128x128_cc4, 128, 4, 2, 2, 4, 0, 3)
+ST2_CONV_KERNEL(conv3x3_mfma_f32_128x256_cc4, 128, 8, 2, 2, 4, 0, 2)
+ST2_CONV_KERNEL(conv3x3_mfma_f32_64x256_cc4, 64, 8, 1, 4, 4, 0, 3)
+ST2_CONV_KERNEL(conv3x3_mfma_f32_64x128_cc4, 64, 4, 1, 4, 4, 0, 3)
+ST2_CONV_KERNEL(conv3x3_mfma_f32_64x256_cc8, 64, 8, 1, 4, 8, 0, 2)
+ST2_CONV_KERNEL(conv3x3_mfma_f32_128x128_cc8, 128, 4, 2, 2, 8, 0, 1)
+ST2_CONV_KERNEL(conv3x3_mfma_f32_128x128_cc4_stamped, 128, 4, 2, 2, 4, 1, 3)
+
+typedef void (*conv_kernel_t)(const ConvKArgs);
+
+static hipError_t run(const ConvProblem& p, int BM, int ROWS, int CCK, conv_kernel_t k_quad, conv_kernel_t k_word, hipStream_t s)
 {
     ConvKArgs k;
     k.in = p.in; k.wpack = p.wpack; k.bias = p.bias; k.out = p.out;
@@ -267,48 +321,72 @@ static hipError_t run(const ConvProblem& p, hipStream_t s)
     k.tiles_y = (p.H + ROWS - 1) / ROWS;
     k.n_mtiles = p.MPad / BM;
     k.relu = p.relu;
+    k.stamps = p.stamps;
+    // 32-bit buffer addressing: activations, weight pack and output must each be < 4 GiB
+    const unsigned long long in_bytes = 4ull * p.K * p.H * p.W, w_bytes = 4ull * conv_pack_floats(p.K, p.M);
+    const unsigned long long out_bytes = 4ull * p.M * p.H * p.W;
+    if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull || out_bytes >= 0xfffffff0ull) return hipErrorInvalidValue;
+    k.in_bytes = (unsigned)in_bytes; k.w_bytes = (unsigned)w_bytes;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    conv3x3_mfma_f32<BM, ROWS, WAVES_M, WAVES_N, CCK><<<dim3((unsigned)nblk), dim3(NTHREADS), 0, s>>>(k);
+    const bool aligned = p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0;
+    (aligned ? k_quad : k_word)<<<dim3((unsigned)nblk), dim3(NTHREADS), 0, s>>>(k);
     return hipGetLastError();
 }
 
-int conv_num_configs() { return 6; }
+int conv_num_configs() { return 7; }
 
 const char* conv_config_name(int cfg)
 {
-    static const char* names[] = {"128x128px cc4", "128x256px cc4", "64x256px cc4", "64x128px cc4", "64x256px cc8", "128x128px cc8"};
-    return cfg >= 0 && cfg < 6 ? names[cfg] : "?";
+    static const char* names[] = {"128x128px cc4", "128x256px cc4", "64x256px cc4", "64x128px cc4", "64x256px cc8", "128x128px cc8",
+                                  "STAMPED 128x128px cc4"};
+    return cfg >= 0 && cfg < 7 ? names[cfg] : "?";
 }
 
+// Tile choice by a small occupancy model.  A launch is a number of equal blocks; each CU receives
+// n = ceil(blocks / 256) of them and runs up to `occ` at a time.  The matrix pipe is shared, so a CU's
+// time is (work of the blocks it runs) / (pipe efficiency at that many co-resident waves per SIMD):
+//   eff(1) .. eff(4+) measured on MI355X with this kernel (sweeps under profiles/): one wave per SIMD
+//   cannot hide the chunk-boundary bubbles, three or four nearly can.
+// Full rounds of `occ` blocks run at eff(occ); the ragged tail of m < occ blocks runs at eff(m).
 int conv_pick_config(const ConvProblem& p)
 {
-    const long long px8 = (long long)((p.W + 31) / 32) * ((p.H + 7) / 8);
-    const long long px4 = (long long)((p.W + 31) / 32) * ((p.H + 3) / 4);
-    if (p.MPad % 128 == 0) {
-        // 128 x 256-pixel tiles while they still give every CU a few blocks, else 128 x 128,
-        // else (few blocks: conv5_1) 64 x 128
-        if (px8 * (p.MPad / 128) >= 1024) return 1;
-        if (px4 * (p.MPad / 128) >= 512) return 0;
-        return 3;
+    struct Cand { int cfg, bm, rows, occ; };
+    static const Cand cands[] = {{1, 128, 8, 2}, {0, 128, 4, 3}, {2, 64, 8, 4}, {3, 64, 4, 5}};
+    static const double eff[6] = {0.0, 0.66, 0.88, 0.93, 0.95, 0.96};
+    const long long tx = (p.W + 31) / 32;
+    int best = 3;
+    double best_t = 1e300;
+    for (const Cand& c : cands) {
+        if (p.MPad % c.bm != 0) continue;
+        const long long blocks = tx * ((p.H + c.rows - 1) / c.rows) * (p.MPad / c.bm);
+        const double work = (double)c.bm * c.rows;                 // per-block MFMA work (x K, common)
+        const long long n = (blocks + 255) / 256;
+        const long long rounds = n / c.occ, tail = n % c.occ;
+        double t = rounds * c.occ * work / eff[c.occ];
+        if (tail) t += tail * work / eff[tail];
+        t *= 1.0 + 0.02 * (c.bm == 64);                              // 64-row tiles re-read activations twice as often
+        if (t < best_t) { best_t = t; best = c.cfg; }
     }
-    if (px8 * (p.MPad / 64) >= 1024) return 2;
-    return 3;
+    return best;
 }
 
 hipError_t launch_conv3x3_cfg(const ConvProblem& p, int cfg, hipStream_t s)
 {
     if (p.MPad % kCoutQuantum != 0 || p.MPad < p.M) return hipErrorInvalidValue;
     if (cfg < 0) cfg = conv_pick_config(p);
-    if ((cfg == 0 || cfg == 1 || cfg == 5) && p.MPad % 128 != 0) return hipErrorInvalidValue;
+    if ((cfg == 0 || cfg == 1 || cfg >= 5) && p.MPad % 128 != 0) return hipErrorInvalidValue;
+#define ST2_RUN(NAME, BM, ROWS, CCK) return run(p, BM, ROWS, CCK, NAME##_q, NAME##_w, s)
     switch (cfg) {
-    case 0: return run<128, 4, 2, 2, 4>(p, s);
-    case 1: return run<128, 8, 2, 2, 4>(p, s);
-    case 2: return run<64, 8, 1, 4, 4>(p, s);
-    case 3: return run<64, 4, 1, 4, 4>(p, s);
-    case 4: return run<64, 8, 1, 4, 8>(p, s);
-    case 5: return run<128, 4, 2, 2, 8>(p, s);
+    case 0: ST2_RUN(conv3x3_mfma_f32_128x128_cc4, 128, 4, 4);
+    case 1: ST2_RUN(conv3x3_mfma_f32_128x256_cc4, 128, 8, 4);
+    case 2: ST2_RUN(conv3x3_mfma_f32_64x256_cc4, 64, 8, 4);
+    case 3: ST2_RUN(conv3x3_mfma_f32_64x128_cc4, 64, 4, 4);
+    case 4: ST2_RUN(conv3x3_mfma_f32_64x256_cc8, 64, 8, 8);
+    case 5: ST2_RUN(conv3x3_mfma_f32_128x128_cc8, 128, 4, 8);
+    case 6: ST2_RUN(conv3x3_mfma_f32_128x128_cc4_stamped, 128, 4, 4);
     }
+#undef ST2_RUN
     return hipErrorInvalidValue;
 }
 
@@ -382,6 +460,85 @@ hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* d
     const size_t lds = smallM_lds(Cout, Cin);
     dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
     conv3x3_dgrad_smallM<<<grid, dim3(256), lds, s>>>(dy, w, dx, inject, Cout, Cin, H, W);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// Ceiling probes (measurement only): what the matrix pipe sustains on this chip for the same
+// instruction with (variant 0) register operands only, (variant 1) + the conv kernel's LDS operand
+// reads, (variant 2) variant 1 at 1 wave per SIMD.
+// ------------------------------------------------------------------------------------------
+// variant: 0 registers only (smooth data) | 1 LDS reads, smooth data | 2 LDS reads, random data |
+//          3 = 2 with the conv kernel's pinned issue order | 4 = random register operands, no LDS
+template <int VARIANT>
+__global__ __launch_bounds__(256) void mfma_probe_k(float* out, int iters, float seed)
+{
+    __shared__ float lds[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256) {
+        unsigned h = (i + 1) * 2654435761u + blockIdx.x * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        lds[i] = (VARIANT >= 2) ? ((h & 0xffffff) / 8388608.0f - 1.0f) : seed + i * 1e-4f;
+    }
+    __syncthreads();
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float a0 = seed + threadIdx.x * 1e-3f, a1 = a0 * 0.5f, b0 = 1.f - a0, b1 = b0 * 0.25f;
+    if (VARIANT == 4) { a0 = lds[threadIdx.x]; a1 = lds[threadIdx.x + 256]; b0 = lds[threadIdx.x + 512]; b1 = lds[threadIdx.x + 768]; }
+    const float* base = lds + (threadIdx.x & 63);
+    for (int it = 0; it < iters; ++it) {
+        if (VARIANT == 3) {
+            float av[2][2], bv[2][2];
+            av[0][0] = base[0]; av[0][1] = base[32]; bv[0][0] = base[4096]; bv[0][1] = base[4096 + 34];
+#pragma unroll
+            for (int s2 = 0; s2 < 18; ++s2) {
+#pragma unroll
+                for (int ij = 0; ij < 4; ++ij) {
+                    acc[ij] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2 & 1][ij >> 1], bv[s2 & 1][ij & 1], acc[ij], 0, 0, 0);
+                    if (ij == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (s2 + 1 < 18) {
+                            av[(s2 + 1) & 1][0] = base[(s2 + 1) * 128]; av[(s2 + 1) & 1][1] = base[(s2 + 1) * 128 + 32];
+                            bv[(s2 + 1) & 1][0] = base[4096 + (s2 + 1) * 70]; bv[(s2 + 1) & 1][1] = base[4096 + (s2 + 1) * 70 + 34];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int s2 = 0; s2 < 18; ++s2) {
+                if (VARIANT >= 1 && VARIANT <= 2) {
+                    a0 = base[s2 * 128]; a1 = base[s2 * 128 + 32];
+                    b0 = base[4096 + s2 * 70]; b1 = base[4096 + s2 * 70 + 34];
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
+            }
+        }
+    }
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r += acc[i][e];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+hipError_t launch_mfma_probe(int variant, float* out, int blocks, int iters, hipStream_t s)
+{
+    switch (variant) {
+    case 0: mfma_probe_k<0><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
+    case 1: mfma_probe_k<1><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
+    case 2: mfma_probe_k<2><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
+    case 3: mfma_probe_k<3><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
+    default: mfma_probe_k<4><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
+    }
     return hipGetLastError();
 }
 

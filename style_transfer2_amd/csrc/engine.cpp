@@ -1022,6 +1022,32 @@ int st_profile_read(st_ctx* c, long long* launches, double* ms, double* flops, d
     return ST_OK;
 }
 
+int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops)
+{
+    if (!tflops || blocks_per_cu <= 0) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device_id));
+    const int blocks = 256 * blocks_per_cu, iters = 2000;
+    float* out = nullptr;
+    ST_TRY(dmalloc(&out, (size_t)blocks * 256));
+    hipStream_t s;
+    HIP_TRY(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    (void)launch_mfma_probe(variant, out, blocks, iters, s);
+    (void)hipEventRecord(e0, s);
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) (void)launch_mfma_probe(variant, out, blocks, iters, s);
+    (void)hipEventRecord(e1, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)reps * blocks * 4 /*waves*/ * iters * 72.0 * 4096.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    dfree(out);
+    return ST_OK;
+}
+
 int st_conv_num_configs(void) { return conv_num_configs(); }
 const char* st_conv_config_name(int cfg) { return conv_config_name(cfg); }
 
@@ -1055,6 +1081,9 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     p.K = K; p.M = M; p.MPad = conv_mpad(M); p.H = H; p.W = W; p.relu = dgrad_epilogue ? 0 : 1;
     if (cfg < 0) cfg = conv_pick_config(p);
     if (cfg_used) *cfg_used = cfg;
+    unsigned long long* dstamps = nullptr;
+    const size_t max_blocks = (size_t)((W + 31) / 32) * ((H + 3) / 4) * (p.MPad / 64);
+    if (cfg >= 6) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
     hipStream_t s;
     HIP_TRY(hipStreamCreate(&s));
     hipEvent_t e0, e1;
@@ -1069,7 +1098,19 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, e0, e1);
         *avg_ms = ms / iters;
+        if (dstamps) {     // in-kernel clock and cycles of the main loop, median block
+            std::vector<unsigned long long> h(max_blocks * 2);
+            (void)hipMemcpy(h.data(), dstamps, max_blocks * 16, hipMemcpyDeviceToHost);
+            std::vector<double> cyc, clk;
+            for (size_t b = 0; b < max_blocks; ++b) if (h[2 * b + 1]) { cyc.push_back((double)h[2 * b]); clk.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1); }
+            if (!cyc.empty()) {
+                std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+                fprintf(stderr, "[stamps] blocks=%zu loop cycles median=%.0f (min %.0f max %.0f) in-kernel clock median=%.3f GHz; chunks=%d -> %.0f cycles/chunk\n",
+                        cyc.size(), cyc[cyc.size() / 2], cyc.front(), cyc.back(), clk[clk.size() / 2], (K + 3) / 4, cyc[cyc.size() / 2] / ((K + 3) / 4));
+            }
+        }
     }
+    if (dstamps) (void)hipFree(dstamps);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
     dfree(din); dfree(dw); dfree(db); dfree(dout); dfree(dmask); dfree(dinj);
     return rc;

@@ -28,6 +28,7 @@ struct ConvProblem {
     const float* inject;    // [M][H][W] or nullptr (dgrad only)
     int K, M, MPad, H, W;
     int relu;               // forward epilogue
+    unsigned long long* stamps = nullptr;   // diagnostic configs only
 };
 size_t conv_pack_floats(int K, int M);                       // floats in a packed weight buffer
 int conv_mpad(int M);
@@ -40,6 +41,7 @@ int conv_num_configs();
 const char* conv_config_name(int cfg);
 int conv_pick_config(const ConvProblem& p);
 hipError_t launch_conv3x3_cfg(const ConvProblem& p, int cfg, hipStream_t s);
+hipError_t launch_mfma_probe(int variant, float* out, int blocks, int iters, hipStream_t s);
 // conv1_1-style dgrad (tiny M): direct VALU kernel, w is the ORIGINAL (Cout,Cin,3,3) layout
 bool conv_dgrad_smallM_ok(int Cout, int Cin);
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,

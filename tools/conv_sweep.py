@@ -12,6 +12,7 @@ only = sys.argv[2].split(',') if len(sys.argv) > 2 else None
 LAYERS = [('conv1_1', 3, 64, 1), ('conv1_2', 64, 64, 1), ('conv2_1', 64, 128, 2), ('conv2_2', 128, 128, 2),
           ('conv3_1', 128, 256, 4), ('conv3_2', 256, 256, 4), ('conv4_1', 256, 512, 8), ('conv4_2', 512, 512, 8),
           ('conv5_1', 512, 512, 16)]
+ITERS = int(os.environ.get("ITERS", "40"))
 ncfg = lib.st_conv_num_configs()
 names = [lib.st_conv_config_name(i).decode() for i in range(ncfg)]
 print('configs:', names)
@@ -27,7 +28,7 @@ for name, cin, cout, div in LAYERS:
         used = ctypes.c_int()
         for cfg in [-1] + list(range(ncfg)):
             ms = ctypes.c_double()
-            rc = lib.st_bench_conv(0, K, M, hw, hw, cfg, 1 if mode == 'bwd' else 0, 5, ctypes.byref(ms), ctypes.byref(used))
+            rc = lib.st_bench_conv(0, K, M, hw, hw, cfg, 1 if mode == "bwd" else 0, ITERS, ctypes.byref(ms), ctypes.byref(used))
             if rc != 0:
                 res.append('   -  ')
                 continue
