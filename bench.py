@@ -28,6 +28,7 @@ sys.path.insert(0, HERE)
 
 import style_transfer2_amd as st2                      # noqa: E402
 from style_transfer2_amd import weights as st2_weights  # noqa: E402
+from style_transfer2_amd import distributed as st2_dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 WEIGHTS = {'content': {'conv4_2': 0.08},
@@ -94,36 +95,11 @@ def main():
     ap.add_argument('--cpu-size', type=int, default=0, help='image size of the CPU sample (default: --size)')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+    group = st2_dist.Group()
+    rank, local_rank, world = group.rank, group.local_rank, group.world
 
     job = make_job(args.size, args.optimizer, local_rank)
-    for _ in range(args.warmup):
-        job.step_async()
-    job.engine.sync()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.step_async()
-    job.engine.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = st2_dist.timed_region(group, job.step_async, args.steps, args.warmup, job.engine.sync)
 
     # per-kernel-class HIP-event timing of the same steps (separate leg so `value` carries no event overhead)
     prof_steps = max(3, min(10, args.steps))
@@ -163,9 +139,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_size or args.size, args.optimizer)
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    group.close()
 
 
 if __name__ == '__main__':

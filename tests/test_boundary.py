@@ -1,0 +1,241 @@
+"""Drop-in boundary on the CPU: wire compatibility of messages.py with the reference's pickles, the
+worker's message loop and ordering guarantees, the C ABI surface, and the "no CPU fallback" rule."""
+import json
+import os
+import pickle
+import re
+import subprocess
+import sys
+from collections import OrderedDict, deque
+
+import numpy as np
+import pytest
+
+import messages
+import worker as worker_mod
+from helpers import GOLDEN, load_json
+from style_transfer2_amd import capi, transfer
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F32 = np.float32
+
+
+# ------------------------------------------------------------------------------------- messages
+def _same(a, b):
+    if isinstance(a, np.ndarray):
+        return isinstance(b, np.ndarray) and a.dtype == b.dtype and np.array_equal(a, b)
+    if isinstance(a, dict):
+        return list(a) == list(b) and all(_same(a[k], b[k]) for k in a)
+    return type(a) == type(b) and a == b
+
+
+def _ours():
+    m = messages
+    img = np.arange(2 * 3 * 3, dtype=np.uint8).reshape(2, 3, 3)
+    weights = {'content': {'conv2_2': 0.08, 'conv1_2': 0.5},
+               'style': {'conv1_1': 1, 'conv2_1': 1, 'conv1_2': 0.3, 'pool1': 0.7}, 'deepdream': {'conv2_1': 0.02}}
+    params = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+    return OrderedDict([
+        ('SetImages', m.SetImages(None, img, img, m.SetImages.RESAMPLE, True)),
+        ('SetImagesResample', m.SetImages((4, 6), m.SetImages.RESAMPLE, m.SetImages.RESAMPLE)),
+        ('SetOptimizer', m.SetOptimizer('adam')),
+        ('SetOptimizerStep', m.SetOptimizer('lbfgs', 0.5)),
+        ('SetWeights', m.SetWeights(weights, params)),
+        ('StartIteration', m.StartIteration()), ('PauseIteration', m.PauseIteration()),
+        ('Shutdown', m.Shutdown()), ('WorkerReady', m.WorkerReady(['data', 'conv1_1'])),
+        ('Iterate', m.Iterate(img.astype(F32), 3, OrderedDict(loss=1.5, fevals=3))),
+        ('GetImages', m.GetImages()),
+    ])
+
+
+def test_messages_are_byte_compatible_with_the_reference_pickles():
+    """Reference pickles load into our classes with identical state, and our pickles are the same
+    BYTES as the reference's (same module path, class names, attribute names and order)."""
+    golden = load_json('message_pickles.json')
+    for name, obj in _ours().items():
+        ref_bytes = bytes.fromhex(golden[name])
+        theirs = pickle.loads(ref_bytes)
+        assert type(theirs) is type(obj) and type(theirs).__module__ == 'messages'
+        assert _same(vars(theirs), vars(obj)), name
+        assert pickle.dumps(obj, protocol=pickle.DEFAULT_PROTOCOL) == ref_bytes, name
+
+
+def test_message_constants_and_validation():
+    assert messages.SetImages.RESAMPLE == 1
+    assert messages.SetOptimizer.step_sizes == {'adam': 10, 'lbfgs': 1}
+    assert messages.SetWeights.loss_names == ('content', 'style', 'deepdream')
+    assert messages.SetWeights.scalar_loss_names == ('tv', 'tv_power', 'p', 'p_power')
+    assert messages.SetOptimizer('adam').step_size == 10 and messages.SetOptimizer('lbfgs', 3).step_size == 3
+    with pytest.raises(ValueError):
+        messages.SetOptimizer('sgd')
+    assert messages.WorkerReady().layers == []
+    assert 'ndarray, shape: (2, 2, 3)' in repr(messages.Iterate(np.zeros((2, 2, 3), F32), 1, {}))
+    for extra in ('AppUp', 'AppDown', 'Reset'):
+        assert hasattr(messages, extra)
+
+
+# --------------------------------------------------------------------------------------- worker
+class FakeSockets:
+    """In-process stand-in for the PULL/PUSH pair (pyzmq is not installed in the build container)."""
+    class Again(Exception):
+        pass
+
+    def __init__(self, inbound):
+        self.inbound = deque(inbound)
+        self.sent = []
+
+    def recv_pyobj(self, flags=0):
+        if not self.inbound:
+            if flags:
+                raise self.Again()
+            return messages.Shutdown()
+        return pickle.loads(pickle.dumps(self.inbound.popleft()))
+
+    def send_pyobj(self, obj):
+        self.sent.append(pickle.loads(pickle.dumps(obj)))
+
+
+class FakeTransfer:
+    """Records calls; becomes runnable once all three images are set (reference worker.py:140-189)."""
+    def __init__(self, max_steps=3):
+        self.calls, self.is_running, self.t, self.max_steps = [], False, 0, max_steps
+        self.have = set()
+        self.optimizer, self.optimizer_cls, self.step_size = None, None, None
+        self.model = type('M', (), {'layers': staticmethod(lambda: ['data', 'conv1_1'])})()
+
+    def __getattr__(self, name):
+        if name.startswith('set_') or name.startswith('resample_') or name in ('reset', 'pause'):
+            def call(*a):
+                self.calls.append(name)
+                if name in ('set_input', 'set_content', 'set_style'):
+                    self.have.add(name)
+                if name == 'pause':
+                    self.is_running = False
+            return call
+        raise AttributeError(name)
+
+    def check_consistency(self):
+        return len(self.have) == 3
+
+    def start(self):
+        self.calls.append('start')
+        self.is_running = self.check_consistency()
+        return self.is_running
+
+    def step(self):
+        self.t += 1
+        if self.t >= self.max_steps:
+            self.is_running = False
+        return np.full((2, 2, 3), self.t, F32), OrderedDict(loss=float(self.t), fevals=self.t)
+
+
+def run_worker(inbound, transfer_obj):
+    socks = FakeSockets(inbound)
+    wk = worker_mod.Worker({}, sock_in=socks, sock_out=socks, transfer=transfer_obj)
+    wk.run()
+    return socks.sent, transfer_obj
+
+
+def test_worker_protocol_order_and_iterates():
+    img = np.zeros((4, 4, 3), np.uint8)
+    sent, tr = run_worker([messages.SetImages(None, img, img, img, True),
+                           messages.SetWeights({'content': {}, 'style': {}, 'deepdream': {}}, {}),
+                           messages.SetOptimizer('adam', 10), messages.StartIteration()], FakeTransfer(3))
+    kinds = [type(m).__name__ for m in sent]
+    assert kinds == ['WorkerReady', 'Iterate', 'Iterate', 'Iterate', 'Shutdown']
+    assert sent[0].layers == ['data', 'conv1_1']
+    assert [m.i for m in sent[1:4]] == [1, 2, 3] and sent[3].trace['fevals'] == 3
+    assert sent[1].image.dtype == F32 and sent[1].image.shape == (2, 2, 3)
+    assert tr.calls[:4] == ['set_input', 'set_content', 'set_style', 'reset']
+    assert 'set_weights' in tr.calls and 'set_step_size' in tr.calls and tr.calls[-1] == 'start'
+
+
+def test_worker_asks_for_images_when_it_cannot_start_and_survives_garbage():
+    sent, tr = run_worker([messages.StartIteration(), 'not a message', messages.PauseIteration()], FakeTransfer())
+    assert [type(m).__name__ for m in sent] == ['WorkerReady', 'GetImages', 'Shutdown']
+    assert tr.calls == ['start', 'pause']
+
+
+def test_worker_resample_sentinels_route_to_resample_methods():
+    sent, tr = run_worker([messages.SetImages((6, 8), messages.SetImages.RESAMPLE, messages.SetImages.RESAMPLE)],
+                          FakeTransfer())
+    assert tr.calls == ['resample_input', 'resample_content']
+
+
+def test_worker_exits_with_code_2_without_backend(tmp_path):
+    """reference worker.py:51-53: missing compute backend -> message on stderr + exit code 2."""
+    cfg = tmp_path / 'c.ini'
+    cfg.write_text('[DEFAULT]\nweights = synthetic\ngpu = 0\nworker_socket = inproc://a\napp_socket = inproc://b\n')
+    code = ("import sys, types; sys.argv=['worker.py', %r];"
+            "z=types.ModuleType('zmq'); z.Context=lambda: types.SimpleNamespace(socket=lambda k: types.SimpleNamespace("
+            "bind=lambda a: None, connect=lambda a: None, send_pyobj=lambda o: None), destroy=lambda l: None);"
+            "z.PULL=z.PUSH=z.NOBLOCK=1; z.ZMQError=Exception; sys.modules['zmq']=z;"
+            "import worker; worker.main()") % str(cfg)
+    r = subprocess.run([sys.executable, '-c', code], cwd=REPO, capture_output=True, text=True,
+                       env=dict(os.environ, HIP_VISIBLE_DEVICES='-1'))
+    assert r.returncode == 2, r.stderr
+    assert 'compute backend is unavailable' in r.stderr
+
+
+# --------------------------------------------------------------------------------------- C ABI
+def test_every_header_symbol_is_exported_and_bound():
+    header = open(os.path.join(REPO, 'include', 'st2.h')).read()
+    declared = set(re.findall(r'\b(st_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 35
+    lib = capi.load_library()                      # loads without a GPU
+    for name in declared:
+        assert hasattr(lib, name), 'header declares %s but the library does not export it' % name
+    assert declared == set(capi.PROTOTYPES), declared ^ set(capi.PROTOTYPES)
+    for line in re.findall(r'/\*.*?\*/', header, re.S)[:1]:
+        assert 'worker.py' in line                 # the header cites the reference interfaces it replaces
+
+
+def test_engine_fails_loudly_without_a_gpu():
+    import style_transfer2_amd as st2
+    r = subprocess.run([sys.executable, '-c',
+                        'import style_transfer2_amd as s\ntry:\n s.Engine()\nexcept s.StError as e:\n print("ERR", e)'],
+                       cwd=REPO, capture_output=True, text=True, env=dict(os.environ, HIP_VISIBLE_DEVICES='-1'))
+    assert 'ERR st2 error 3' in r.stdout, r.stdout + r.stderr
+    os.environ['ST2_HIP_LIB'] = '/nonexistent/libst2_hip.so'
+    try:
+        capi._lib = None
+        with pytest.raises(st2.HipUnavailable):
+            capi.load_library()
+    finally:
+        del os.environ['ST2_HIP_LIB']
+        capi._lib = None
+
+
+def test_product_code_never_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may use it."""
+    offenders = []
+    for root, dirs, files in os.walk(os.path.join(REPO, 'style_transfer2_amd')):
+        for f in files:
+            if f.endswith(('.py', '.cpp', '.hip', '.h', '.cuh')):
+                text = open(os.path.join(root, f)).read()
+                if re.search(r'^\s*(import|from)\s+oracle\b', text, re.M) or 'oracle/' in text and f.endswith('.py'):
+                    offenders.append(f)
+    for f in ('worker.py', 'messages.py'):
+        if re.search(r'^\s*(import|from)\s+oracle\b', open(os.path.join(REPO, f)).read(), re.M):
+            offenders.append(f)
+    assert not offenders, offenders
+    bench = open(os.path.join(REPO, 'bench.py')).read()
+    assert bench.count('import oracle') == 1
+    assert bench.split('import oracle')[0].rsplit('\ndef ', 1)[1].startswith('cpu_baseline(')   # only inside that leg
+
+
+# --------------------------------------------------------------------------- host-side mirrors
+def test_package_weight_table_matches_pandas_vectors():
+    for name, case in load_json('weight_order.json').items():
+        rows, cells = transfer.weight_table(case['weights'])
+        assert rows == case['rows'], name
+        for kind, col in case['cells'].items():
+            for layer, v in col.items():
+                got = cells[kind][layer]
+                assert (np.isnan(got) if v is None else float(got) == v), (name, kind, layer)
+
+
+def test_config1_inputs_fixture_geometry():
+    g = np.load(os.path.join(GOLDEN, 'config1_inputs.npz'))
+    assert g['golden_gate'].shape == (192, 256, 3) and g['starry_night'].shape == (160, 256, 3)
+    assert g['golden_gate'].dtype == np.uint8

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""The style-transfer worker process, MI355X edition.
+
+Drop-in for the reference's ``worker.py`` (launched by ``app.py`` as ``worker.py [config] [-d...]``,
+reference app.py:38,341): same config keys, same sockets (PULL bind ``worker_socket``, PUSH connect
+``app_socket``), same message protocol and ordering (``WorkerReady`` first, one ``Iterate`` per step,
+``GetImages`` when it cannot iterate, ``Shutdown`` always last), exit code 2 when the compute backend
+is missing (reference worker.py:51-53).  The per-iteration work runs on the GPU through
+``style_transfer2_amd``; there is no CPU fallback.
+"""
+
+import argparse
+import configparser
+import logging
+import os
+from pathlib import Path
+import signal
+import sys
+
+MODULE_DIR = Path(__file__).parent.resolve()
+sys.path.insert(0, str(MODULE_DIR))
+
+from messages import (GetImages, Iterate, PauseIteration, SetImages, SetOptimizer, SetWeights,  # noqa: E402
+                      Shutdown, StartIteration, WorkerReady)
+import messages  # noqa: E402
+
+logger = logging.getLogger('worker')
+
+BACKEND_MSG = '''
+Error: the MI355X compute backend is unavailable (%s).
+Build it with `python -c "import __graft_entry__ as g; g.build()"` and check `gpu` in the config.'''
+
+
+# ---------------------------------------------------------------------------------------------------
+# config / logging / signals (reference utils.py:110-127, 172-190)
+# ---------------------------------------------------------------------------------------------------
+def parse_args(desc=''):
+    parser = argparse.ArgumentParser(description=desc)
+    parser.add_argument('config', nargs='?', help='the config file')
+    parser.add_argument('--debug', '-d', action='count', help='debug')
+    args = parser.parse_args()
+    args.debug = args.debug or 0
+    return args
+
+
+def read_config(args):
+    cp = configparser.ConfigParser()
+    files = [str(MODULE_DIR / 'config.ini'), str(MODULE_DIR / 'config_non_git.ini')]
+    if args.config:
+        files.append(args.config)
+    cp.read(files)
+    return cp['DEFAULT']
+
+
+def setup_logging(debug=0):
+    logging.basicConfig(level=logging.DEBUG if debug else logging.INFO, datefmt='%H:%M:%S',
+                        format='%(asctime)s.%(msecs)03d %(process)d %(name)s %(levelname)s: %(message)s')
+    if debug > 1:
+        messages.Message.debug = True
+    logging.captureWarnings(True)
+
+
+def setup_signals():
+    def on_hup(*_):
+        raise KeyboardInterrupt()
+    signal.signal(signal.SIGHUP, on_hup)
+
+
+# ---------------------------------------------------------------------------------------------------
+def build_transfer(config):
+    """Model + StyleTransfer for this worker (reference worker.py:326-332).  Exits with code 2 when the
+    HIP library, the GPU or the weights are missing."""
+    try:
+        import style_transfer2_amd as st2
+        from style_transfer2_amd import weights as st2_weights
+        gpu = config.getint('gpu', fallback=0)
+        weights_path = MODULE_DIR / config.get('caffemodel', 'models/vgg19.npz')
+        if weights_path.suffix == '.npz' and weights_path.exists():
+            params = st2_weights.load_npz(str(weights_path), st2.VGG19_TOPOLOGY)
+        elif config.get('weights', '') == 'synthetic':
+            logger.warning('Using seeded synthetic VGG19 weights (config: weights = synthetic).')
+            params = st2_weights.he_normal(st2.VGG19_TOPOLOGY, seed=0)
+        else:
+            raise st2.HipUnavailable('weights file %s not found (.npz expected; or set weights = synthetic)'
+                                     % weights_path)
+        model = st2.HipModel(params, device=max(gpu, 0))
+        return st2.StyleTransfer(model)
+    except Exception as err:  # HipUnavailable, StError, OSError ...
+        print(BACKEND_MSG % err, file=sys.stderr)
+        sys.exit(2)
+
+
+class Worker:
+    """Message loop (reference worker.py:318-409).  ``sock_in``/``sock_out`` may be injected (tests);
+    otherwise pyzmq PULL/PUSH sockets are created from the config."""
+
+    def __init__(self, config, sock_in=None, sock_out=None, transfer=None):
+        self._ctx = None
+        if sock_in is None or sock_out is None:
+            import zmq
+            self._ctx = zmq.Context()
+            sock_in = self._ctx.socket(zmq.PULL)
+            sock_out = self._ctx.socket(zmq.PUSH)
+            sock_in.bind(config['worker_socket'])
+            sock_out.connect(config['app_socket'])
+            self._again = zmq.ZMQError
+            self._noblock = zmq.NOBLOCK
+        else:
+            self._again = getattr(sock_in, 'Again', BlockingIOError)
+            self._noblock = 1
+        self.sock_in, self.sock_out = sock_in, sock_out
+        self.run_should_stop = False
+        self.transfer = transfer if transfer is not None else build_transfer(config)
+        self.sock_out.send_pyobj(WorkerReady(layers=self.transfer.model.layers()))
+
+    def close(self):
+        if self._ctx is not None:
+            self._ctx.destroy(0)
+
+    def run(self):
+        try:
+            while not self.run_should_stop:
+                if self.transfer.is_running:
+                    self._drain_then_step()
+                elif self.process_message(self.sock_in.recv_pyobj()):
+                    break
+        except KeyboardInterrupt:
+            pass
+        finally:
+            self.sock_out.send_pyobj(Shutdown())
+
+    def _drain_then_step(self):
+        """Handle everything queued without blocking, then do exactly one iteration."""
+        try:
+            while True:
+                if self.process_message(self.sock_in.recv_pyobj(self._noblock)):
+                    self.run_should_stop = True
+                    return
+        except self._again:
+            pass
+        if not self.transfer.is_running:
+            return
+        if self.transfer.check_consistency():
+            image, trace = self.transfer.step()
+            self.sock_out.send_pyobj(Iterate(image, self.transfer.t, trace))
+        else:
+            self.sock_out.send_pyobj(GetImages())
+
+    def process_message(self, msg):
+        """Returns True when the worker should shut down."""
+        tr = self.transfer
+
+        def is_image(obj):
+            return obj is not None and not isinstance(obj, int)
+
+        if isinstance(msg, SetImages):
+            if is_image(msg.input_image):
+                tr.set_input(msg.input_image)
+            elif msg.input_image == SetImages.RESAMPLE:
+                tr.resample_input(msg.size)
+            if is_image(msg.content_image):
+                tr.set_content(msg.content_image)
+            elif msg.content_image == SetImages.RESAMPLE:
+                tr.resample_content(msg.size)
+            if is_image(msg.style_image):
+                tr.set_style(msg.style_image)
+            if msg.reset_state:
+                tr.reset()
+        elif isinstance(msg, SetOptimizer):
+            tr.optimizer_cls = SetOptimizer.classes[msg.optimizer]
+            tr.set_step_size(msg.step_size)
+            if not isinstance(tr.optimizer, tr.optimizer_cls):
+                tr.reset()
+        elif isinstance(msg, SetWeights):
+            tr.set_weights(msg.weights, msg.params)
+        elif isinstance(msg, Shutdown):
+            return True
+        elif isinstance(msg, StartIteration):
+            if not tr.start():
+                self.sock_out.send_pyobj(GetImages())
+        elif isinstance(msg, PauseIteration):
+            tr.pause()
+        else:
+            logger.error('Invalid message received over ZeroMQ.')
+        return False
+
+
+def main():
+    args = parse_args(__doc__)
+    config = read_config(args)
+    debug = args.debug + config.getint('debug', 0)
+    setup_logging(debug)
+    setup_signals()
+    worker = None
+    try:
+        worker = Worker(config)
+        worker.run()
+    except ImportError as err:          # pyzmq missing
+        print(BACKEND_MSG % err, file=sys.stderr)
+        sys.exit(2)
+    finally:
+        logger.info('Shutting down worker process.')
+        if worker is not None:
+            worker.close()
+
+
+if __name__ == '__main__':
+    main()
