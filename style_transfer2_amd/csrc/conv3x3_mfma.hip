@@ -64,7 +64,11 @@ struct ConvKArgs {
     int K, M, MPad, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
     unsigned in_bytes, w_bytes;   // extents of `in` and `wpack` for the buffer descriptors
     unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
+    // style-gradient epilogue (EPI_STYLE): out = c2*acc [raw]  or  (sw / *norm) * c2*acc + (accumulate ? out : 0)
+    float c2, sw; const float* norm; int fused, accumulate; float* partial;
 };
+
+enum { EPI_CONV = 0, EPI_STYLE = 1 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr unsigned kOOB = 0xffffffffu;       // a buffer voffset beyond num_records: the DMA writes zeros
@@ -75,29 +79,35 @@ constexpr unsigned kOOB = 0xffffffffu;       // a buffer voffset beyond num_reco
 //   ALIGNED (W % 4 == 0): an activation row is 10 aligned quads (x0-4 .. x0+35) -> dwordx4 DMA
 //   else                 : the same 40-float row image, one dword per lane
 // DIAG = 1 adds s_memtime/s_memrealtime stamps around the main loop (measurement builds only).
-template <int BM, int ROWS, int WAVES_M, int WAVES_N, int CCK, bool ALIGNED, int DIAG>
+// TAPS = 9: the 3x3 conv.  TAPS = 1: a 1x1 "conv" (no halo) = the style-gradient GEMM S = D @ F with the
+// (symmetric) Gram difference D as the weight matrix, on the same pipeline.
+template <int BM, int ROWS, int WAVES_M, int WAVES_N, int CCK, bool ALIGNED, int DIAG, int TAPS = 9, int EPI = EPI_CONV>
 __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
 {
+    constexpr int HALO = TAPS == 9 ? 1 : 0;
+    constexpr int IW = HALO ? IN_W : 32;         // floats per staged activation row
     constexpr int TM = BM / WAVES_M / 32;        // 32-row MFMA tiles per wave along M
     constexpr int TN = ROWS / WAVES_N;           // image rows (32-pixel MFMA tiles) per wave
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(TM >= 1 && TN >= 1 && CCK % CC == 0, "tile");
     constexpr int NSUB = CCK / CC;               // packed sub-slabs per staged chunk
-    constexpr int IN_ROWS = ROWS + 2;
-    constexpr int IN_PLANE = IN_ROWS * IN_W;
+    constexpr int IN_ROWS = ROWS + 2 * HALO;
+    constexpr int IN_PLANE = IN_ROWS * IW;
     constexpr int N_IN = CCK * IN_PLANE;                      // floats in the activation tile
     constexpr int I_LANE = ALIGNED ? 4 : 1;                   // floats per lane per DMA
     constexpr int I_INSTR = (N_IN / I_LANE + 63) / 64;        // wave-DMAs per activation tile
     constexpr int N_IN_PAD = I_INSTR * 64 * I_LANE;
-    constexpr int W_FLOATS = 9 * CCK * BM;                    // floats in the weight slab
+    constexpr int W_FLOATS = TAPS * CCK * BM;                 // floats in the weight slab
     constexpr int BUF = W_FLOATS + N_IN_PAD;
     constexpr int W_INSTR = W_FLOATS / 4 / 64;                // dwordx4 wave-DMAs per slab
     constexpr int W_PER_WAVE = (W_INSTR + 3) / 4;
     constexpr int I_PER_WAVE = (I_INSTR + 3) / 4;
     constexpr int NPIECE = W_PER_WAVE + I_PER_WAVE;
-    constexpr int NSTEP = 9 * (CCK / 2);
+    constexpr int NSTEP = TAPS * (CCK / 2);
+    static_assert(NSTEP % 2 == 0, "two operand register sets alternate per step");
     static_assert(W_FLOATS % 256 == 0, "weight slab is a whole number of 1-KiB DMA pieces");
-    static_assert(NPIECE <= NSTEP, "DMA pieces are issued one per k-step");
+    constexpr int PPS = (NPIECE + NSTEP - 2) / (NSTEP - 1);   // DMA pieces per k-step (the last step carries the barrier instead)
+    static_assert(PPS * (NSTEP - 1) >= NPIECE, "every DMA piece has a k-step to ride on");
 
     __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
@@ -128,44 +138,45 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
 
     // ---- per-lane DMA byte offsets, constant over the whole K loop ----
     unsigned ioff[I_PER_WAVE];
-    int icc[I_PER_WAVE];                         // channel-in-chunk (for the ragged last chunk)
 #pragma unroll
     for (int t = 0; t < I_PER_WAVE; ++t) {
         const int e = ((wave + 4 * t) * 64 + lane) * I_LANE;      // first float of this lane in the tile image
         const int c = e / IN_PLANE;
         const int rem = e - c * IN_PLANE;
-        const int rr = rem / IN_W;
-        const int col = rem - rr * IN_W;
-        const int gy = y0 - 1 + rr, gx = x0 - 4 + col;
+        const int rr = rem / IW;
+        const int col = rem - rr * IW;
+        const int gy = y0 - HALO + rr, gx = x0 - 4 * HALO + col;
         const bool ok = e < N_IN && gy >= 0 && gy < a.H && gx >= 0 && gx + (I_LANE - 1) < a.W;
         ioff[t] = ok ? ((unsigned)c * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
-        icc[t] = c;
     }
     unsigned woff[W_PER_WAVE];
 #pragma unroll
     for (int t = 0; t < W_PER_WAVE; ++t) {
         const int f = (wave + 4 * t) * 64 + lane;
-        const int sub = f / (9 * CC * BM / 4);
-        const int rem = f - sub * (9 * CC * BM / 4);
+        const int sub = f / (TAPS * CC * BM / 4);
+        const int rem = f - sub * (TAPS * CC * BM / 4);
         const int row = rem / (BM / 4), qq = rem % (BM / 4);
-        woff[t] = (unsigned)((sub * 9 * CC + row) * a.MPad + qq * 4) * 4u;
+        woff[t] = (unsigned)((sub * TAPS * CC + row) * a.MPad + qq * 4) * 4u;
     }
 
     // One DMA "piece" = one wave-instruction (1 KiB of weights; 64 quads/words of activations).
+    // The chunk offset is added to the per-lane offset (not passed as soffset) so that the buffer
+    // range check covers it: rows / channels past the end of a ragged last chunk arrive as zeros.
     auto dma_piece = [&](int t, int ch, int buf) {
         float* dst = smem + buf * BUF;
         if (t < W_PER_WAVE) {
             const int i = wave + 4 * t;
             if (W_INSTR % 4 == 0 || i < W_INSTR) {
-                const unsigned soff = ((unsigned)ch * NSUB * 9 * CC * a.MPad + m0) * 4u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + i * 256), 16, woff[t], soff, 0, 0);
+                const unsigned soff = ((unsigned)ch * NSUB * TAPS * CC * a.MPad + m0) * 4u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + i * 256), 16, woff[t] + soff, 0, 0, 0);
             }
         } else {
             const int u = t - W_PER_WAVE;
             const int j = wave + 4 * u;
             if (I_INSTR % 4 == 0 || j < I_INSTR) {
-                const unsigned soff = (unsigned)ch * CCK * plane * 4u;
-                const unsigned vo = (ch * CCK + icc[u] < a.K) ? ioff[u] : kOOB;
+                const unsigned coff = (unsigned)ch * CCK * plane * 4u;
+                const unsigned vo = ioff[u] == kOOB ? kOOB : ioff[u] + coff;
+                const unsigned soff = 0;
                 if (ALIGNED) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(dst + W_FLOATS + j * 256), 16, vo, soff, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(dst + W_FLOATS + j * 64), 4, vo, soff, 0, 0);
             }
@@ -183,7 +194,7 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
     const int khalf = lane >> 5;             // which of the 2 k's of an MFMA this lane feeds
     const int l31 = lane & 31;
     const int a_off = khalf * BM + wave_m * (TM * 32) + l31;
-    const int b_off = W_FLOATS + khalf * IN_PLANE + (wave_n * TN) * IN_W + l31 + 3;   // image col 3 = pixel x0-1
+    const int b_off = W_FLOATS + khalf * IN_PLANE + (wave_n * TN) * IW + l31 + 3 * HALO;   // halo image: col 3 = pixel x0-1
 
     // k-steps (tap-major inside a chunk) form one continuous stream across chunks.  Per step:
     //   MFMA #0 | LDS reads of the NEXT step (second register set) | one DMA piece | MFMA #1..
@@ -193,13 +204,13 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
     float av[2][TM], bv[2][TN];
     auto fetch = [&](const float* a_base, const float* b_base, int s2, float (&ao)[TM], float (&bo)[TN]) {
         const int tap = s2 / (CCK / 2), kk = s2 % (CCK / 2);
-        const int dy = tap / 3, dx = tap % 3;
+        const int dy = HALO ? tap / 3 : 0, dx = HALO ? tap % 3 : 0;
         const int c = 2 * kk;                           // + khalf (folded into the bases)
         const int sub = c / CC, cc = c % CC;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) ao[i] = a_base[(sub * 9 * CC + tap * CC + cc) * BM + i * 32];
+        for (int i = 0; i < TM; ++i) ao[i] = a_base[(sub * TAPS * CC + tap * CC + cc) * BM + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bo[j] = b_base[c * IN_PLANE + (j + dy) * IN_W + dx];
+        for (int j = 0; j < TN; ++j) bo[j] = b_base[c * IN_PLANE + (j + dy) * IW + dx];
     };
 
 #pragma unroll
@@ -226,7 +237,11 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
                     __builtin_amdgcn_sched_barrier(0);
                     if (s2 + 1 < NSTEP) {
                         fetch(a_base, b_base, s2 + 1, av[(s2 + 1) & 1], bv[(s2 + 1) & 1]);
-                        if (s2 < NPIECE && more) dma_piece(s2, ch + 1, cur ^ 1);
+                        if (more) {
+#pragma unroll
+                            for (int pp = 0; pp < PPS; ++pp)
+                                if (s2 * PPS + pp < NPIECE) dma_piece(s2 * PPS + pp, ch + 1, cur ^ 1);
+                        }
                     } else if (more) {
                         __syncthreads();
                         fetch(a_next, b_next, 0, av[0], bv[0]);
@@ -247,6 +262,48 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
     // independent, unconditional loads (rows beyond M are clamped, their stores skipped).
     // 32-bit element offsets from the (uniform) tensor bases: the tensors are < 4 GiB (checked at launch).
     const int gx = x0 + l31;
+    if (EPI == EPI_STYLE) {
+        // S = c2 * (D @ F); partial[block] = sum S^2; raw: out = S; fused: out = (sw / norm) * S (+ out)
+        const float coef = a.fused ? a.sw / *a.norm : 0.f;
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gy = y0 + wave_n * TN + j;
+            if (gy >= a.H || gx >= a.W) continue;
+            const unsigned pix = (unsigned)gy * a.W + gx;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h;
+                    float v[8], old[8];
+                    unsigned off[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int m = mbase + (e & 3) + 8 * (e >> 2);
+                        off[e] = (unsigned)(m < a.M ? m : a.M - 1) * plane + pix;
+                        v[e] = acc[i][j][8 * h + e] * a.c2;
+                        if (m < a.M) ss += v[e] * v[e];
+                    }
+                    if (a.fused && a.accumulate) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) old[e] = a.out[off[e]];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float r2 = a.fused ? coef * v[e] + (a.accumulate ? old[e] : 0.f) : v[e];
+                        if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = r2;
+                    }
+                }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        __syncthreads();                     // every wave is done with the staged tiles
+        if (lane == 0) smem[wave] = ss;
+        __syncthreads();
+        if (tid == 0) a.partial[blockIdx.x] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+        return;
+    }
     const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -307,12 +364,19 @@ ST2_CONV_KERNEL(conv3x3_mfma_f32_64x128_cc4, 64, 4, 1, 4, 4, 0, 3)
 ST2_CONV_KERNEL(conv3x3_mfma_f32_64x256_cc8, 64, 8, 1, 4, 8, 0, 2)
 ST2_CONV_KERNEL(conv3x3_mfma_f32_128x128_cc8, 128, 4, 2, 2, 8, 0, 1)
 ST2_CONV_KERNEL(conv3x3_mfma_f32_128x128_cc4_stamped, 128, 4, 2, 2, 4, 1, 3)
+#define ST2_STYLE_KERNEL(NAME, BM, ROWS, WM, WN, CCK, WPE)                                                \
+    __global__ __launch_bounds__(NTHREADS, WPE) void NAME##_q(const ConvKArgs a) { conv3x3_body<BM, ROWS, WM, WN, CCK, true, 0, 1, EPI_STYLE>(a); } \
+    __global__ __launch_bounds__(NTHREADS, WPE) void NAME##_w(const ConvKArgs a) { conv3x3_body<BM, ROWS, WM, WN, CCK, false, 0, 1, EPI_STYLE>(a); }
+ST2_STYLE_KERNEL(style_grad_mfma_f32_128x128_cc32, 128, 4, 2, 2, 32, 2)
+ST2_STYLE_KERNEL(style_grad_mfma_f32_64x256_cc16, 64, 8, 1, 4, 16, 3)
 
 typedef void (*conv_kernel_t)(const ConvKArgs);
 
-static hipError_t run(const ConvProblem& p, int BM, int ROWS, int CCK, conv_kernel_t k_quad, conv_kernel_t k_word, hipStream_t s)
+static hipError_t run(const ConvProblem& p, int BM, int ROWS, int CCK, conv_kernel_t k_quad, conv_kernel_t k_word, hipStream_t s,
+                      const ConvKArgs* style = nullptr, int* n_blocks = nullptr)
 {
-    ConvKArgs k;
+    ConvKArgs k{};
+    if (style) k = *style;
     k.in = p.in; k.wpack = p.wpack; k.bias = p.bias; k.out = p.out;
     k.mask_src = p.mask_src; k.inject = p.inject;
     k.K = p.K; k.M = p.M; k.MPad = p.MPad; k.H = p.H; k.W = p.W;
@@ -323,12 +387,14 @@ static hipError_t run(const ConvProblem& p, int BM, int ROWS, int CCK, conv_kern
     k.relu = p.relu;
     k.stamps = p.stamps;
     // 32-bit buffer addressing: activations, weight pack and output must each be < 4 GiB
-    const unsigned long long in_bytes = 4ull * p.K * p.H * p.W, w_bytes = 4ull * conv_pack_floats(p.K, p.M);
+    const unsigned long long in_bytes = 4ull * p.K * p.H * p.W;
+    const unsigned long long w_bytes = style ? 4ull * p.K * p.MPad : 4ull * conv_pack_floats(p.K, p.M);
     const unsigned long long out_bytes = 4ull * p.M * p.H * p.W;
     if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull || out_bytes >= 0xfffffff0ull) return hipErrorInvalidValue;
     k.in_bytes = (unsigned)in_bytes; k.w_bytes = (unsigned)w_bytes;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (n_blocks) *n_blocks = (int)nblk;
     const bool aligned = p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0;
     (aligned ? k_quad : k_word)<<<dim3((unsigned)nblk), dim3(NTHREADS), 0, s>>>(k);
     return hipGetLastError();
@@ -391,6 +457,27 @@ hipError_t launch_conv3x3_cfg(const ConvProblem& p, int cfg, hipStream_t s)
 }
 
 hipError_t launch_conv3x3(const ConvProblem& p, hipStream_t s) { return launch_conv3x3_cfg(p, -1, s); }
+
+// Style gradient S = c2 * (D @ F) on the conv pipeline (TAPS = 1).  Dp is D laid out [C][MPad].
+static void style_tile(int C, int* bm, int* rows) { if (C > 64) { *bm = 128; *rows = 4; } else { *bm = 64; *rows = 8; } }
+
+int style_grad_blocks(int C, int H, int W)
+{
+    int bm, rows;
+    style_tile(C, &bm, &rows);
+    return ((W + 31) / 32) * ((H + rows - 1) / rows) * (conv_mpad(C) / bm);
+}
+
+hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float c2, int fused, float sw, const float* norm,
+                             int accumulate, float* partial, int* n_partial, int C, int H, int W, hipStream_t s)
+{
+    ConvProblem p{};
+    p.in = F; p.wpack = Dp; p.out = dst; p.K = C; p.M = C; p.MPad = conv_mpad(C); p.H = H; p.W = W;
+    ConvKArgs st{};
+    st.c2 = c2; st.sw = sw; st.norm = norm; st.fused = fused; st.accumulate = accumulate; st.partial = partial;
+    if (C > 64) return run(p, 128, 4, 32, style_grad_mfma_f32_128x128_cc32_q, style_grad_mfma_f32_128x128_cc32_w, s, &st, n_partial);
+    return run(p, 64, 8, 16, style_grad_mfma_f32_64x256_cc16_q, style_grad_mfma_f32_64x256_cc16_w, s, &st, n_partial);
+}
 
 // ------------------------------------------------------------------------------------------
 // dgrad with a tiny output-channel count (conv1_1 -> image, M = 3): not GEMM shaped, so a direct

@@ -106,8 +106,8 @@ struct st_ctx {
     std::vector<float*> inject;
     float *diffA = nullptr, *diffB = nullptr, *stmp = nullptr;
     size_t max_blob = 0;
-    float *gram_slabs = nullptr, *dbuf = nullptr;
-    size_t gram_slab_cap = 0;
+    float *gram_slabs = nullptr, *gram_fold = nullptr, *dbuf = nullptr;
+    size_t gram_slab_cap = 0, gram_fold_cap = 0;
     std::vector<float*> layer_part;                // per blob: 5 * kMaxPartials
     std::vector<float*> s2_part;                   // per blob: style-grad partial sums
     std::vector<int> s2_cap;
@@ -244,11 +244,17 @@ static int ensure_gram_bufs(st_ctx* c, int C, int hw, GramPlan& pl)
         ST_TRY(dmalloc(&c->gram_slabs, pl.slab_floats));
         c->gram_slab_cap = pl.slab_floats;
     }
+    const size_t fold = (size_t)gram_fold_groups(pl) * C * C;
+    if (fold > c->gram_fold_cap) {
+        dfree(c->gram_fold);
+        ST_TRY(dmalloc(&c->gram_fold, fold));
+        c->gram_fold_cap = fold;
+    }
     return ST_OK;
 }
 
 // G (or G - target) of blob data F -> out (C*C); optional sum-of-squares partials
-static int gram_into(st_ctx* c, const float* F, int C, int hw, const float* target, float* out, float* partial, int* n_partial)
+static int gram_into(st_ctx* c, const float* F, int C, int hw, const float* target, float* out, int out_ld, float* partial, int* n_partial)
 {
     GramPlan pl;
     ST_TRY(ensure_gram_bufs(c, C, hw, pl));
@@ -258,7 +264,7 @@ static int gram_into(st_ctx* c, const float* F, int C, int hw, const float* targ
     }
     {
         ProfScope ps(c, P_GRAM_REDUCE, 0, 4.0 * (double)pl.slab_floats);
-        HIP_TRY(launch_gram_reduce(c->gram_slabs, target, out, partial, n_partial, C, hw, pl, c->stream));
+        HIP_TRY(launch_gram_reduce(c->gram_slabs, c->gram_fold, target, out, out_ld, partial, n_partial, C, hw, pl, c->stream));
     }
     return ST_OK;
 }
@@ -392,24 +398,24 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
             wrote = true;
         }
         if (al.s) {
-            if (!c->dbuf) {          // C x C scratch for (G - G_style), sized for the widest blob
+            if (!c->dbuf) {          // [C][MPad] scratch for D = G - G_style, sized for the widest blob
                 size_t cc = 1;
-                for (int i = 0; i < c->nb; ++i) cc = std::max(cc, (size_t)a.C[i] * a.C[i]);
+                for (int i = 0; i < c->nb; ++i) cc = std::max(cc, (size_t)a.C[i] * conv_mpad(a.C[i]));
                 ST_TRY(dmalloc(&c->dbuf, cc));
+                HIP_TRY(hipMemsetAsync(c->dbuf, 0, cc * sizeof(float), c->stream));
             }
-            ST_TRY(gram_into(c, a.data[b], C, hw, c->style_gram[b], c->dbuf, part + 4 * kMaxPartials, &cnt[4]));
+            ST_TRY(gram_into(c, a.data[b], C, hw, c->style_gram[b], c->dbuf, conv_mpad(C), part + 4 * kMaxPartials, &cnt[4]));
             const float c2 = (float)(2.0 / ((double)C * C * (double)n));
-            const int ptiles = (hw + 255) / 256, nmt = C > 64 ? (C + 127) / 128 : 1;
-            const int need = ptiles * nmt;
+            const int need = style_grad_blocks(C, a.h[b], a.w[b]);
             if (c->s2_cap[b] < need) { dfree(c->s2_part[b]); ST_TRY(dmalloc(&c->s2_part[b], need)); c->s2_cap[b] = need; }
             const double fl = 2.0 * C * C * (double)hw;
             if (c->norm_valid[b * 3 + 1]) {
                 ProfScope ps(c, P_STYLE_GRAD, fl, 4.0 * n * 2);
-                HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->inject[b], c2, 1, al.sw, nrm + 1, wrote, c->s2_part[b], &cnt[5], C, hw, c->stream));
+                HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->inject[b], c2, 1, al.sw, nrm + 1, wrote, c->s2_part[b], &cnt[5], C, a.h[b], a.w[b], c->stream));
             } else {              // first evaluation: S unscaled -> norm -> saxpy (worker.py:265-269)
                 if (!c->stmp) ST_TRY(dmalloc(&c->stmp, c->max_blob));
                 { ProfScope ps(c, P_STYLE_GRAD, fl, 4.0 * n * 2);
-                  HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->stmp, c2, 0, al.sw, nrm + 1, 0, c->s2_part[b], &cnt[5], C, hw, c->stream)); }
+                  HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->stmp, c2, 0, al.sw, nrm + 1, 0, c->s2_part[b], &cnt[5], C, a.h[b], a.w[b], c->stream)); }
                 { ProfScope ps(c, P_FINALIZE, 0, 0);
                   HIP_TRY(launch_finalize_norm(c->s2_part[b], cnt[5], (double)n, nrm + 1, c->stream)); }
                 c->norm_valid[b * 3 + 1] = 1;
@@ -630,7 +636,7 @@ int st_destroy(st_ctx* c)
     for (auto& p : c->inject) dfree(p);
     for (auto& p : c->layer_part) dfree(p);
     for (auto& p : c->s2_part) dfree(p);
-    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->dbuf);
+    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->gram_fold); dfree(c->dbuf);
     dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->scal); dfree(c->dot_part); dfree(c->hwc_dev);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     if (c->trace_host) (void)hipHostFree(c->trace_host);
@@ -735,7 +741,7 @@ int st_gram(st_ctx* c, int index, float* out)
     const int C = c->act.C[index], hw = c->act.h[index] * c->act.w[index];
     float* g = nullptr;
     ST_TRY(dmalloc(&g, (size_t)C * C));
-    int r = gram_into(c, c->act.data[index], C, hw, nullptr, g, nullptr, nullptr);
+    int r = gram_into(c, c->act.data[index], C, hw, nullptr, g, C, nullptr, nullptr);
     if (r == ST_OK) {
         hipError_t e = hipMemcpyAsync(out, g, (size_t)C * C * sizeof(float), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -851,7 +857,7 @@ int st_set_style(st_ctx* c, const void* hwc, int H, int W, int is_u8)
     for (int i = 0; i < c->nb && r == ST_OK; ++i) {
         const int C = a->C[i], hw = a->h[i] * a->w[i];
         if (!c->style_gram[i]) r = dmalloc(&c->style_gram[i], (size_t)C * C);
-        if (r == ST_OK) r = gram_into(c, a->data[i], C, hw, nullptr, c->style_gram[i], nullptr, nullptr);
+        if (r == ST_OK) r = gram_into(c, a->data[i], C, hw, nullptr, c->style_gram[i], C, nullptr, nullptr);
     }
     (void)hipStreamSynchronize(c->stream);
     if (!same) act_free(aux);

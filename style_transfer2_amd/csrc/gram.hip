@@ -2,7 +2,7 @@
 //
 //   gram_partial : G_s = F[:, slab_s] F[:, slab_s]^T        worker.py:109-114 (np.dot(x, x.T))
 //   gram_reduce  : D = sum_s G_s / n - G_style, sum D^2      worker.py:114, 261, 267
-//   style_grad   : S = c2 * (D @ F) [+ fused saxpy]          worker.py:262-269
+//   (the style gradient S = c2 * (D @ F) runs on the conv pipeline: conv3x3_mfma.hip, TAPS = 1)
 //
 // F is a blob, [C][hw] fp32 row-major (NCHW with N = 1).  The Gram GEMM contracts over hw
 // (up to 2^20), so it is split along K into slabs -> [splits][C][C] fp32 partials that a second
@@ -133,9 +133,10 @@ hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, cons
     return hipGetLastError();
 }
 
+// `out` is written with leading dimension out_ld (>= C): the style-gradient GEMM wants D as [C][MPad].
 __global__ __launch_bounds__(256) void gram_reduce_k(const float* __restrict__ slabs, const float* __restrict__ target,
                                                      float* __restrict__ out, float* __restrict__ partial,
-                                                     int cc, int splits, float n)
+                                                     int cc, int splits, float n, int C, int out_ld)
 {
     __shared__ float scratch[4];
     float acc[1] = {0.f};
@@ -144,141 +145,44 @@ __global__ __launch_bounds__(256) void gram_reduce_k(const float* __restrict__ s
         for (int s = 0; s < splits; ++s) sum += slabs[(size_t)s * cc + i];
         float v = sum / n;                           // np.dot(x, x.T) / np.float32(x.size)
         if (target) v -= target[i];                  // gram_matrix(F) - grams[layer]
-        out[i] = v;
+        out[(i / C) * out_ld + (i % C)] = v;
         acc[0] += v * v;
     }
     block_sum(acc, scratch);
     if (threadIdx.x == 0 && partial) partial[blockIdx.x] = acc[0];
 }
 
-hipError_t launch_gram_reduce(const float* slabs, const float* target, float* out, float* partial,
+// First stage for many splits: fold `splits` slabs into `groups` slabs (each block: 256 elements x
+// one group of consecutive splits, summed in order) so the final pass is short and still deterministic.
+__global__ __launch_bounds__(256) void gram_fold_k(const float* __restrict__ slabs, float* __restrict__ folded,
+                                                   int cc, int splits, int per_group)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (i >= cc) return;
+    const int s0 = g * per_group, s1 = min(splits, s0 + per_group);
+    float sum = 0.f;
+    for (int s = s0; s < s1; ++s) sum += slabs[(size_t)s * cc + i];
+    folded[(size_t)g * cc + i] = sum;
+}
+
+int gram_fold_groups(const GramPlan& pl) { return pl.splits > 32 ? 32 : 0; }
+
+hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* target, float* out, int out_ld, float* partial,
                               int* n_partial, int C, int hw, const GramPlan& pl, hipStream_t s)
 {
     const int cc = C * C;
+    int splits = pl.splits;
+    const int groups = gram_fold_groups(pl);
+    if (groups) {
+        const int per = (pl.splits + groups - 1) / groups;
+        gram_fold_k<<<dim3((cc + 255) / 256, groups), 256, 0, s>>>(slabs, folded, cc, pl.splits, per);
+        slabs = folded;
+        splits = (pl.splits + per - 1) / per;
+    }
     const int grid = reduce_grid((size_t)cc, 256, kMaxPartials);
     if (n_partial) *n_partial = grid;
-    gram_reduce_k<<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, pl.splits, (float)((double)C * hw));
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------- style gradient
-// S[m][p] = c2 * sum_k D[m][k] F[k][p].  D is symmetric (difference of two Gram matrices), so the A
-// operand is staged from rows of D with m contiguous: d_s[k][m] = D[k][m].
-constexpr int SKC = 16;          // K (channels) per staged chunk
-constexpr int SBN = 256;         // pixels per workgroup
-
-template <int BM, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void style_grad_k(const float* __restrict__ D, const float* __restrict__ F,
-                                                    float* __restrict__ dst, float c2, int mode, float sw,
-                                                    const float* __restrict__ norm, int accumulate,
-                                                    float* __restrict__ partial, int C, int hw, int n_mtiles)
-{
-    constexpr int TM = BM / WAVES_M / 32;
-    constexpr int TN = SBN / WAVES_N / 32;
-    constexpr int ND = SKC * BM, NF = SKC * SBN;
-    constexpr int D_PER_T = ND / 256, F_PER_T = NF / 256;
-    __shared__ float d_s[ND];
-    __shared__ float f_s[NF];
-    __shared__ float scratch[4];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-    const int mt = blockIdx.x % n_mtiles;
-    const int ptile = blockIdx.x / n_mtiles;
-    const int m0 = mt * BM;
-    const size_t p0 = (size_t)ptile * SBN;
-
-    float dreg[D_PER_T], freg[F_PER_T];
-    auto load = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < D_PER_T; ++i) {
-            const int e = tid + i * 256;
-            const int k = e / BM, m = e % BM;
-            dreg[i] = (k0 + k < C && m0 + m < C) ? D[(size_t)(k0 + k) * C + m0 + m] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < F_PER_T; ++i) {
-            const int e = tid + i * 256;
-            const int k = e / SBN, p = e % SBN;
-            freg[i] = (k0 + k < C && p0 + p < (size_t)hw) ? F[(size_t)(k0 + k) * hw + p0 + p] : 0.f;
-        }
-    };
-    auto store = [&]() {
-#pragma unroll
-        for (int i = 0; i < D_PER_T; ++i) d_s[tid + i * 256] = dreg[i];
-#pragma unroll
-        for (int i = 0; i < F_PER_T; ++i) f_s[tid + i * 256] = freg[i];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int khalf = lane >> 5, l31 = lane & 31;
-    const float* a_base = d_s + khalf * BM + wave_m * (TM * 32) + l31;
-    const float* b_base = f_s + khalf * SBN + wave_n * (TN * 32) + l31;
-
-    load(0);
-    for (int k0 = 0; k0 < C; k0 += SKC) {
-        __syncthreads();
-        store();
-        __syncthreads();
-        if (k0 + SKC < C) load(k0 + SKC);
-#pragma unroll
-        for (int kk = 0; kk < SKC / 2; ++kk) {
-            float av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = a_base[2 * kk * BM + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = b_base[2 * kk * SBN + j * 32];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    const float coef = mode ? sw / *norm : 0.f;        // sw / sn[layer]
-    float ss[1] = {0.f};
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const size_t p = p0 + wave_n * (TN * 32) + j * 32 + l31;
-        if (p >= (size_t)hw) continue;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wave_m * (TM * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                if (m >= C) continue;
-                const size_t idx = (size_t)m * hw + p;
-                const float v = acc[i][j][e] * c2;     // s_grad *= 2 / (gram_diff.size * feat.size)
-                ss[0] += v * v;
-                if (mode == 0) dst[idx] = v;
-                else dst[idx] = coef * v + (accumulate ? dst[idx] : 0.f);
-            }
-    }
-    block_sum(ss, scratch);
-    if (tid == 0) partial[blockIdx.x] = ss[0];
-}
-
-hipError_t launch_style_grad(const float* D, const float* F, float* dst, float c2, int mode,
-                             float sw, const float* norm, int accumulate, float* partial,
-                             int* n_partial, int C, int hw, hipStream_t s)
-{
-    const int ptiles = (hw + SBN - 1) / SBN;
-    const bool big = C > 64;
-    const int bm = big ? 128 : 64;
-    const int n_mtiles = (C + bm - 1) / bm;
-    const long long grid = (long long)ptiles * n_mtiles;
-    if (grid > 0x7fffffffLL) return hipErrorInvalidValue;
-    *n_partial = (int)grid;   // NOTE: may exceed kMaxPartials; the engine sizes this slot separately
-    if (big) style_grad_k<128, 2, 2><<<(unsigned)grid, 256, 0, s>>>(D, F, dst, c2, mode, sw, norm, accumulate, partial, C, hw, n_mtiles);
-    else style_grad_k<64, 1, 4><<<(unsigned)grid, 256, 0, s>>>(D, F, dst, c2, mode, sw, norm, accumulate, partial, C, hw, n_mtiles);
+    gram_reduce_k<<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)((double)C * hw), C, out_ld);
     return hipGetLastError();
 }
 

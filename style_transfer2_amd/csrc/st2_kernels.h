@@ -63,17 +63,20 @@ struct GramPlan { int bt, tiles, splits, kslab; size_t slab_floats; };
 GramPlan gram_plan(int C, int hw);
 hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s);
 // out[i][j] = sum_s slabs[s][i][j] / n  - (target ? target[i][j] : 0);  partial[blockIdx] = sum out^2
-hipError_t launch_gram_reduce(const float* slabs, const float* target, float* out, float* partial,
+// `folded` is scratch of gram_fold_groups(pl) * C * C floats (two-stage reduction when there are many splits)
+int gram_fold_groups(const GramPlan& pl);
+hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* target, float* out, int out_ld, float* partial,
                               int* n_partial, int C, int hw, const GramPlan& pl, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
-// Style gradient  S = c2 * (D @ F)  (D is C x C symmetric, F is [C][hw]) on MFMA.
-//   mode 0 (raw)  : tmp = S                      and partial += S^2   (first evaluation: norm unknown)
-//   mode 1 (fused): inject = (sw / *norm) * S + (accumulate ? inject : 0) ; partial += S^2
+// Style gradient  S = c2 * (D @ F)  (D = G - G_style, C x C symmetric; F = blob [C][H][W]) on the conv
+// pipeline with a single tap.  Dp is D with leading dimension conv_mpad(C).
+//   fused = 0 : dst = S                              partial[block] = sum S^2   (first evaluation)
+//   fused = 1 : dst = (sw / *norm) * S + (accumulate ? dst : 0) ; partial as above
 // ------------------------------------------------------------------------------------------
-hipError_t launch_style_grad(const float* D, const float* F, float* dst, float c2, int mode,
-                             float sw, const float* norm, int accumulate, float* partial,
-                             int* n_partial, int C, int hw, hipStream_t s);
+int style_grad_blocks(int C, int H, int W);          // partial-sum slots the launch writes
+hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float c2, int fused, float sw, const float* norm,
+                             int accumulate, float* partial, int* n_partial, int C, int H, int W, hipStream_t s);
 // inject = (sw / *norm) * S + (accumulate ? inject : 0)
 hipError_t launch_scaled_accumulate(const float* S, float* inject, float sw, const float* norm,
                                     int accumulate, size_t n, hipStream_t s);
