@@ -118,8 +118,17 @@ def main():
         launches = sum(c['launches'] for c in conv)
         achieved = flops / (ms * 1e-3) / 1e12 if ms else 0.0
         total_ms = sum(v['ms'] for v in prof.values())
+        # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command
+        # (FETCH_SIZE doubled for wide loads, WRITE_SIZE exact: tools/pmc_traffic.py); null when absent.
+        traffic = None
+        tpath = os.path.join(HERE, 'profiles', 'pmc_traffic.json')
+        if args.size == 1024 and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath))['_conv3x3_mfma_f32_all']['hbm_bytes_per_launch']
+            except (KeyError, ValueError):
+                traffic = None
         out = {
-            'metric': 'style-transfer iters/sec @1024px VGG19',
+            'metric': 'style-transfer iters/sec @%dpx VGG19' % args.size,
             'value': its, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
@@ -130,7 +139,7 @@ def main():
                        'jobs': world, 'parallelism': 'independent jobs, 1 per GPU, no collective'},
             'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_mfma_f32 (forward + dgrad launches)',
                          'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
                          'flops_per_launch': flops / launches if launches else 0.0,
                          'avg_launch_ms': ms / launches if launches else 0.0,
                          'share_of_step': ms / total_ms if total_ms else 0.0},

@@ -485,68 +485,100 @@ hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float 
 // dx[m][y][x] = sum_{co,ky,kx} w[co][m][ky][kx] * dy[co][y-ky+1][x-kx+1]  (+ inject)
 // ------------------------------------------------------------------------------------------
 constexpr int SM_MAXM = 4;
-constexpr int SM_TX = 32, SM_TY = 8;
+constexpr int SM_TX = 32, SM_TY = 8, SM_CH = 8;
 
+// Weights are wave-uniform: they are read with scalar loads straight from the original
+// (Cout, M, 3, 3) layout (27 consecutive floats per input channel for M = 3), so the LDS only
+// serves the activation tile: 9 ds_read_b32 + 9*M v_fmac (SGPR operand) per channel and pixel.
+template <int M>
 __global__ __launch_bounds__(256) void conv3x3_dgrad_smallM(const float* __restrict__ dy, const float* __restrict__ w,
                                                             float* __restrict__ dx, const float* __restrict__ inject,
-                                                            int Cout, int M, int H, int W)
+                                                            int Cout, int H, int W)
 {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* w_s = sm;                                   // [Cout][M][9]
-    float* t_s = sm + Cout * M * 9;                    // [8 channels][SM_TY+2][SM_TX+2]
-    constexpr int TW = SM_TX + 2, TH = SM_TY + 2, CH = 8;
+    constexpr int TW = SM_TX + 2, TH = SM_TY + 2;
+    __shared__ float t_s[2][SM_CH * TH * TW];
     const int tid = threadIdx.x;
-    for (int i = tid; i < Cout * M * 9; i += 256) w_s[i] = w[i];
     const int x0 = blockIdx.x * SM_TX, y0 = blockIdx.y * SM_TY;
     const int lx = tid % SM_TX, ly = tid / SM_TX;
     const size_t plane = (size_t)H * W;
-    float acc[SM_MAXM] = {0.f, 0.f, 0.f, 0.f};
-    for (int c0 = 0; c0 < Cout; c0 += CH) {
-        __syncthreads();
-        for (int e = tid; e < CH * TH * TW; e += 256) {
-            const int c = e / (TH * TW), rem = e % (TH * TW), rr = rem / TW, col = rem % TW;
-            const int gy = y0 - 1 + rr, gx = x0 - 1 + col;
-            float v = 0.f;
-            if (c0 + c < Cout && gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = dy[(size_t)(c0 + c) * plane + (size_t)gy * W + gx];
-            t_s[e] = v;
+    float acc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = 0.f;
+
+    constexpr int NE = SM_CH * TH * TW, PER_T = (NE + 255) / 256;
+    int toff[PER_T];                          // tile element -> offset inside one channel plane (or -1)
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+        const int e = tid + i * 256;
+        const int rem = e % (TH * TW), rr = rem / TW, col = rem % TW;
+        const int gy = y0 - 1 + rr, gx = x0 - 1 + col;
+        toff[i] = (e < NE && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+    }
+    float stage[PER_T];
+    auto load = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int c = (tid + i * 256) / (TH * TW);
+            stage[i] = (toff[i] >= 0 && c0 + c < Cout) ? dy[(size_t)(c0 + c) * plane + toff[i]] : 0.f;
         }
-        __syncthreads();
-        for (int c = 0; c < CH && c0 + c < Cout; ++c) {
+    };
+    auto store = [&](int buf) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+        for (int i = 0; i < PER_T; ++i)
+            if (tid + i * 256 < NE) t_s[buf][tid + i * 256] = stage[i];
+    };
+
+    load(0);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = 0; c0 < Cout; c0 += SM_CH) {
+        const bool more = c0 + SM_CH < Cout;
+        if (more) load(c0 + SM_CH);              // in flight while this chunk is consumed
+        const float* tile = t_s[buf];
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    // source pixel (y - ky + 1, x - kx + 1) -> tile coords (ly + 2 - ky, lx + 2 - kx)
-                    const float g = t_s[(c * TH + (ly + 2 - ky)) * TW + (lx + 2 - kx)];
+        for (int c = 0; c < SM_CH; ++c) {
+            if (c0 + c < Cout) {
+                const float* wc = w + (size_t)(c0 + c) * M * 9;      // uniform -> s_load
 #pragma unroll
-                    for (int m = 0; m < SM_MAXM; ++m)
-                        if (m < M) acc[m] += w_s[((c0 + c) * M + m) * 9 + ky * 3 + kx] * g;
-                }
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        // source pixel (y - ky + 1, x - kx + 1) -> tile coords (ly + 2 - ky, lx + 2 - kx)
+                        const float g = tile[(c * TH + (ly + 2 - ky)) * TW + (lx + 2 - kx)];
+#pragma unroll
+                        for (int m = 0; m < M; ++m) acc[m] += wc[m * 9 + ky * 3 + kx] * g;
+                    }
+            }
+        }
+        if (more) {
+            store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
         }
     }
     const int gx = x0 + lx, gy = y0 + ly;
     if (gx < W && gy < H)
+#pragma unroll
         for (int m = 0; m < M; ++m) {
             const size_t idx = (size_t)m * plane + (size_t)gy * W + gx;
             dx[idx] = acc[m] + (inject ? inject[idx] : 0.f);
         }
 }
 
-static size_t smallM_lds(int Cout, int Cin)
-{
-    return ((size_t)Cout * Cin * 9 + 8 * (SM_TY + 2) * (SM_TX + 2)) * sizeof(float);
-}
-
-bool conv_dgrad_smallM_ok(int Cout, int Cin) { return Cin <= SM_MAXM && smallM_lds(Cout, Cin) <= 64 * 1024; }
+bool conv_dgrad_smallM_ok(int Cout, int Cin) { (void)Cout; return Cin >= 1 && Cin <= SM_MAXM; }
 
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
                                        int Cout, int Cin, int H, int W, hipStream_t s)
 {
     if (!conv_dgrad_smallM_ok(Cout, Cin)) return hipErrorInvalidValue;
-    const size_t lds = smallM_lds(Cout, Cin);
     dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
-    conv3x3_dgrad_smallM<<<grid, dim3(256), lds, s>>>(dy, w, dx, inject, Cout, Cin, H, W);
+    switch (Cin) {
+    case 1: conv3x3_dgrad_smallM<1><<<grid, dim3(256), 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    case 2: conv3x3_dgrad_smallM<2><<<grid, dim3(256), 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    case 3: conv3x3_dgrad_smallM<3><<<grid, dim3(256), 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    default: conv3x3_dgrad_smallM<4><<<grid, dim3(256), 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    }
     return hipGetLastError();
 }
 

@@ -248,3 +248,40 @@ def test_full_size_1024_properties():
     G = gpu.engine.gram('conv1_1')
     F = fg['conv1_1'].astype(np.float64)
     assert np.isclose(np.trace(G.astype(np.float64)) * F.size, (F ** 2).sum(), rtol=1e-5)
+
+
+# ------------------------------------------------ BASELINE config 1: the reference's own example images
+def test_config1_golden_gate_starry_night_256px_adam_50_iters():
+    """configs[0]: examples/golden_gate.jpg + starry_night.jpg resized by the reference's resize_to_fit to
+    fit 256 (192x256 content, 160x256 style; fixture tests/golden/config1_inputs.npz), VGG19 (seeded
+    synthetic weights), initial_weights.yaml losses, Adam step 10, 50 iterations: HIP engine vs CPU oracle.
+    Tight bar on the per-step loss while the trajectories coincide, loose image bar (Adam is sign-like)."""
+    g = np.load(__import__('os').path.join(__import__('helpers').GOLDEN, 'config1_inputs.npz'))
+    content, style = g['golden_gate'], g['starry_night']
+    init = np.random.RandomState(3).randint(0, 256, content.shape).astype(np.uint8)   # app.py:82,251 noise init
+    topo = oracle.VGG19_TOPOLOGY
+    params = oracle.he_init_weights(topo, seed=0)
+    weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1},
+               'deepdream': {}}
+    params4 = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+    cpu = oracle.TransferOracle(oracle.NetOracle(topo, params, full_forward=False))
+    dev = st2.StyleTransfer(st2.HipModel(params))
+    for st in (cpu, dev):
+        st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+        st.set_weights(weights, params4)
+    cpu.set_optimizer('adam', 10)
+    dev.optimizer_cls = st2.AdamOptimizer; dev.set_step_size(10); dev.reset()
+    assert cpu.start() and dev.start()
+    lc, ld = [], []
+    for i in range(50):
+        ic, tc = cpu.step()
+        idv, td = dev.step()
+        lc.append(tc['loss']); ld.append(td['loss'])
+        if i == 0:
+            assert list(td) == list(tc)
+            assert np.isclose(td['loss'], tc['loss'], rtol=1e-4) and np.isclose(td['grad'], tc['grad'], rtol=1e-3)
+    assert np.allclose(ld[:10], lc[:10], rtol=2e-3)
+    assert np.allclose(ld, lc, rtol=2e-2)
+    assert idv.shape == (192, 256, 3) and idv.dtype == F32
+    assert np.mean((idv - ic) ** 2) <= 4.0        # 0-255^2 units; the image moved by thousands
+    assert np.mean((ic - init) ** 2) > 1000.0
