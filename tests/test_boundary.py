@@ -239,3 +239,45 @@ def test_config1_inputs_fixture_geometry():
     g = np.load(os.path.join(GOLDEN, 'config1_inputs.npz'))
     assert g['golden_gate'].shape == (192, 256, 3) and g['starry_night'].shape == (160, 256, 3)
     assert g['golden_gate'].dtype == np.uint8
+
+
+def test_async_sender_keeps_order_and_flushes_before_close():
+    import time
+
+    class SlowSock:
+        def __init__(self):
+            self.sent = []
+
+        def send_pyobj(self, obj):
+            time.sleep(0.01)
+            self.sent.append(obj)
+
+    sock = SlowSock()
+    sender = worker_mod.AsyncSender(sock, depth=2)
+    t0 = time.perf_counter()
+    for i in range(8):
+        sender.send_pyobj(i)
+    queued_in = time.perf_counter() - t0
+    sender.close()
+    assert sock.sent == list(range(8))
+    assert queued_in >= 0.04            # bounded queue: the producer was held back, not 8 sends deep
+
+    class BadSock:
+        def send_pyobj(self, obj):
+            raise OSError('peer gone')
+
+    sender = worker_mod.AsyncSender(BadSock())
+    sender.send_pyobj(1)
+    time.sleep(0.05)
+    with pytest.raises(OSError):
+        sender.send_pyobj(2)
+    with pytest.raises(OSError):
+        sender.close()
+
+
+def test_worker_synchronous_send_option():
+    socks = FakeSockets([messages.StartIteration()])
+    wk = worker_mod.Worker({'async_iterate': '0'}, sock_in=socks, sock_out=socks, transfer=FakeTransfer())
+    assert wk.sock_out is socks
+    wk.run()
+    assert [type(m).__name__ for m in socks.sent] == ['WorkerReady', 'GetImages', 'Shutdown']

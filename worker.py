@@ -14,8 +14,10 @@ import configparser
 import logging
 import os
 from pathlib import Path
+import queue
 import signal
 import sys
+import threading
 
 MODULE_DIR = Path(__file__).parent.resolve()
 sys.path.insert(0, str(MODULE_DIR))
@@ -77,17 +79,57 @@ def build_transfer(config):
         weights_path = MODULE_DIR / config.get('caffemodel', 'models/vgg19.npz')
         if weights_path.suffix == '.npz' and weights_path.exists():
             params = st2_weights.load_npz(str(weights_path), st2.VGG19_TOPOLOGY)
+        elif weights_path.suffix == '.caffemodel' and weights_path.exists():
+            from style_transfer2_amd import caffemodel
+            params = caffemodel.vgg_params(caffemodel.read_caffemodel(str(weights_path)), st2.VGG19_TOPOLOGY,
+                                           bgr_to_rgb=config.getboolean('caffemodel_is_bgr', fallback=False))
         elif config.get('weights', '') == 'synthetic':
             logger.warning('Using seeded synthetic VGG19 weights (config: weights = synthetic).')
             params = st2_weights.he_normal(st2.VGG19_TOPOLOGY, seed=0)
         else:
-            raise st2.HipUnavailable('weights file %s not found (.npz expected; or set weights = synthetic)'
+            raise st2.HipUnavailable('weights file %s not found (.npz or .caffemodel; or set weights = synthetic)'
                                      % weights_path)
         model = st2.HipModel(params, device=max(gpu, 0))
         return st2.StyleTransfer(model)
     except Exception as err:  # HipUnavailable, StError, OSError ...
         print(BACKEND_MSG % err, file=sys.stderr)
         sys.exit(2)
+
+
+class AsyncSender:
+    """Owns the outbound socket on its own thread: pickling + sending an ``Iterate`` (12.6 MB at 1024^2)
+    overlaps the next iteration's GPU work instead of stalling it.  Order is
+    preserved (one FIFO), every message still goes out exactly once, and the queue is bounded so the
+    worker never runs more than ``depth`` iterates ahead of what the app has been sent."""
+
+    def __init__(self, sock, depth=2):
+        self.sock = sock
+        self.q = queue.Queue(maxsize=depth)
+        self.error = None
+        self.thread = threading.Thread(target=self._run, name='iterate-sender', daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            msg = self.q.get()
+            if msg is None:
+                return
+            try:
+                self.sock.send_pyobj(msg)
+            except Exception as err:      # surfaced on the worker thread at the next send
+                self.error = err
+
+    def send_pyobj(self, msg):
+        if self.error is not None:
+            raise self.error
+        self.q.put(msg)
+
+    def close(self):
+        """Flush everything queued, then stop the thread."""
+        self.q.put(None)
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
 
 
 class Worker:
@@ -108,12 +150,18 @@ class Worker:
         else:
             self._again = getattr(sock_in, 'Again', BlockingIOError)
             self._noblock = 1
-        self.sock_in, self.sock_out = sock_in, sock_out
+        self.sock_in = sock_in
+        self._raw_out = sock_out
+        async_send = str(config.get('async_iterate', '1')).lower() not in ('0', 'false', 'no')
+        self.sock_out = AsyncSender(sock_out) if async_send else sock_out
         self.run_should_stop = False
         self.transfer = transfer if transfer is not None else build_transfer(config)
         self.sock_out.send_pyobj(WorkerReady(layers=self.transfer.model.layers()))
 
     def close(self):
+        if isinstance(self.sock_out, AsyncSender):
+            sender, self.sock_out = self.sock_out, self._raw_out
+            sender.close()
         if self._ctx is not None:
             self._ctx.destroy(0)
 
@@ -128,6 +176,9 @@ class Worker:
             pass
         finally:
             self.sock_out.send_pyobj(Shutdown())
+            if isinstance(self.sock_out, AsyncSender):       # Shutdown is the last thing on the wire
+                sender, self.sock_out = self.sock_out, self._raw_out
+                sender.close()
 
     def _drain_then_step(self):
         """Handle everything queued without blocking, then do exactly one iteration."""
