@@ -1,0 +1,142 @@
+"""Tile-sharded single-image mode (BASELINE config 5) on the CPU: geometry/plan unit tests, and the full
+distributed algorithm (gloo, 2 and 4 ranks, oracle tile backend) against the single-process oracle."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'tests'))
+
+import oracle                                                     # noqa: E402
+from style_transfer2_amd import tiling                            # noqa: E402
+from style_transfer2_amd.engine import VGG19_TOPOLOGY             # noqa: E402
+
+TOPO = oracle.tiny_topology((8, 16), (2, 2))
+WEIGHTS = {'content': {'conv2_2': 0.08, 'conv1_2': 0.5}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'pool1': 0.7},
+           'deepdream': {'conv2_1': 0.02}}
+PARAMS = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+GH, GW = 32, 48
+
+
+def test_receptive_apron_and_stride():
+    names = ['data'] + [l[1] for l in VGG19_TOPOLOGY]
+    assert tiling.receptive_apron(VGG19_TOPOLOGY, names.index('conv5_1')) == 80      # 70 px, rounded to 16
+    assert tiling.total_stride(VGG19_TOPOLOGY, names.index('conv5_1')) == 16
+    assert tiling.receptive_apron(VGG19_TOPOLOGY, names.index('conv1_2')) == 2
+    assert tiling.receptive_apron(TOPO, 5) == 6 and tiling.total_stride(TOPO, 5) == 2
+    assert tiling.receptive_apron(VGG19_TOPOLOGY, 0) == 0
+
+
+def test_grid_geometry_and_plans_cover_everything_once():
+    g = tiling.TileGrid(8192, 8192, 2, 4, VGG19_TOPOLOGY, 17)
+    assert [t for t in g.tiles][:2] == [tiling.Rect(0, 0, 4096, 2048), tiling.Rect(0, 2048, 4096, 4096)]
+    assert g.windows[0] == tiling.Rect(0, 0, 4176, 2128) and g.windows[5] == tiling.Rect(4016, 1968, 8192, 4176)
+    g = tiling.TileGrid(40, 54, 2, 3, TOPO, 5)
+    cover = np.zeros((40, 54), int)
+    for t in g.tiles:
+        assert t.y0 % 2 == 0 and t.x0 % 2 == 0
+        cover[t.y0:t.y1, t.x0:t.x1] += 1
+    assert np.all(cover == 1)
+    # apron refresh: every non-tile pixel of every window is delivered exactly once, by its owner
+    for dst, w in enumerate(g.windows):
+        got = np.zeros((40, 54), int)
+        for s, d, r in g.apron_refresh_plan():
+            if d == dst:
+                assert tiling.rect_and(r, g.tiles[s]) == r
+                got[r.y0:r.y1, r.x0:r.x1] += 1
+        want = np.zeros((40, 54), int)
+        want[w.y0:w.y1, w.x0:w.x1] = 1
+        t = g.tiles[dst]
+        want[t.y0:t.y1, t.x0:t.x1] = 0
+        assert np.array_equal(got, want)
+    # ring: every border cell of the (th+2, tw+2) ring filled exactly once with the wrapped global pixel
+    img = np.arange(40 * 54).reshape(40, 54)
+    for dst, items in enumerate(g.ring_plan()):
+        t = g.tiles[dst]
+        th, tw = t.y1 - t.y0, t.x1 - t.x0
+        ring = np.full((th + 2, tw + 2), -1)
+        cnt = np.zeros((th + 2, tw + 2), int)
+        for src, r, ry, rx in items:
+            assert tiling.rect_and(r, g.tiles[src]) == r
+            ring[ry:ry + r.y1 - r.y0, rx:rx + r.x1 - r.x0] = img[r.y0:r.y1, r.x0:r.x1]
+            cnt[ry:ry + r.y1 - r.y0, rx:rx + r.x1 - r.x0] += 1
+        border = np.ones_like(cnt)
+        border[1:-1, 1:-1] = 0
+        assert np.array_equal(cnt, border)
+        ys = (np.arange(t.y0 - 1, t.y1 + 1) % 40)[:, None]
+        xs = (np.arange(t.x0 - 1, t.x1 + 1) % 54)[None, :]
+        assert np.array_equal(ring[border == 1], img[ys, xs][border == 1])
+    with pytest.raises(ValueError):
+        tiling.TileGrid(16, 16, 4, 1, VGG19_TOPOLOGY, 17)
+
+
+def images():
+    rs = np.random.RandomState
+    return (rs(1).randint(0, 256, (GH, GW, 3)).astype(np.uint8), rs(2).randint(0, 256, (20, 28, 3)).astype(np.uint8),
+            rs(3).randint(0, 256, (GH, GW, 3)).astype(np.uint8))
+
+
+def single_process_reference(steps):
+    content, style, init = images()
+    st = oracle.TransferOracle(oracle.NetOracle(TOPO, oracle.he_init_weights(TOPO, 0, 0.1)))
+    st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+    st.set_weights(WEIGHTS, PARAMS)
+    st.set_optimizer('adam', 10)
+    assert st.start()
+    out = []
+    for _ in range(steps):
+        img, tr = st.step()
+        out.append((np.asarray(img, np.float32).copy(), dict(tr)))
+    return out
+
+
+def _rank_main(rank, world, rows, cols, port, steps, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from style_transfer2_amd import tiled
+    from tile_oracle import OracleTileBackend
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    content, style, init = images()
+    grid = tiling.TileGrid(GH, GW, rows, cols, TOPO, 5)
+    backend = OracleTileBackend(TOPO, oracle.he_init_weights(TOPO, 0, 0.1), grid, rank, content, style, init,
+                                WEIGHTS, PARAMS, step_size=10)
+    tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world))
+    res = []
+    for _ in range(steps):
+        vals = tt.step()
+        res.append((tt.tile_image(), vals))
+    q.put((rank, tuple(grid.tiles[rank]), res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('rows,cols', [(1, 2), (2, 2)])
+def test_tiled_adam_matches_single_process_oracle(rows, cols):
+    steps, world = 3, rows * cols
+    ref = single_process_reference(steps)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() + rows * 7 + cols) % 1500
+    procs = [ctx.Process(target=_rank_main, args=(r, world, rows, cols, port, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    keys = list(ref[0][1])
+    for step in range(steps):
+        full = np.zeros_like(ref[step][0])
+        for rank, (y0, x0, y1, x1), res in got:
+            full[y0:y1, x0:x1] = res[step][0]
+            vals = res[step][1]
+            # every rank ends with the same GLOBAL trace; compare loss and grad rms with the reference
+            assert np.isclose(vals[-2], ref[step][1]['loss'], rtol=2e-5), (step, rank)
+            assert np.isclose(vals[-1], ref[step][1]['grad'], rtol=2e-5), (step, rank)
+        assert np.allclose(full, ref[step][0], rtol=0, atol=2e-3), (step, np.abs(full - ref[step][0]).max())
+    assert 'conv1_1_s_loss' in keys
