@@ -104,6 +104,26 @@ const char* st_profile_class_name(int cls);
 /* sums since the last call: launches, milliseconds, algorithmic FLOPs and bytes per class */
 int st_profile_read(st_ctx* ctx, long long* launches, double* ms, double* flops, double* bytes);
 
+/* ---- tile-sharded single image (BASELINE config 5; style_transfer2_amd/tiling.py) ------------------------------------
+ * One context = one rank's window (tile + apron) of a gH x gW image.  No reference counterpart: the reference
+ * runs one image per worker; its numerics (global Gram normalisation worker.py:114, global RMS norms :254,266,275,
+ * periodic TV utils.py:232-254) fix what must be reduced/exchanged.  Phases of one Adam iteration; the caller
+ * all-reduces the returned device buffers (RCCL) and exchanges gradient / image strips between them:
+ *   st_tile_forward -> [AR p1] -> st_tile_losses -> (first eval: st_tile_style_raw -> [AR p2]) -> st_tile_losses_finish
+ *   -> st_tile_backward -> [overlap-add window gradient] -> st_tile_update(ring) -> [AR p3] -> [apron refresh] -> st_tile_swap
+ * p1 = per active layer {sum d^2, sum gc^2, sum F^2, sum gd^2} (+ C*C raw Gram sums for style layers), p2/p3 tail =
+ * sum S^2 per style layer, p3 head = {tv, p, scd^2, tvg^2, pg^2, grad^2} sums over the tile. */
+int st_tile_configure(st_ctx* ctx, int gH, int gW, int wy0, int wx0, int ty0, int tx0, int ty1, int tx1);
+int st_tile_forward(st_ctx* ctx, float** dev_ptr, int* n_floats);
+int st_tile_losses(st_ctx* ctx, float** dev_ptr, int* n_floats);
+int st_tile_style_raw(st_ctx* ctx);
+int st_tile_losses_finish(st_ctx* ctx);
+int st_tile_backward(st_ctx* ctx, float** dev_grad);
+int st_tile_update(st_ctx* ctx, const float* ring_dev, float** dev_ptr, int* n_floats);
+/* which: 0 current x (3,wh,ww), 1 next x, 2 local sum D^2 per style layer, 3 norms [blob][c,s,d] */
+int st_tile_buffer(st_ctx* ctx, int which, float** dev_ptr);
+int st_tile_swap(st_ctx* ctx);
+
 /* isolated timing of the conv3x3 MFMA kernel on one layer shape (K input channels, M output
  * channels, HxW, random data).  cfg < 0: the engine's own tile choice (returned in *cfg_used).
  * dgrad_epilogue != 0 adds the ReLU-mask + injected-diff epilogue of the backward pass. */

@@ -61,6 +61,15 @@ PROTOTYPES = {
     'st_profile_class_name': (c_char_p, [c_int]),
     'st_profile_read': (c_int, [c_void_p, POINTER(c_longlong), POINTER(c_double), POINTER(c_double),
                                 POINTER(c_double)]),
+    'st_tile_configure': (c_int, [c_void_p] + [c_int] * 8),
+    'st_tile_forward': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int)]),
+    'st_tile_losses': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int)]),
+    'st_tile_style_raw': (c_int, [c_void_p]),
+    'st_tile_losses_finish': (c_int, [c_void_p]),
+    'st_tile_backward': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'st_tile_update': (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_int)]),
+    'st_tile_buffer': (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    'st_tile_swap': (c_int, [c_void_p]),
     'st_bench_conv': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_int)]),
     'st_bench_mfma': (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
     'st_conv_num_configs': (c_int, []),

@@ -66,6 +66,7 @@ struct ConvKArgs {
     unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
     // style-gradient epilogue (EPI_STYLE): out = c2*acc [raw]  or  (sw / *norm) * c2*acc + (accumulate ? out : 0)
     float c2, sw; const float* norm; int fused, accumulate; float* partial;
+    int ry0, rx0, ry1, rx1;       // region of interest of the style epilogue (tile-sharded mode); whole blob otherwise
 };
 
 enum { EPI_CONV = 0, EPI_STYLE = 1 };
@@ -271,6 +272,8 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
             const int gy = y0 + wave_n * TN + j;
             if (gy >= a.H || gx >= a.W) continue;
             const unsigned pix = (unsigned)gy * a.W + gx;
+            const bool in_roi = gy >= a.ry0 && gy < a.ry1 && gx >= a.rx0 && gx < a.rx1;
+            if (!in_roi && a.fused && a.accumulate) continue;      // nothing to add outside the region
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -282,7 +285,7 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
                     for (int e = 0; e < 8; ++e) {
                         const int m = mbase + (e & 3) + 8 * (e >> 2);
                         off[e] = (unsigned)(m < a.M ? m : a.M - 1) * plane + pix;
-                        v[e] = acc[i][j][8 * h + e] * a.c2;
+                        v[e] = in_roi ? acc[i][j][8 * h + e] * a.c2 : 0.f;
                         if (m < a.M) ss += v[e] * v[e];
                     }
                     if (a.fused && a.accumulate) {
@@ -469,12 +472,14 @@ int style_grad_blocks(int C, int H, int W)
 }
 
 hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float c2, int fused, float sw, const float* norm,
-                             int accumulate, float* partial, int* n_partial, int C, int H, int W, hipStream_t s)
+                             int accumulate, float* partial, int* n_partial, int C, int H, int W, hipStream_t s,
+                             const PixRoi* roi)
 {
     ConvProblem p{};
     p.in = F; p.wpack = Dp; p.out = dst; p.K = C; p.M = C; p.MPad = conv_mpad(C); p.H = H; p.W = W;
     ConvKArgs st{};
     st.c2 = c2; st.sw = sw; st.norm = norm; st.fused = fused; st.accumulate = accumulate; st.partial = partial;
+    st.ry0 = roi ? roi->y0 : 0; st.rx0 = roi ? roi->x0 : 0; st.ry1 = roi ? roi->y1 : H; st.rx1 = roi ? roi->x1 : W;
     if (C > 64) return run(p, 128, 4, 32, style_grad_mfma_f32_128x128_cc32_q, style_grad_mfma_f32_128x128_cc32_w, s, &st, n_partial);
     return run(p, 64, 8, 16, style_grad_mfma_f32_64x256_cc16_q, style_grad_mfma_f32_64x256_cc16_w, s, &st, n_partial);
 }

@@ -38,7 +38,7 @@ GramPlan gram_plan(int C, int hw)
 
 template <int BT>
 __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ F, float* __restrict__ slabs,
-                                                      int C, int hw, int tiles_1d, int kslab)
+                                                      int C, int hw, int tiles_1d, int kslab, GramRoi roi)
 {
     constexpr int T = BT / 64;                       // 32x32 MFMA tiles per wave per dimension
     constexpr int ROWS_PER_T = BT / 8;               // rows each thread stages (256 threads = 8 rows x 32 k)
@@ -60,11 +60,14 @@ __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ 
 
     auto load = [&](int k0) {
         const int k = k0 + sk;
+        // k runs over the pixels of the region of interest (the whole blob unless tile-sharded)
+        const int ky = k / roi.rw, kx = k - ky * roi.rw;
+        const size_t pix = (size_t)(roi.y0 + ky) * roi.pitch + roi.x0 + kx;
 #pragma unroll
         for (int it = 0; it < ROWS_PER_T; ++it) {
             const int r = sr + it * 8;
-            ra[it] = (i0 + r < C && k < kend) ? F[(size_t)(i0 + r) * hw + k] : 0.f;
-            if (!diag) rb[it] = (j0 + r < C && k < kend) ? F[(size_t)(j0 + r) * hw + k] : 0.f;
+            ra[it] = (i0 + r < C && k < kend) ? F[(size_t)(i0 + r) * roi.plane + pix] : 0.f;
+            if (!diag) rb[it] = (j0 + r < C && k < kend) ? F[(size_t)(j0 + r) * roi.plane + pix] : 0.f;
         }
     };
     auto store = [&]() {
@@ -124,12 +127,14 @@ __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ 
         }
 }
 
-hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s)
+hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s,
+                               const GramRoi* roi_in)
 {
     const int t1 = (C + pl.bt - 1) / pl.bt;
     const unsigned grid = (unsigned)(pl.tiles * pl.splits);
-    if (pl.bt == 128) gram_partial_k<128><<<grid, 256, 0, s>>>(F, slabs, C, hw, t1, pl.kslab);
-    else gram_partial_k<64><<<grid, 256, 0, s>>>(F, slabs, C, hw, t1, pl.kslab);
+    GramRoi roi = roi_in ? *roi_in : GramRoi{0, 0, hw, hw, (size_t)hw};   // default: one "row" of hw pixels
+    if (pl.bt == 128) gram_partial_k<128><<<grid, 256, 0, s>>>(F, slabs, C, hw, t1, pl.kslab, roi);
+    else gram_partial_k<64><<<grid, 256, 0, s>>>(F, slabs, C, hw, t1, pl.kslab, roi);
     return hipGetLastError();
 }
 
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void gram_fold_k(const float* __restrict__ sla
 int gram_fold_groups(const GramPlan& pl) { return pl.splits > 32 ? 32 : 0; }
 
 hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* target, float* out, int out_ld, float* partial,
-                              int* n_partial, int C, int hw, const GramPlan& pl, hipStream_t s)
+                              int* n_partial, int C, double divisor, const GramPlan& pl, hipStream_t s)
 {
     const int cc = C * C;
     int splits = pl.splits;
@@ -182,7 +187,7 @@ hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* ta
     }
     const int grid = reduce_grid((size_t)cc, 256, kMaxPartials);
     if (n_partial) *n_partial = grid;
-    gram_reduce_k<<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)((double)C * hw), C, out_ld);
+    gram_reduce_k<<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)divisor, C, out_ld);
     return hipGetLastError();
 }
 

@@ -115,6 +115,13 @@ __global__ __launch_bounds__(256) void layer_elem_k(const LayerElemArgs a)
         if (a.deepdream) inv_d = *a.norm_d;
     }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        if (a.w) {                                        // tile-sharded: only the region of interest counts
+            const int x = (int)(i % a.w), y = (int)((i / a.w) % a.h);
+            if (y < a.ry0 || y >= a.ry1 || x < a.rx0 || x >= a.rx1) {
+                if (a.write) a.inject[i] = 0.f;
+                continue;
+            }
+        }
         const float f = a.feat[i];
         float out = 0.f;
         if (a.content) {
@@ -272,6 +279,89 @@ hipError_t launch_image_pass(const ImagePassArgs& a, int* n_partial, hipStream_t
     return hipGetLastError();
 }
 
+// Tile-sharded image pass: same arithmetic, neighbours outside the tile come from the gathered ring.
+__global__ __launch_bounds__(256) void image_pass_tile_k(const ImageTileArgs t)
+{
+    __shared__ float scratch[32];
+    const ImagePassArgs& a = t.base;
+    const int th = t.th, tw = t.tw, ww = a.W;
+    const size_t wplane = (size_t)a.H * a.W, tplane = (size_t)th * tw, rplane = (size_t)(th + 2) * (tw + 2);
+    const size_t total = tplane * 3;
+    const float half_beta = a.tv_beta * 0.5f;
+    const int beta_is_2 = a.tv_beta == 2.0f;
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int x = (int)(idx % tw);
+        const int y = (int)((idx / tw) % th);
+        const int c = (int)(idx / tplane);
+        const float* p = a.x + c * wplane;
+        const float* rg = t.ring + c * rplane;
+        auto U = [&](int yy, int xx) -> float {            // yy in [-1, th], xx in [-1, tw]
+            const bool inside = yy >= 0 && yy < th && xx >= 0 && xx < tw;
+            const float v = inside ? p[(size_t)(t.ty + yy) * ww + t.tx + xx] : rg[(size_t)(yy + 1) * (tw + 2) + xx + 1];
+            return v / 255.0f;
+        };
+        const size_t widx = c * wplane + (size_t)(t.ty + y) * ww + t.tx + x;
+        const float xv = p[(size_t)(t.ty + y) * ww + t.tx + x];
+        const float u = xv / 255.0f;
+        const float u_r = U(y, x + 1), u_d = U(y + 1, x), u_l = U(y, x - 1), u_u = U(y - 1, x);
+        const float u_dl = U(y + 1, x - 1), u_ur = U(y - 1, x + 1);
+        const float a0 = u - u_r, b0 = u - u_d;
+        const float q0 = (a0 * a0 + b0 * b0) + 1e-8f;
+        const float k0 = tv_k(q0, half_beta, beta_is_2);
+        const float da0 = (2.0f * a0) * k0, db0 = (2.0f * b0) * k0;
+        const float aL = u_l - u, bL = u_l - u_dl;
+        const float qL = (aL * aL + bL * bL) + 1e-8f;
+        const float daL = (2.0f * aL) * tv_k(qL, half_beta, beta_is_2);
+        const float aU = u_u - u_ur, bU = u_u - u;
+        const float qU = (aU * aU + bU * bU) + 1e-8f;
+        const float dbU = (2.0f * bU) * tv_k(qU, half_beta, beta_is_2);
+        float g_tv = da0 + db0;
+        g_tv -= daL;
+        g_tv -= dbU;
+        acc[0] += beta_is_2 ? q0 : powf(q0, half_beta);
+        const float mag = fabsf(u);
+        const float sgn = u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);
+        acc[1] += powf(mag, a.p_pow);
+        const float g_p = sgn * powf(mag, a.p_pow - 1.0f);
+        const float scd = a.scd ? a.scd[widx] : 0.f;
+        const float tg = a.tv_w * g_tv;
+        const float pg = a.p_w * g_p;
+        float g = scd + tg;
+        g += pg;
+        acc[2] += scd * scd;
+        acc[3] += tg * tg;
+        acc[4] += pg * pg;
+        acc[5] += g * g;
+        if (a.grad) a.grad[widx] = g;
+        if (a.x_out) {
+            const float m_old = a.m_is_zero ? 0.f : a.m[widx];
+            const float v_old = a.v_is_zero ? 0.f : a.v[widx];
+            const float m_new = a.d1 * m_old + a.c1 * g;
+            const float v_new = a.d2 * v_old + a.c2 * (g * g);
+            a.m[widx] = m_new;
+            a.v[widx] = v_new;
+            const float m_hat = m_new / a.corr1;
+            const float v_hat = v_new / a.corr2;
+            a.x_out[widx] = xv - (a.step * m_hat) / (sqrtf(v_hat) + 1e-8f);
+        }
+    }
+    block_sum(acc, scratch);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.partial[i * kMaxPartials + blockIdx.x] = acc[i];
+    }
+}
+
+hipError_t launch_image_pass_tile(const ImageTileArgs& a, int* n_partial, hipStream_t s)
+{
+    const size_t total = (size_t)3 * a.th * a.tw;
+    const int grid = reduce_grid(total, 256 * 4, kMaxPartials);
+    *n_partial = grid;
+    image_pass_tile_k<<<grid, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
 // -------------------------------------------------------------------------------- pre / deprocess
 __constant__ float kMean[3] = {123.68f, 116.779f, 103.939f};   // worker.py:34
 
@@ -396,6 +486,12 @@ __global__ __launch_bounds__(256) void dot_final_k(const float* part, int n_part
     __shared__ double scratch[256];
     const double sum = sum_partials(part, n_part, scratch);
     if (threadIdx.x == 0) *out = (float)sum;
+}
+
+hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t s)
+{
+    dot_final_k<<<1, 256, 0, s>>>(part, n, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_dot(const float* x, const float* y, size_t n, float* partial, float* out, hipStream_t s)

@@ -61,12 +61,16 @@ hipError_t launch_maxpool_bwd(const float* dy, const float* x, float* dx, const 
 // ------------------------------------------------------------------------------------------
 struct GramPlan { int bt, tiles, splits, kslab; size_t slab_floats; };
 GramPlan gram_plan(int C, int hw);
-hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s);
+// region of interest of a blob [C][H][W]: hw (= rw * rows) pixels starting at (y0, x0); pitch = W, plane = H*W
+struct GramRoi { int y0, x0, rw, pitch; size_t plane; };
+hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s,
+                               const GramRoi* roi = nullptr);
 // out[i][j] = sum_s slabs[s][i][j] / n  - (target ? target[i][j] : 0);  partial[blockIdx] = sum out^2
 // `folded` is scratch of gram_fold_groups(pl) * C * C floats (two-stage reduction when there are many splits)
 int gram_fold_groups(const GramPlan& pl);
+// out = sum_s slabs[s] / divisor - (target ? target : 0)   (divisor = C*hw for a Gram matrix, 1 for raw sums)
 hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* target, float* out, int out_ld, float* partial,
-                              int* n_partial, int C, int hw, const GramPlan& pl, hipStream_t s);
+                              int* n_partial, int C, double divisor, const GramPlan& pl, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // Style gradient  S = c2 * (D @ F)  (D = G - G_style, C x C symmetric; F = blob [C][H][W]) on the conv
@@ -75,8 +79,12 @@ hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* ta
 //   fused = 1 : dst = (sw / *norm) * S + (accumulate ? dst : 0) ; partial as above
 // ------------------------------------------------------------------------------------------
 int style_grad_blocks(int C, int H, int W);          // partial-sum slots the launch writes
+struct PixRoi { int y0, x0, y1, x1; };               // half-open pixel rectangle of a blob
 hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float c2, int fused, float sw, const float* norm,
-                             int accumulate, float* partial, int* n_partial, int C, int H, int W, hipStream_t s);
+                             int accumulate, float* partial, int* n_partial, int C, int H, int W, hipStream_t s,
+                             const PixRoi* roi = nullptr);
+// out[0] = sum(part[0..n)) in double, rounded to float (deterministic, one workgroup)
+hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t s);
 // inject = (sw / *norm) * S + (accumulate ? inject : 0)
 hipError_t launch_scaled_accumulate(const float* S, float* inject, float sw, const float* norm,
                                     int accumulate, size_t n, hipStream_t s);
@@ -98,6 +106,8 @@ struct LayerElemArgs {
     float* part_gc2;        // sum (cn_coef (F-Fc))^2
     float* part_f2;         // sum F^2
     float* part_gd2;        // sum (dn_coef F)^2
+    // region of interest (tile-sharded mode): sums and non-zero writes only inside; w == 0 means whole tensor
+    int h, w, ry0, rx0, ry1, rx1;
 };
 hipError_t launch_layer_elem(const LayerElemArgs& a, int* n_partial, hipStream_t s);
 
@@ -122,6 +132,14 @@ struct ImagePassArgs {
     float* partial;         // 6 rows of kMaxPartials: tv, p, scd^2, (tv_w g_tv)^2, (p_w g_p)^2, grad^2
 };
 hipError_t launch_image_pass(const ImagePassArgs& a, int* n_partial, hipStream_t s);
+// Tile-sharded variant: the tile [ty, ty+th) x [tx, tx+tw) of a window image of pitch ww; neighbours outside
+// the tile come from `ring` ([3][th+2][tw+2], the periodic-wrap neighbourhood gathered from the owners).
+struct ImageTileArgs {
+    ImagePassArgs base;      // x / scd / x_out / m / v are WINDOW tensors (3, wh, ww); C/H/W = 3, wh, ww
+    const float* ring;
+    int ty, tx, th, tw;
+};
+hipError_t launch_image_pass_tile(const ImageTileArgs& a, int* n_partial, hipStream_t s);
 
 // pre/deprocess, worker.py:63-71
 hipError_t launch_preprocess_u8(const uint8_t* hwc, float* nchw, int H, int W, hipStream_t s);

@@ -1,0 +1,158 @@
+"""HIP tile backend of the tile-sharded mode: one ``Engine`` per rank holding that rank's window in HBM;
+the phases of tiled.TiledTransfer map 1:1 onto the ``st_tile_*`` entry points of the C ABI.  Device buffers
+are handed to torch (for RCCL) as zero-copy views through ``__cuda_array_interface__``."""
+
+from ctypes import byref, c_int, c_void_p
+
+import numpy as np
+import torch
+
+from .capi import check
+from .engine import Engine, OPT_ADAM
+from .tiling import blob_geometry
+from .transfer import weight_table, LOSS_NAMES, SCALAR_LOSS_NAMES, EPS
+
+F32 = np.float32
+
+
+class _DevArray:
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': '<f4', 'data': (int(ptr), False),
+                                         'version': 2, 'strides': None}
+
+
+def dev_tensor(ptr, shape, device):
+    return torch.as_tensor(_DevArray(ptr, shape), device=device)
+
+
+class HipTileBackend:
+    def __init__(self, net_params, grid, rank, content, style, init, weights, params, step_size=10,
+                 topology=None, device=0):
+        self.engine = Engine(topology, device)
+        self.engine.load_weights(net_params)
+        self.lib, self.ctx = self.engine.lib, self.engine._ctx
+        self.device = torch.device('cuda', device)
+        self.grid, self.rank = grid, rank
+        w, t = grid.windows[rank], grid.tiles[rank]
+        crop = lambda im, r: np.ascontiguousarray(im[r.y0:r.y1, r.x0:r.x1])
+        self.engine.set_input(crop(init, w))
+        self.engine.set_content(crop(content, w))
+        self.engine.set_style(style)
+        rows, cells = weight_table(weights)
+        cols = [[cells[k][r] for r in rows] for k in LOSS_NAMES]
+        self.engine.set_weights(rows, cols[0], cols[1], cols[2], [params[k] for k in SCALAR_LOSS_NAMES])
+        self.engine.optimizer_reset(OPT_ADAM, step_size)
+        self.engine.clear_norms()
+        check(self.lib.st_tile_configure(self.ctx, grid.gH, grid.gW, w.y0, w.x0, t.y0, t.x0, t.y1, t.x1))
+        self.params = params
+        self.wh, self.ww = w.y1 - w.y0, w.x1 - w.x0
+        topo = self.engine.topology
+        names = self.engine.blob_names
+        ggeo = blob_geometry(topo, grid.gH, grid.gW)
+        self.active = []
+        for r in rows:
+            cw, sw, dw = (cells[k][r] for k in LOSS_NAMES)
+            flags = tuple(abs(v) > EPS for v in (cw, sw, dw))
+            if any(flags):
+                c, gh, gw, _ = ggeo[names.index(r)]
+                self.active.append((r, names.index(r), F32(cw), F32(sw), F32(dw)) + flags + (c, c * gh * gw))
+        self.n_style = sum(1 for a in self.active if a[6])
+
+    def _sync(self):
+        self.engine.sync()
+
+    def _buf(self, which, shape):
+        p = c_void_p()
+        check(self.lib.st_tile_buffer(self.ctx, which, byref(p)))
+        return dev_tensor(p.value, shape, self.device)
+
+    def x_cur(self):
+        return self._buf(0, (3, self.wh, self.ww))
+
+    def x_next(self):
+        return self._buf(1, (3, self.wh, self.ww))
+
+    def swap(self):
+        torch.cuda.synchronize(self.device)
+        check(self.lib.st_tile_swap(self.ctx))
+
+    # ---- phases -------------------------------------------------------------------------------------------
+    def forward_partials(self):
+        torch.cuda.synchronize(self.device)
+        p, n = c_void_p(), c_int()
+        check(self.lib.st_tile_forward(self.ctx, byref(p), byref(n)))
+        self._sync()
+        self.p1 = dev_tensor(p.value, (n.value,), self.device) if n.value else None
+        return self.p1
+
+    def losses_need_style_norm(self):
+        torch.cuda.synchronize(self.device)
+        self.p1_host = self.p1.cpu().numpy().copy() if self.p1 is not None else np.zeros(0, F32)
+        p, n = c_void_p(), c_int()
+        check(self.lib.st_tile_losses(self.ctx, byref(p), byref(n)))
+        self.p2 = None
+        if n.value:
+            check(self.lib.st_tile_style_raw(self.ctx))
+            self._sync()
+            self.p2 = dev_tensor(p.value, (n.value,), self.device)
+        return self.p2
+
+    def finish_losses(self):
+        torch.cuda.synchronize(self.device)
+        self.s2_host = self.p2.cpu().numpy().copy() if self.p2 is not None else None
+        check(self.lib.st_tile_losses_finish(self.ctx))
+        self._sync()
+
+    def backward(self):
+        p = c_void_p()
+        check(self.lib.st_tile_backward(self.ctx, byref(p)))
+        return dev_tensor(p.value, (3, self.wh, self.ww), self.device)
+
+    def update(self, ring):
+        ring = ring.contiguous()
+        torch.cuda.synchronize(self.device)
+        self._ring = ring                                    # keep alive until the kernel has run
+        p, n = c_void_p(), c_int()
+        check(self.lib.st_tile_update(self.ctx, c_void_p(ring.data_ptr()), byref(p), byref(n)))
+        self.p3 = dev_tensor(p.value, (n.value,), self.device)
+        return self.p3
+
+    def finish_trace(self):
+        """Trace scalars from the reduced sums, in the reference's fp32 order (worker.py:249-301); same layout
+        as the single-GPU engine: 6 per active layer + 8."""
+        torch.cuda.synchronize(self.device)
+        p3 = self.p3.cpu().numpy()
+        s2 = self.s2_host if self.s2_host is not None else p3[6:]
+        d2 = self._buf(2, (max(self.n_style, 1),)).cpu().numpy()
+        norms = self._buf(3, (len(self.engine.blob_names) * 3,)).cpu().numpy()
+        vals, loss, pos, k = [], F32(0), 0, 0
+        for name, b, cw, sw, dw, c_on, s_on, d_on, C, n in self.active:
+            sums = self.p1_host[pos:pos + 4]
+            pos += 4
+            v6 = [0.0] * 6
+            if c_on:
+                cn = norms[b * 3 + 0]
+                v6[0] = cw * F32(sums[0] / n) / cn
+                v6[1] = abs(cw) * np.sqrt(F32(sums[1] / n)) / cn
+                loss += v6[0]
+            if s_on:
+                sn = norms[b * 3 + 1]
+                v6[2] = sw * F32(d2[k] / (C * C)) / sn
+                v6[3] = abs(sw / sn) * np.sqrt(F32(s2[k] / n))
+                loss += v6[2]
+                pos += C * C
+                k += 1
+            if d_on:
+                dn = norms[b * 3 + 2]
+                v6[4] = -dw * F32(sums[2] / n) / dn
+                v6[5] = abs(dw) * np.sqrt(F32(sums[3] / n)) / dn
+                loss += v6[4]
+            vals += v6
+        n3 = 3.0 * self.grid.gH * self.grid.gW
+        scd_loss = loss
+        t_loss = F32(self.params['tv']) * p3[0]
+        p_loss = F32(self.params['p']) * (p3[1] / F32(self.params['p_power']))
+        total = scd_loss + t_loss + p_loss
+        vals += [scd_loss, t_loss, p_loss, np.sqrt(F32(p3[2] / n3)), np.sqrt(F32(p3[3] / n3)),
+                 np.sqrt(F32(p3[4] / n3)), total, np.sqrt(F32(p3[5] / n3))]
+        return np.asarray(vals, np.float64)

@@ -285,3 +285,96 @@ def test_config1_golden_gate_starry_night_256px_adam_50_iters():
     assert idv.shape == (192, 256, 3) and idv.dtype == F32
     assert np.mean((idv - ic) ** 2) <= 4.0        # 0-255^2 units; the image moved by thousands
     assert np.mean((ic - init) ** 2) > 1000.0
+
+
+# ----------------------------------------------------------- tile-sharded mode (BASELINE config 5) on the GPU
+TILED_TOPO = oracle.tiny_topology((8, 16), (2, 2))
+TILED_WEIGHTS = {'content': {'conv2_2': 0.08, 'conv1_2': 0.5}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'pool1': 0.7},
+                 'deepdream': {'conv2_1': 0.02}}
+TILED_PARAMS = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+
+
+def _tiled_images(h, w):
+    rs = np.random.RandomState
+    return (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (20, 28, 3)).astype(np.uint8),
+            rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
+
+
+def test_tiled_single_rank_equals_plain_engine():
+    """A 1x1 grid (tile = whole image, ring = the image's own periodic wrap) must reproduce the ordinary
+    engine step: same kernels, reductions routed through the tile phases."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    h, w = 32, 48
+    content, style, init = _tiled_images(h, w)
+    params = oracle.he_init_weights(TILED_TOPO, 0, 0.1)
+    grid = tiling.TileGrid(h, w, 1, 1, TILED_TOPO, 5)
+    tt = tiled.TiledTransfer(grid, 0, HipTileBackend(params, grid, 0, content, style, init, TILED_WEIGHTS, TILED_PARAMS,
+                                                     step_size=10, topology=TILED_TOPO), tiled.Comm())
+    ref = st2.StyleTransfer(st2.HipModel(params, topology=TILED_TOPO))
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(TILED_WEIGHTS, TILED_PARAMS)
+    ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
+    assert ref.start()
+    for i in range(4):
+        vals = tt.step()
+        img, tr = ref.step()
+        assert np.isclose(vals[-2], tr['loss'], rtol=1e-5), i
+        assert np.isclose(vals[-1], tr['grad'], rtol=1e-5), i
+        assert np.allclose(tt.tile_image(), img, rtol=0, atol=2e-3), i
+
+
+def _tiled_gpu_rank(rank, world, rows, cols, port, steps, h, w, q):
+    import os, sys
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    dist.init_process_group('gloo', rank=rank, world_size=world)      # one GPU here: ranks share it, data staged via host
+    content, style, init = _tiled_images(h, w)
+    grid = tiling.TileGrid(h, w, rows, cols, TILED_TOPO, 5)
+    backend = HipTileBackend(oracle.he_init_weights(TILED_TOPO, 0, 0.1), grid, rank, content, style, init,
+                             TILED_WEIGHTS, TILED_PARAMS, step_size=10, topology=TILED_TOPO)
+    tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world))
+    res = []
+    for _ in range(steps):
+        vals = tt.step()
+        res.append((tt.tile_image(), vals))
+    q.put((rank, tuple(grid.tiles[rank]), res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('rows,cols', [(1, 2), (2, 2)])
+def test_tiled_multi_rank_on_one_gpu_matches_oracle(rows, cols):
+    """2 / 4 processes share the GPU (each with its own engine + window), exchange through gloo, and must
+    reproduce the single-process CPU oracle on the whole image."""
+    import torch.multiprocessing as mp
+    h, w, steps, world = 32, 48, 3, rows * cols
+    content, style, init = _tiled_images(h, w)
+    cpu = oracle.TransferOracle(oracle.NetOracle(TILED_TOPO, oracle.he_init_weights(TILED_TOPO, 0, 0.1)))
+    cpu.set_input(init); cpu.set_content(content); cpu.set_style(style); cpu.reset()
+    cpu.set_weights(TILED_WEIGHTS, TILED_PARAMS); cpu.set_optimizer('adam', 10)
+    assert cpu.start()
+    ref = []
+    for _ in range(steps):
+        img, tr = cpu.step()
+        ref.append((np.asarray(img, F32).copy(), dict(tr)))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + (__import__('os').getpid() + rows * 5 + cols) % 1000
+    procs = [ctx.Process(target=_tiled_gpu_rank, args=(r, world, rows, cols, port, steps, h, w, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for step in range(steps):
+        full = np.zeros_like(ref[step][0])
+        for rank, (y0, x0, y1, x1), res in got:
+            full[y0:y1, x0:x1] = res[step][0]
+            assert np.isclose(res[step][1][-2], ref[step][1]['loss'], rtol=1e-4), (step, rank)
+            assert np.isclose(res[step][1][-1], ref[step][1]['grad'], rtol=1e-3), (step, rank)
+        assert np.mean((full - ref[step][0]) ** 2) <= 1.0, step
+    assert np.allclose(full, ref[-1][0], rtol=0, atol=0.5) or np.mean(np.abs(full - ref[-1][0]) > 0.5) < 0.02
