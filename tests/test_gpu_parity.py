@@ -378,3 +378,66 @@ def test_tiled_multi_rank_on_one_gpu_matches_oracle(rows, cols):
             assert np.isclose(res[step][1][-1], ref[step][1]['grad'], rtol=1e-3), (step, rank)
         assert np.mean((full - ref[step][0]) ** 2) <= 1.0, step
     assert np.allclose(full, ref[-1][0], rtol=0, atol=0.5) or np.mean(np.abs(full - ref[-1][0]) > 0.5) < 0.02
+
+
+def _tiled_vgg_rank(rank, world, port, steps, h, w, q):
+    import os
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (96, 80, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
+    topo = oracle.VGG19_TOPOLOGY
+    grid = tiling.TileGrid(h, w, 1, 2, topo, 17)
+    weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
+               'deepdream': {}}
+    backend = HipTileBackend(oracle.he_init_weights(topo, seed=0), grid, rank, content, style, init, weights,
+                             {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}, step_size=10)
+    tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world))
+    res = []
+    for _ in range(steps):
+        vals = tt.step()
+        res.append((tt.tile_image(), vals))
+    q.put((rank, tuple(grid.tiles[rank]), tuple(grid.windows[rank]), res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tiled_vgg19_two_ranks_match_single_gpu_engine():
+    """Full VGG19 to conv5_1 (receptive-field apron 80 px): 2 ranks on a 176 x 416 image vs the plain engine."""
+    import torch.multiprocessing as mp
+    h, w, steps = 176, 416, 2
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (96, 80, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
+    weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
+               'deepdream': {}}
+    ref = st2.StyleTransfer(st2.HipModel(oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0)))
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(weights, {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2})
+    ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
+    assert ref.start()
+    want = [ref.step() for _ in range(steps)]
+    want = [(np.asarray(i, F32).copy(), dict(t)) for i, t in want]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29300 + __import__('os').getpid() % 500
+    procs = [ctx.Process(target=_tiled_vgg_rank, args=(r, 2, port, steps, h, w, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, tile, window, res in got:
+        assert window[3] - window[1] == 208 + 80          # tile 208 px + the 80-px apron on its inner side
+    for step in range(steps):
+        full = np.zeros_like(want[step][0])
+        for rank, (y0, x0, y1, x1), window, res in got:
+            full[y0:y1, x0:x1] = res[step][0]
+            assert np.isclose(res[step][1][-2], want[step][1]['loss'], rtol=1e-4), (step, rank)
+            assert np.isclose(res[step][1][-1], want[step][1]['grad'], rtol=1e-3), (step, rank)
+        assert np.mean((full - want[step][0]) ** 2) <= 1.0, step

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Tile-sharded single-image benchmark (BASELINE config 5).
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_tiled.py \
+        --size 8192 --grid 2x4 --steps 10
+    python tools/bench_tiled.py --size 2048 --grid 1x1          # one GPU: the tile phases without communication
+
+One rank per GPU, RCCL for the all-reduces and the strip exchanges.  Prints one JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import style_transfer2_amd as st2                                    # noqa: E402
+from style_transfer2_amd import tiled, tiling, weights as st2_weights   # noqa: E402
+from style_transfer2_amd.tile_backend import HipTileBackend             # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--size', default='8192', help='N or HxW of the whole image')
+ap.add_argument('--style-size', type=int, default=1024)
+ap.add_argument('--grid', default='2x4')
+ap.add_argument('--steps', type=int, default=10)
+ap.add_argument('--warmup', type=int, default=2)
+args = ap.parse_args()
+rows, cols = (int(v) for v in args.grid.split('x'))
+gH, gW = (int(v) for v in args.size.split('x')) if 'x' in args.size else (int(args.size), int(args.size))
+rank, local, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+assert world == rows * cols, 'world size %d != grid %s' % (world, args.grid)
+dist = None
+if world > 1:
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+WEIGHTS = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
+           'deepdream': {}}
+PARAMS = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+topo = st2.VGG19_TOPOLOGY
+grid = tiling.TileGrid(gH, gW, rows, cols, topo, 17)
+win = grid.windows[rank]
+
+
+def window_image(seed):
+    """Deterministic pseudo-random image, generated per window so that no rank holds the full 8192^2 image."""
+    yy, xx = np.mgrid[win.y0:win.y1, win.x0:win.x1].astype(np.uint32)
+    out = np.empty((win.y1 - win.y0, win.x1 - win.x0, 3), np.uint8)
+    for c in range(3):
+        hsh = (yy * np.uint32(73856093)) ^ (xx * np.uint32(19349663)) ^ np.uint32((seed * 3 + c) * 83492791)
+        hsh ^= hsh >> np.uint32(13)
+        hsh *= np.uint32(1274126177)
+        out[..., c] = (hsh >> np.uint32(11)) & np.uint32(255)
+    return out
+
+
+class WindowView:
+    """Stands in for a full image: HipTileBackend only ever crops its own window out of it."""
+    def __init__(self, arr):
+        self.arr = arr
+
+    def __getitem__(self, idx):
+        ys, xs = idx
+        return self.arr[ys.start - win.y0:ys.stop - win.y0, xs.start - win.x0:xs.stop - win.x0]
+
+
+style = np.random.RandomState(2).randint(0, 256, (args.style_size, args.style_size, 3)).astype(np.uint8)
+backend = HipTileBackend(st2_weights.he_normal(topo, seed=0), grid, rank, WindowView(window_image(1)), style,
+                         WindowView(window_image(3)), WEIGHTS, PARAMS, step_size=10, device=local)
+tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world))
+for _ in range(args.warmup):
+    tt.step()
+backend.engine.sync()
+if dist is not None:
+    dist.barrier()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    vals = tt.step()
+backend.engine.sync()
+if dist is not None:
+    dist.barrier()
+dt = time.perf_counter() - t0
+if rank == 0:
+    print(json.dumps({'metric': 'tile-sharded style-transfer iters/sec @%sx%s VGG19' % (gH, gW), 'value': args.steps / dt,
+                      'unit': 'it/s', 'n_gpus': world, 'grid': args.grid, 'steps': args.steps, 'ms_per_step': 1e3 * dt / args.steps,
+                      'apron_px': grid.apron, 'window': [win.y1 - win.y0, win.x1 - win.x0], 'loss': float(vals[-2]),
+                      'dtype': 'f32', 'scaling': 'strong', 'data': 'synthetic'}))
+if dist is not None:
+    dist.destroy_process_group()
