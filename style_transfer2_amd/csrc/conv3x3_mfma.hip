@@ -367,6 +367,7 @@ ST2_CONV_KERNEL(conv3x3_mfma_f32_64x128_cc4, 64, 4, 1, 4, 4, 0, 3)
 ST2_CONV_KERNEL(conv3x3_mfma_f32_64x256_cc8, 64, 8, 1, 4, 8, 0, 2)
 ST2_CONV_KERNEL(conv3x3_mfma_f32_128x128_cc8, 128, 4, 2, 2, 8, 0, 1)
 ST2_CONV_KERNEL(conv3x3_mfma_f32_128x128_cc4_stamped, 128, 4, 2, 2, 4, 1, 3)
+ST2_CONV_KERNEL(conv3x3_mfma_f32_64x64_cc4, 64, 2, 2, 2, 4, 0, 4)
 #define ST2_STYLE_KERNEL(NAME, BM, ROWS, WM, WN, CCK, WPE)                                                \
     __global__ __launch_bounds__(NTHREADS, WPE) void NAME##_q(const ConvKArgs a) { conv3x3_body<BM, ROWS, WM, WN, CCK, true, 0, 1, EPI_STYLE>(a); } \
     __global__ __launch_bounds__(NTHREADS, WPE) void NAME##_w(const ConvKArgs a) { conv3x3_body<BM, ROWS, WM, WN, CCK, false, 0, 1, EPI_STYLE>(a); }
@@ -403,13 +404,13 @@ static hipError_t run(const ConvProblem& p, int BM, int ROWS, int CCK, conv_kern
     return hipGetLastError();
 }
 
-int conv_num_configs() { return 7; }
+int conv_num_configs() { return 8; }
 
 const char* conv_config_name(int cfg)
 {
     static const char* names[] = {"128x128px cc4", "128x256px cc4", "64x256px cc4", "64x128px cc4", "64x256px cc8", "128x128px cc8",
-                                  "STAMPED 128x128px cc4"};
-    return cfg >= 0 && cfg < 7 ? names[cfg] : "?";
+                                  "STAMPED 128x128px cc4", "64x64px cc4"};
+    return cfg >= 0 && cfg < 8 ? names[cfg] : "?";
 }
 
 // Tile choice by a small occupancy model.  A launch is a number of equal blocks; each CU receives
@@ -421,8 +422,8 @@ const char* conv_config_name(int cfg)
 int conv_pick_config(const ConvProblem& p)
 {
     struct Cand { int cfg, bm, rows, occ; };
-    static const Cand cands[] = {{1, 128, 8, 2}, {0, 128, 4, 3}, {2, 64, 8, 4}, {3, 64, 4, 5}};
-    static const double eff[6] = {0.0, 0.66, 0.88, 0.93, 0.95, 0.96};
+    static const Cand cands[] = {{1, 128, 8, 2}, {0, 128, 4, 3}, {2, 64, 8, 4}, {3, 64, 4, 5}, {7, 64, 2, 6}};
+    static const double eff[7] = {0.0, 0.66, 0.88, 0.93, 0.95, 0.96, 0.96};
     const long long tx = (p.W + 31) / 32;
     int best = 3;
     double best_t = 1e300;
@@ -434,7 +435,7 @@ int conv_pick_config(const ConvProblem& p)
         const long long rounds = n / c.occ, tail = n % c.occ;
         double t = rounds * c.occ * work / eff[c.occ];
         if (tail) t += tail * work / eff[tail];
-        t *= 1.0 + 0.02 * (c.bm == 64);                              // 64-row tiles re-read activations twice as often
+        t *= 1.0 + 0.02 * (c.bm == 64) + 0.04 * (c.rows == 2);       // small tiles re-read activations / weights more often
         if (t < best_t) { best_t = t; best = c.cfg; }
     }
     return best;
@@ -444,7 +445,7 @@ hipError_t launch_conv3x3_cfg(const ConvProblem& p, int cfg, hipStream_t s)
 {
     if (p.MPad % kCoutQuantum != 0 || p.MPad < p.M) return hipErrorInvalidValue;
     if (cfg < 0) cfg = conv_pick_config(p);
-    if ((cfg == 0 || cfg == 1 || cfg >= 5) && p.MPad % 128 != 0) return hipErrorInvalidValue;
+    if ((cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && p.MPad % 128 != 0) return hipErrorInvalidValue;
 #define ST2_RUN(NAME, BM, ROWS, CCK) return run(p, BM, ROWS, CCK, NAME##_q, NAME##_w, s)
     switch (cfg) {
     case 0: ST2_RUN(conv3x3_mfma_f32_128x128_cc4, 128, 4, 4);
@@ -454,6 +455,7 @@ hipError_t launch_conv3x3_cfg(const ConvProblem& p, int cfg, hipStream_t s)
     case 4: ST2_RUN(conv3x3_mfma_f32_64x256_cc8, 64, 8, 8);
     case 5: ST2_RUN(conv3x3_mfma_f32_128x128_cc8, 128, 4, 8);
     case 6: ST2_RUN(conv3x3_mfma_f32_128x128_cc4_stamped, 128, 4, 4);
+    case 7: ST2_RUN(conv3x3_mfma_f32_64x64_cc4, 64, 2, 4);
     }
 #undef ST2_RUN
     return hipErrorInvalidValue;

@@ -115,6 +115,7 @@ struct st_ctx {
     float* image_part = nullptr;                   // 6 * kMaxPartials
     int image_cnt = 0;
     float* trace_dev = nullptr;
+    double* trace_sums = nullptr;                  // device scratch of the trace finalisation
     float* trace_host = nullptr;                   // pinned
     int trace_len_last = 8;
     float* hwc_dev = nullptr;
@@ -164,7 +165,7 @@ static int dmalloc(float** p, size_t nfloats)
 }
 static void dfree(float*& p)
 {
-    if (p) (void)hipFree(p);
+    if (p && hipFree(p) != hipSuccess) (void)hipGetLastError();   // never leave a sticky error behind
     p = nullptr;
 }
 
@@ -482,6 +483,7 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
         t.image_part = c->image_part; t.image_count = c->image_cnt; t.image_n = 3.0 * c->H * c->W;
         t.tv_w = c->tv_w; t.p_w = c->p_w; t.p_pow = c->p_pow; t.have_grad = want_grad;
         t.out = c->trace_dev;
+        t.sums = c->trace_sums;
         c->trace_len_last = t.n_layers * 6 + 8;
         ProfScope ps(c, P_FINALIZE, 0, 0);
         HIP_TRY(launch_finalize_trace(t, c->stream));
@@ -620,6 +622,7 @@ int st_create(st_ctx** out, int device_id, const st_layer_desc* layers, int n_la
     ST_TRY(dmalloc(&c->norms, c->nb * 3));
     ST_TRY(dmalloc(&c->image_part, 6 * kMaxPartials));
     ST_TRY(dmalloc(&c->trace_dev, kMaxTraceLayers * 6 + 8));
+    HIP_TRY(hipMalloc((void**)&c->trace_sums, (kMaxTraceLayers * kLayerSlots + kImageSlots) * sizeof(double)));
     ST_TRY(dmalloc(&c->scal, 64));
     ST_TRY(dmalloc(&c->dot_part, kMaxPartials));
     HIP_TRY(hipHostMalloc((void**)&c->trace_host, (kMaxTraceLayers * 6 + 8) * sizeof(float), 0));
@@ -649,6 +652,7 @@ int st_destroy(st_ctx* c)
     dfree(c->tile.p1); dfree(c->tile.p2); dfree(c->tile.p3); dfree(c->tile.pd); dfree(c->tile.wgrad);
     dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->scal); dfree(c->dot_part); dfree(c->hwc_dev);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
+    if (c->trace_sums) (void)hipFree(c->trace_sums);
     if (c->trace_host) (void)hipHostFree(c->trace_host);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -1404,7 +1408,7 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     if (cfg_used) *cfg_used = cfg;
     unsigned long long* dstamps = nullptr;
     const size_t max_blocks = (size_t)((W + 31) / 32) * ((H + 3) / 4) * (p.MPad / 64);
-    if (cfg >= 6) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
+    if (cfg == 6) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
     hipStream_t s;
     HIP_TRY(hipStreamCreate(&s));
     hipEvent_t e0, e1;

@@ -48,10 +48,73 @@ __global__ __launch_bounds__(256) void maxpool_fwd_k(const float* __restrict__ i
     }
 }
 
+// Fast paths for H even, W % 4 == 0 (every window full): one thread = two adjacent windows = a 2 x 4 patch,
+// 16-byte loads and stores.
+__device__ __forceinline__ int first_max4(float a, float b, float c, float d, float* best)
+{
+    // Caffe scan order (r0,c0) (r0,c1) (r1,c0) (r1,c1); strictly greater wins -> first maximum
+    int arg = 0; float m = a;
+    if (b > m) { m = b; arg = 1; }
+    if (c > m) { m = c; arg = 2; }
+    if (d > m) { m = d; arg = 3; }
+    *best = m;
+    return arg;
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_v4_k(const float* __restrict__ in, float* __restrict__ out,
+                                                        size_t n_patches, int W4, int Ho)
+{
+    // patch id -> (plane row pair, quad column); in: rows of W = 4*W4 floats
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n_patches; idx += (size_t)gridDim.x * 256) {
+        const size_t q = idx % W4, pr = idx / W4;                 // pr = c * Ho + py
+        const float4 r0 = *reinterpret_cast<const float4*>(in + (pr * 2) * (size_t)W4 * 4 + q * 4);
+        const float4 r1 = *reinterpret_cast<const float4*>(in + (pr * 2 + 1) * (size_t)W4 * 4 + q * 4);
+        float2 o;
+        first_max4(r0.x, r0.y, r1.x, r1.y, &o.x);
+        first_max4(r0.z, r0.w, r1.z, r1.w, &o.y);
+        *reinterpret_cast<float2*>(out + pr * (size_t)W4 * 2 + q * 2) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_v4_k(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        float* __restrict__ dx, const float* __restrict__ inject,
+                                                        int apply_mask, size_t n_patches, int W4)
+{
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n_patches; idx += (size_t)gridDim.x * 256) {
+        const size_t q = idx % W4, pr = idx / W4;
+        const size_t o0 = (pr * 2) * (size_t)W4 * 4 + q * 4, o1 = o0 + (size_t)W4 * 4;
+        const float4 r0 = *reinterpret_cast<const float4*>(x + o0);
+        const float4 r1 = *reinterpret_cast<const float4*>(x + o1);
+        const float2 g = *reinterpret_cast<const float2*>(dy + pr * (size_t)W4 * 2 + q * 2);
+        float best;
+        const int a0 = first_max4(r0.x, r0.y, r1.x, r1.y, &best);
+        const int a1 = first_max4(r0.z, r0.w, r1.z, r1.w, &best);
+        float4 d0 = make_float4(a0 == 0 ? g.x : 0.f, a0 == 1 ? g.x : 0.f, a1 == 0 ? g.y : 0.f, a1 == 1 ? g.y : 0.f);
+        float4 d1 = make_float4(a0 == 2 ? g.x : 0.f, a0 == 3 ? g.x : 0.f, a1 == 2 ? g.y : 0.f, a1 == 3 ? g.y : 0.f);
+        if (apply_mask) {
+            d0.x = r0.x > 0.f ? d0.x : 0.f; d0.y = r0.y > 0.f ? d0.y : 0.f; d0.z = r0.z > 0.f ? d0.z : 0.f; d0.w = r0.w > 0.f ? d0.w : 0.f;
+            d1.x = r1.x > 0.f ? d1.x : 0.f; d1.y = r1.y > 0.f ? d1.y : 0.f; d1.z = r1.z > 0.f ? d1.z : 0.f; d1.w = r1.w > 0.f ? d1.w : 0.f;
+        }
+        if (inject) {
+            const float4 i0 = *reinterpret_cast<const float4*>(inject + o0);
+            const float4 i1 = *reinterpret_cast<const float4*>(inject + o1);
+            d0.x += i0.x; d0.y += i0.y; d0.z += i0.z; d0.w += i0.w;
+            d1.x += i1.x; d1.y += i1.y; d1.z += i1.z; d1.w += i1.w;
+        }
+        *reinterpret_cast<float4*>(dx + o0) = d0;
+        *reinterpret_cast<float4*>(dx + o1) = d1;
+    }
+}
+
 hipError_t launch_maxpool_fwd(const float* in, float* out, int C, int H, int W, hipStream_t s)
 {
     const int Ho = pooled_size(H), Wo = pooled_size(W);
     const size_t total = (size_t)C * Ho * Wo;
+    if (H % 2 == 0 && W % 4 == 0) {
+        const size_t n_patches = (size_t)C * Ho * (W / 4);
+        maxpool_fwd_v4_k<<<reduce_grid(n_patches, 256, 65536), 256, 0, s>>>(in, out, n_patches, W / 4, Ho);
+        return hipGetLastError();
+    }
     maxpool_fwd_k<<<reduce_grid(total, 256, 65536), 256, 0, s>>>(in, out, C, H, W, Ho, Wo);
     return hipGetLastError();
 }
@@ -100,6 +163,11 @@ hipError_t launch_maxpool_bwd(const float* dy, const float* x, float* dx, const 
 {
     const int Ho = pooled_size(H), Wo = pooled_size(W);
     const size_t total = (size_t)C * Ho * Wo;
+    if (H % 2 == 0 && W % 4 == 0) {
+        const size_t n_patches = (size_t)C * Ho * (W / 4);
+        maxpool_bwd_v4_k<<<reduce_grid(n_patches, 256, 65536), 256, 0, s>>>(dy, x, dx, inject, apply_mask, n_patches, W / 4);
+        return hipGetLastError();
+    }
     maxpool_bwd_k<<<reduce_grid(total, 256, 65536), 256, 0, s>>>(dy, x, dx, inject, apply_mask, C, H, W, Ho, Wo);
     return hipGetLastError();
 }
@@ -403,23 +471,28 @@ hipError_t launch_deprocess(const float* nchw, float* hwc, int H, int W, hipStre
 }
 
 // ---------------------------------------------------------------------------------- trace scalars
-__global__ __launch_bounds__(256) void finalize_trace_k(const TraceArgs a)
+// Stage 1: one workgroup per partial-sum slot (layer x 6 + 6 image slots) -> a.sums[slot] (double).
+__global__ __launch_bounds__(256) void trace_sums_k(const TraceArgs a)
 {
     __shared__ double scratch[256];
-    __shared__ double sums[kMaxTraceLayers * kLayerSlots + kImageSlots];
-    for (int l = 0; l < a.n_layers; ++l)
-        for (int k = 0; k < kLayerSlots; ++k) {
-            double v = 0.0;
-            if (a.layer[l].part[k] && a.layer[l].count[k] > 0)
-                v = sum_partials(a.layer[l].part[k], a.layer[l].count[k], scratch);
-            if (threadIdx.x == 0) sums[l * kLayerSlots + k] = v;
-        }
-    for (int k = 0; k < kImageSlots; ++k) {
-        const double v = sum_partials(a.image_part + k * kMaxPartials, a.image_count, scratch);
-        if (threadIdx.x == 0) sums[a.n_layers * kLayerSlots + k] = v;
+    const int slot = blockIdx.x;
+    const int nl = a.n_layers * kLayerSlots;
+    double v = 0.0;
+    if (slot < nl) {
+        const TraceLayer& L = a.layer[slot / kLayerSlots];
+        const int k = slot % kLayerSlots;
+        if (L.part[k] && L.count[k] > 0) v = sum_partials(L.part[k], L.count[k], scratch);
+    } else {
+        v = sum_partials(a.image_part + (slot - nl) * kMaxPartials, a.image_count, scratch);
     }
-    __syncthreads();
+    if (threadIdx.x == 0) a.sums[slot] = v;
+}
+
+// Stage 2: the scalar arithmetic of the trace, in the reference's fp32 order (worker.py:249-301).
+__global__ void finalize_trace_k(const TraceArgs a)
+{
     if (threadIdx.x != 0) return;
+    const double* sums = a.sums;
     float loss = 0.f;
     for (int l = 0; l < a.n_layers; ++l) {
         const TraceLayer& L = a.layer[l];
@@ -466,7 +539,8 @@ __global__ __launch_bounds__(256) void finalize_trace_k(const TraceArgs a)
 
 hipError_t launch_finalize_trace(const TraceArgs& a, hipStream_t s)
 {
-    finalize_trace_k<<<1, 256, 0, s>>>(a);
+    trace_sums_k<<<a.n_layers * kLayerSlots + kImageSlots, 256, 0, s>>>(a);
+    finalize_trace_k<<<1, 64, 0, s>>>(a);
     return hipGetLastError();
 }
 

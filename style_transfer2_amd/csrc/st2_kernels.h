@@ -170,6 +170,7 @@ struct TraceArgs {
     float tv_w, p_w, p_pow;
     int have_grad;
     float* out;                  // [n_layers*6 + 8]
+    double* sums;                // scratch: n_layers*6 + 6 doubles
 };
 hipError_t launch_finalize_trace(const TraceArgs& a, hipStream_t s);
 
