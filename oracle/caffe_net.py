@@ -211,6 +211,20 @@ class NetOracle:
             self._blobs[layer[1]] = x
         return OrderedDict((n, self._blobs[n][None]) for n in wanted)
 
+    def adopt_forward_state(self, blobs):
+        """Replace the saved forward state (ReLU masks, pool arg-max) by that of another implementation's
+        blobs ({name: (1,C,h,w)}) for every blob given.  ReLU and max-pool are discontinuous: two correct fp32
+        forwards that differ by rounding (1e-6 relative) disagree on the sign of a handful of pre-activations
+        and on a handful of near-tied pooling windows per few million activations, and each such flip changes
+        the gradient locally by O(1).  Parity tests of the BACKWARD arithmetic therefore run the oracle's
+        backward on the implementation-under-test's own forward state; the end-to-end gradient is compared
+        separately with a bound that allows for those flips."""
+        for name, arr in blobs.items():
+            self._blobs[name] = np.ascontiguousarray(np.asarray(arr, F32)[0])
+        for i, layer in enumerate(self.topology):
+            if layer[0] == 'pool' and self.blob_names[i] in self._blobs and layer[1] in self._slots:
+                _, self._slots[layer[1]] = maxpool_forward(self._blobs[self.blob_names[i]])
+
     # worker.py:88-106
     def backward(self, diffs):
         """Ranged backward with per-blob diff injection.

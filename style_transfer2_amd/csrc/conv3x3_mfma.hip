@@ -16,6 +16,7 @@
 // fp32 MFMA == a k-ordered fmaf chain, so results are plain IEEE fp32.
 #include "st2_kernels.h"
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace st2 {
@@ -461,7 +462,14 @@ hipError_t launch_conv3x3_cfg(const ConvProblem& p, int cfg, hipStream_t s)
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_conv3x3(const ConvProblem& p, hipStream_t s) { return launch_conv3x3_cfg(p, -1, s); }
+hipError_t launch_conv3x3(const ConvProblem& p, hipStream_t s)
+{
+    // ST2_CONV_CFG=<id> forces one tile configuration (debugging / tests of every configuration)
+    static const int forced = [] { const char* e = getenv("ST2_CONV_CFG"); return e ? atoi(e) : -1; }();
+    if (forced >= 0 && !((forced == 0 || forced == 1 || forced == 5 || forced == 6) && p.MPad % 128 != 0))
+        return launch_conv3x3_cfg(p, forced, s);
+    return launch_conv3x3_cfg(p, -1, s);
+}
 
 // Style gradient S = c2 * (D @ F) on the conv pipeline (TAPS = 1).  Dp is D laid out [C][MPad].
 static void style_tile(int C, int* bm, int* rows) { if (C > 64) { *bm = 128; *rows = 4; } else { *bm = 64; *rows = 8; } }

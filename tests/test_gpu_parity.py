@@ -441,3 +441,53 @@ def test_tiled_vgg19_two_ranks_match_single_gpu_engine():
             assert np.isclose(res[step][1][-2], want[step][1]['loss'], rtol=1e-4), (step, rank)
             assert np.isclose(res[step][1][-1], want[step][1]['grad'], rtol=1e-3), (step, rank)
         assert np.mean((full - want[step][0]) ** 2) <= 1.0, step
+
+
+def test_vgg19_odd_default_size_225x300_unaligned_paths():
+    """The reference's default initial_size = 300 gives 225 x 300 (config.ini:16): widths 300, 150, 75, 38, 19 exercise
+    ceil-mode pooling with clipped windows and the un-aligned (dword DMA) conv variants at VGG widths.
+
+    ReLU / max-pool are discontinuous, so at this size a handful of sign / arg-max flips between two correct fp32
+    forwards are expected (oracle.NetOracle.adopt_forward_state explains).  Three checks: forward blobs (tight),
+    the whole backward chain on a shared forward state (tight), the end-to-end objective (flip-tolerant)."""
+    topo = oracle.VGG19_TOPOLOGY
+    params = oracle.he_init_weights(topo, seed=0)
+    net = oracle.NetOracle(topo, params, full_forward=False)
+    gpu = st2.HipModel(params)
+    rs = np.random.RandomState
+    content = rs(1).randint(0, 256, (225, 300, 3)).astype(np.uint8)
+    style = rs(2).randint(0, 256, (187, 300, 3)).astype(np.uint8)
+    init = rs(3).randint(0, 256, (225, 300, 3)).astype(np.uint8)
+    # (1) forward
+    x = net.preprocess(init)
+    names = ['conv1_1', 'pool1', 'conv2_2', 'pool2', 'conv3_4', 'pool3', 'conv4_2', 'pool4', 'conv5_1']
+    fc, fg = net.forward(x, names), gpu.forward(x, names)
+    flips = 0
+    for n in names:
+        assert fg[n].shape == fc[n].shape and rel_l2(fg[n], fc[n]) <= 1e-5, n
+        flips += int(np.sum((fc[n] > 0) != (fg[n] > 0)))
+    assert flips <= 50                     # a few per several million activations, not a pattern
+    # (2) ranged backward with injections at conv, pool and data blobs, on the GPU's forward state
+    full = gpu.forward(x, ['data'] + [l[1] for l in topo[:17]])
+    net.forward(x, list(full))
+    net.adopt_forward_state(full)
+    diffs = {n: rs(5 + i).randn(*full[n].shape).astype(F32) for i, n in enumerate(['conv5_1', 'pool4', 'conv4_2', 'conv3_1', 'pool1', 'conv1_1'])}
+    assert rel_l2(gpu.backward(diffs), net.backward(diffs)) <= 1e-5
+    # (3) end to end: loss tight, gradient flip-tolerant, trace values
+    weights = {'content': {'conv4_2': 0.08, 'pool3': 0.01},
+               'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1, 'pool4': 0.5},
+               'deepdream': {'conv5_1': 0.01}}
+    params4 = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+    cpu = oracle.TransferOracle(oracle.NetOracle(topo, params, full_forward=False))
+    dev = st2.StyleTransfer(gpu)
+    for st in (cpu, dev):
+        st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+        st.set_weights(weights, params4)
+    lo, go = cpu.opfunc(cpu.input)
+    ld, gd = dev.opfunc()
+    assert gd.shape == go.shape == (1, 3, 225, 300)
+    assert np.isclose(ld, lo, rtol=1e-5)
+    assert rel_l2(gd, go) <= 5e-3
+    err = np.abs(gd - go)[0].max(0)
+    assert np.mean(err > 1e-3 * np.abs(go).max()) <= 0.02      # the disagreement is confined to a few receptive fields
+    check_trace(list(cpu.traces[-1].data), list(cpu.traces[-1].data.values()), dev.traces[-1].data, rtol=2e-3)
