@@ -491,3 +491,87 @@ def test_vgg19_odd_default_size_225x300_unaligned_paths():
     err = np.abs(gd - go)[0].max(0)
     assert np.mean(err > 1e-3 * np.abs(go).max()) <= 0.02      # the disagreement is confined to a few receptive fields
     check_trace(list(cpu.traces[-1].data), list(cpu.traces[-1].data.values()), dev.traces[-1].data, rtol=2e-3)
+
+
+# ------------------------------------------------------------------- the worker loop on the real engine
+def test_worker_end_to_end_on_gpu_with_resample_and_optimizer_switch():
+    """The drop-in worker.py driven through its message protocol (in-process sockets) on the HIP engine:
+    SetImages / SetWeights / SetOptimizer / Start, iterates, a RESAMPLE of input+content to a new size with a live
+    Adam optimizer (host Pillow path, optimizers.py:29-40), an optimizer switch, pause, shutdown."""
+    import sys, os, pickle
+    from collections import deque
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import messages, worker as worker_mod
+
+    class Socks:
+        class Again(Exception):
+            pass
+
+        def __init__(self):
+            self.inbound, self.sent = deque(), []
+
+        def recv_pyobj(self, flags=0):
+            if not self.inbound:
+                if flags:
+                    raise self.Again()
+                return messages.Shutdown()
+            return pickle.loads(pickle.dumps(self.inbound.popleft()))
+
+        def send_pyobj(self, obj):
+            self.sent.append(obj)
+            n_it = sum(isinstance(m, messages.Iterate) for m in self.sent)
+            script = {3: [messages.SetImages((48, 64), messages.SetImages.RESAMPLE, messages.SetImages.RESAMPLE)],
+                      6: [messages.SetOptimizer('lbfgs', 1)],
+                      9: [messages.PauseIteration()]}
+            if isinstance(obj, messages.Iterate) and n_it in script:
+                self.inbound.extend(script.pop(n_it) if n_it in script else [])
+
+    topo = oracle.tiny_topology((8, 16), (2, 2))
+    tr = st2.StyleTransfer(st2.HipModel(oracle.he_init_weights(topo, 0, 0.1), topology=topo))
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (32, 40, 3)).astype(np.uint8), rs(2).randint(0, 256, (24, 24, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (32, 40, 3)).astype(np.uint8))
+    socks = Socks()
+    socks.inbound.extend([messages.SetImages(None, init, content, style, True),
+                          messages.SetWeights({'content': {'conv2_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1}, 'deepdream': {}},
+                                              {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}),
+                          messages.SetOptimizer('adam', 10), messages.StartIteration()])
+    wk = worker_mod.Worker({'async_iterate': '0'}, sock_in=socks, sock_out=socks, transfer=tr)
+    wk.run()
+    kinds = [type(m).__name__ for m in socks.sent]
+    assert kinds[0] == 'WorkerReady' and kinds[-1] == 'Shutdown' and kinds.count('Iterate') == 9
+    its = [m for m in socks.sent if isinstance(m, messages.Iterate)]
+    assert [m.i for m in its] == [1, 2, 3, 4, 5, 6, 1, 2, 3]     # SetOptimizer with a new class resets t (worker.py:387-391)
+    assert its[2].image.shape == (32, 40, 3) and its[3].image.shape == (48, 64, 3)       # resampled after iterate 3
+    assert all(np.isfinite(m.trace['loss']) and m.image.dtype == F32 for m in its)
+    assert its[5].trace['loss'] != its[4].trace['loss']        # still iterating after the resample
+    assert 'conv1_1_s_grad' in its[-1].trace and its[-1].trace['fevals'] == 3
+    assert isinstance(tr.optimizer, st2.LBFGSOptimizer)
+
+
+def test_engine_error_paths_are_loud():
+    topo = oracle.tiny_topology((8, 16), (2, 2))
+    params = oracle.he_init_weights(topo, 0, 0.1)
+    eng = st2.Engine(topo)
+    with pytest.raises(st2.StError, match='never loaded'):
+        eng.set_content(np.zeros((8, 8, 3), np.uint8))
+    eng.load_weights(params)
+    with pytest.raises(st2.StError, match='no input image'):
+        eng.opfunc()
+    eng.set_input(np.zeros((16, 16, 3), np.uint8))
+    with pytest.raises(st2.StError, match='content features missing'):
+        eng.opfunc()
+    eng.set_content(np.zeros((8, 8, 3), np.uint8))
+    with pytest.raises(st2.StError, match='different size'):
+        eng.opfunc()
+    eng.set_content(np.zeros((16, 16, 3), np.uint8))
+    with pytest.raises(st2.StError, match='style Gram'):
+        eng.opfunc()
+    eng.set_style(np.zeros((12, 12, 3), np.uint8))
+    with pytest.raises(st2.StError, match='no optimizer'):
+        eng.step()
+    with pytest.raises(ValueError):
+        eng.set_input(np.zeros((4, 4), np.uint8))
+    with pytest.raises(KeyError):
+        st2.StyleTransfer(st2.HipModel(None, engine=eng)).set_weights({'content': {}}, {})
+    eng.close()
