@@ -104,6 +104,20 @@ const char* st_profile_class_name(int cls);
 /* sums since the last call: launches, milliseconds, algorithmic FLOPs and bytes per class */
 int st_profile_read(st_ctx* ctx, long long* launches, double* ms, double* flops, double* bytes);
 
+/* ---- device-resident resampling: optimizer.resample / StyleTransfer.resample_content ------------------------
+ * (optimizers.py:29-40,110-119; worker.py:154-170; utils.py:130-160 = Pillow Image.resize on float planes).
+ * A table describes one axis exactly as Pillow's precompute_coeffs does (host-computed): for output index i the
+ * window starts at lo[i], has n[i] taps, coefficients k[i*kmax .. ] (double, normalised). */
+typedef struct st_resample_table { const int* lo; const int* n; const double* k; int kmax; int out_size; } st_resample_table;
+/* Resamples the optimizer state to (lan_y.out_size x lan_x.out_size): x by Lanczos (or replaced by new_x_nchw when not
+ * NULL), Adam's m by Lanczos, Adam's v by bilinear then max(0, .); L-BFGS: x only (the caller then signals
+ * objective_changed).  bil_* may be NULL for L-BFGS. */
+int st_resample_state(st_ctx* ctx, const st_resample_table* lan_x, const st_resample_table* lan_y,
+                      const st_resample_table* bil_x, const st_resample_table* bil_y, const float* new_x_nchw);
+/* Resamples the preprocessed content image by Lanczos and recomputes the content features. */
+int st_resample_content(st_ctx* ctx, const st_resample_table* lan_x, const st_resample_table* lan_y);
+int st_get_content_nchw(st_ctx* ctx, float* out, int* H, int* W);   /* out may be NULL to query the shape */
+
 /* ---- tile-sharded single image (BASELINE config 5; style_transfer2_amd/tiling.py) ------------------------------------
  * One context = one rank's window (tile + apron) of a gH x gW image.  No reference counterpart: the reference
  * runs one image per worker; its numerics (global Gram normalisation worker.py:114, global RMS norms :254,266,275,

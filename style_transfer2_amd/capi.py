@@ -15,6 +15,10 @@ class StError(RuntimeError):
     """A non-zero status from the C ABI; the message is st_last_error()."""
 
 
+class ResampleTable(ctypes.Structure):
+    _fields_ = [('lo', POINTER(c_int)), ('n', POINTER(c_int)), ('k', POINTER(c_double)), ('kmax', c_int), ('out_size', c_int)]
+
+
 class LayerDesc(ctypes.Structure):
     _fields_ = [('kind', c_int), ('name', c_char_p), ('cin', c_int), ('cout', c_int)]
 
@@ -61,6 +65,9 @@ PROTOTYPES = {
     'st_profile_class_name': (c_char_p, [c_int]),
     'st_profile_read': (c_int, [c_void_p, POINTER(c_longlong), POINTER(c_double), POINTER(c_double),
                                 POINTER(c_double)]),
+    'st_resample_state': (c_int, [c_void_p, POINTER(ResampleTable), POINTER(ResampleTable), POINTER(ResampleTable), POINTER(ResampleTable), c_void_p]),
+    'st_resample_content': (c_int, [c_void_p, POINTER(ResampleTable), POINTER(ResampleTable)]),
+    'st_get_content_nchw': (c_int, [c_void_p, c_void_p, POINTER(c_int), POINTER(c_int)]),
     'st_tile_configure': (c_int, [c_void_p] + [c_int] * 8),
     'st_tile_forward': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int)]),
     'st_tile_losses': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int)]),

@@ -430,6 +430,69 @@ hipError_t launch_image_pass_tile(const ImageTileArgs& a, int* n_partial, hipStr
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------- Pillow-exact plane resampling
+// Pillow's ImagingResample for 32-bit float planes (reference utils.py:130-160 -> Image.resize): separable,
+// horizontal pass then vertical pass, per output coordinate a window [xmin, xmin + ksize) of normalised double
+// coefficients (computed on the host exactly as Pillow's precompute_coeffs), double accumulation in window order,
+// float32 intermediate.  This file is built with -ffp-contract=off: mul and add round separately, as in Pillow.
+__global__ __launch_bounds__(256) void resample_h_k(const float* __restrict__ src, float* __restrict__ dst, size_t rows,
+                                                    int w_in, int w_out, ResampleTable t, int clamp0)
+{
+    const size_t total = rows * w_out;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int xx = (int)(idx % w_out);
+        const size_t row = idx / w_out;
+        const float* p = src + row * w_in + t.lo[xx];
+        const double* k = t.k + (size_t)xx * t.kmax;
+        double ss = 0.0;
+        for (int i = 0; i < t.n[xx]; ++i) ss += (double)p[i] * k[i];
+        float v = (float)ss;
+        if (clamp0) v = v > 0.f ? v : 0.f;
+        dst[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void resample_v_k(const float* __restrict__ src, float* __restrict__ dst, int planes,
+                                                    int h_in, int h_out, int w, ResampleTable t, int clamp0)
+{
+    const size_t total = (size_t)planes * h_out * w;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int x = (int)(idx % w);
+        const int yy = (int)((idx / w) % h_out);
+        const size_t pl = idx / ((size_t)w * h_out);
+        const float* p = src + (pl * h_in + t.lo[yy]) * w + x;
+        const double* k = t.k + (size_t)yy * t.kmax;
+        double ss = 0.0;
+        for (int i = 0; i < t.n[yy]; ++i) ss += (double)p[(size_t)i * w] * k[i];
+        float v = (float)ss;
+        if (clamp0) v = v > 0.f ? v : 0.f;
+        dst[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void clamp0_copy_k(const float* src, float* dst, size_t n, int clamp0)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dst[i] = clamp0 ? (src[i] > 0.f ? src[i] : 0.f) : src[i];
+}
+
+hipError_t launch_resample(const float* src, float* tmp, float* dst, int planes, int h_in, int w_in, int h_out, int w_out,
+                           const ResampleTable& tx, const ResampleTable& ty, int clamp0, hipStream_t s)
+{
+    // Pillow skips a pass whose size does not change
+    const bool need_h = w_in != w_out, need_v = h_in != h_out;
+    const float* cur = src;
+    if (need_h) {
+        float* out = need_v ? tmp : dst;
+        const size_t rows = (size_t)planes * h_in;
+        resample_h_k<<<reduce_grid(rows * w_out, 256, 16384), 256, 0, s>>>(cur, out, rows, w_in, w_out, tx, need_v ? 0 : clamp0);
+        cur = out;
+    }
+    if (need_v) resample_v_k<<<reduce_grid((size_t)planes * h_out * w_out, 256, 16384), 256, 0, s>>>(cur, dst, planes, h_in, h_out, w_out, ty, clamp0);
+    if (!need_h && !need_v) clamp0_copy_k<<<reduce_grid((size_t)planes * h_in * w_in, 1024, 8192), 256, 0, s>>>(src, dst, (size_t)planes * h_in * w_in, clamp0);
+    return hipGetLastError();
+}
+
 // -------------------------------------------------------------------------------- pre / deprocess
 __constant__ float kMean[3] = {123.68f, 116.779f, 103.939f};   // worker.py:34
 

@@ -141,6 +141,12 @@ struct ImageTileArgs {
 };
 hipError_t launch_image_pass_tile(const ImageTileArgs& a, int* n_partial, hipStream_t s);
 
+// Pillow-exact separable resampling of float planes (utils.py:130-160).  Tables live on the device:
+// lo[i] = first source index, n[i] = window length, k[i*kmax + j] = normalised double coefficients.
+struct ResampleTable { const int* lo; const int* n; const double* k; int kmax; };
+hipError_t launch_resample(const float* src, float* tmp, float* dst, int planes, int h_in, int w_in, int h_out, int w_out,
+                           const ResampleTable& tx, const ResampleTable& ty, int clamp0, hipStream_t s);
+
 // pre/deprocess, worker.py:63-71
 hipError_t launch_preprocess_u8(const uint8_t* hwc, float* nchw, int H, int W, hipStream_t s);
 hipError_t launch_preprocess_f32(const float* hwc, float* nchw, int H, int W, hipStream_t s);

@@ -4,9 +4,6 @@ The state (x, m, v / the L-BFGS pairs) lives in HBM inside the engine; these obj
 reference's interface: ``cls(x, opfunc, step_size=)``, ``.step()``, ``.resample(size, new_x)``,
 ``.objective_changed()`` and a ``.step_size`` attribute."""
 
-import numpy as np
-
-from . import resample
 from .engine import OPT_ADAM, OPT_LBFGS
 
 
@@ -37,18 +34,10 @@ class AdamOptimizer(_DeviceOptimizer):
     kind = OPT_ADAM
 
     def resample(self, size, new_x=None):
-        """reference optimizers.py:29-40: x Lanczos (or replaced), m Lanczos, v bilinear clipped at 0"""
-        m, v, items1, items2 = self.engine.adam_get_state()
-        if new_x is not None:
-            x = np.asarray(new_x, np.float32)
-            size = x.shape[2:]
-        else:
-            x = resample.resample_nchw(self.engine.get_input_nchw(), size)
-        m = resample.resample_nchw(m, size)
-        v = np.maximum(0, resample.resample_nchw(v, size, method=resample.BILINEAR))
-        self.engine.set_input_nchw(x)
-        self.engine.adam_set_state(m, v, items1, items2)
-        return x
+        """reference optimizers.py:29-40: x Lanczos (or replaced), m Lanczos, v bilinear clipped at 0 -- all on the
+        device with Pillow's own coefficient tables (resample.pillow_coeffs), bit-exact with the reference's Pillow."""
+        self.engine.resample_state(size, new_x)
+        return None
 
 
 class LBFGSOptimizer(_DeviceOptimizer):
@@ -57,10 +46,6 @@ class LBFGSOptimizer(_DeviceOptimizer):
 
     def resample(self, size, new_x=None):
         """reference optimizers.py:110-119"""
-        if new_x is not None:
-            x = np.asarray(new_x, np.float32)
-        else:
-            x = resample.resample_nchw(self.engine.get_input_nchw(), size)
-        self.engine.set_input_nchw(x)
+        self.engine.resample_state(size, new_x)
         self.objective_changed()
-        return x
+        return None

@@ -204,6 +204,50 @@ class Engine:
         v = np.ascontiguousarray(v, F32)
         check(self.lib.st_adam_set_state(self._ctx, _ptr(m), _ptr(v), int(items1), int(items2)))
 
+    # -- device-resident resampling (Pillow-exact) -------------------------------------------------------
+    @staticmethod
+    def _table(in_size, out_size, method):
+        from . import resample
+        lo, n, k = resample.pillow_coeffs(in_size, out_size, method)
+        t = capi.ResampleTable()
+        t._keep = (np.ascontiguousarray(lo), np.ascontiguousarray(n), np.ascontiguousarray(k))
+        t.lo = t._keep[0].ctypes.data_as(ctypes.POINTER(c_int))
+        t.n = t._keep[1].ctypes.data_as(ctypes.POINTER(c_int))
+        t.k = t._keep[2].ctypes.data_as(ctypes.POINTER(c_double))
+        t.kmax, t.out_size = k.shape[1], out_size
+        return t
+
+    def resample_state(self, size, new_x=None):
+        """optimizer.resample (optimizers.py:29-40,110-119) on the device: x (Lanczos, or replaced by new_x),
+        Adam m (Lanczos), Adam v (bilinear, clipped at 0)."""
+        from . import resample
+        h, w = self.input_shape()
+        if new_x is not None:
+            new_x = np.ascontiguousarray(new_x, F32)
+            size = new_x.shape[2:]
+        size = tuple(int(v) for v in size)
+        lx, ly = self._table(w, size[1], resample.LANCZOS), self._table(h, size[0], resample.LANCZOS)
+        bx, by = self._table(w, size[1], resample.BILINEAR), self._table(h, size[0], resample.BILINEAR)
+        check(self.lib.st_resample_state(self._ctx, byref(lx), byref(ly), byref(bx), byref(by), _ptr(new_x)))
+
+    def resample_content(self, size):
+        from . import resample
+        h, w = self.content_shape()
+        size = tuple(int(v) for v in size)
+        lx, ly = self._table(w, size[1], resample.LANCZOS), self._table(h, size[0], resample.LANCZOS)
+        check(self.lib.st_resample_content(self._ctx, byref(lx), byref(ly)))
+
+    def content_shape(self):
+        h, w = c_int(), c_int()
+        check(self.lib.st_get_content_nchw(self._ctx, None, byref(h), byref(w)))
+        return h.value, w.value
+
+    def get_content_nchw(self):
+        h, w = self.content_shape()
+        out = np.empty((1, 3, h, w), F32)
+        check(self.lib.st_get_content_nchw(self._ctx, _ptr(out), None, None))
+        return out
+
     def step(self, want_image=True, want_trace=True):
         """One iteration.  With both flags False nothing is read back and the call is asynchronous."""
         h, w = self.input_shape()

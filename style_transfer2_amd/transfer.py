@@ -3,7 +3,7 @@ of the same name (worker.py:117-315) method for method, with every tensor reside
 
 What differs from the reference, by design:
   * ``input`` / ``features`` / ``grams`` live in HBM inside the engine; ``input`` is a property
-    that downloads a copy, ``content`` (needed by ``resample_content``) is kept on the host;
+    that downloads a copy, and so is ``content``; resampling (SetImages.RESAMPLE) runs on the device too;
   * ``opfunc`` and ``step`` run as device launches (forward, fused loss passes, ranged backward,
     fused TV/p-norm/Adam pass); the per-iteration trace is reduced on the device and read back
     with the iterate;
@@ -17,7 +17,6 @@ import time
 
 import numpy as np
 
-from . import resample
 from .device_optimizers import AdamOptimizer, LBFGSOptimizer
 
 F32 = np.float32
@@ -64,7 +63,7 @@ class StyleTransfer:
         self.is_starting = False
         self.t = 0
         self.input_shape = None
-        self.content = None
+        self.content_shape = None
         self.has_grams = False
         # reference worker.py:129-133: all-ones weights on every blob until SetWeights arrives
         self.rows = list(self.model.layers())
@@ -82,13 +81,17 @@ class StyleTransfer:
         return self.engine.get_input_nchw() if self.input_shape is not None else None
 
     @property
+    def content(self):
+        return self.engine.get_content_nchw() if self.content_shape is not None else None
+
+    @property
     def weights(self):
         return self.cells
 
     # ------------------------------------------------------------------ reference worker.py:140-152
     def check_consistency(self):
-        return (self.input_shape is not None and self.content is not None and self.has_grams
-                and self.input_shape == self.content.shape)
+        return (self.input_shape is not None and self.content_shape is not None and self.has_grams
+                and self.input_shape == self.content_shape)
 
     def objective_changed(self):
         if self.optimizer is not None:
@@ -111,11 +114,11 @@ class StyleTransfer:
 
     def resample_content(self, size):
         size = tuple(size)
-        if self.content is not None:
-            self.content = resample.resample_nchw(self.content, size)
+        if self.content_shape is not None:
+            self.engine.resample_content(size)                      # Lanczos on the device, then the features
         else:
-            self.content = np.zeros((1, 3) + size, F32)
-        self.engine.set_content_nchw(self.content)
+            self.engine.set_content_nchw(np.zeros((1, 3) + size, F32))
+        self.content_shape = (1, 3) + size
         self._start()
         self.objective_changed()
 
@@ -154,7 +157,7 @@ class StyleTransfer:
             self._start()
 
     def set_content(self, image):
-        self.content = self.model.preprocess(image)
+        self.content_shape = (1, 3) + tuple(np.shape(image)[:2])
         self.engine.set_content(image)
         self._start()
         self.objective_changed()
