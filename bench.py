@@ -31,6 +31,7 @@ from style_transfer2_amd import weights as st2_weights  # noqa: E402
 from style_transfer2_amd import distributed as st2_dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (8 passes x 4 cyc)
 WEIGHTS = {'content': {'conv4_2': 0.08},
            'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
            'deepdream': {}}
@@ -45,9 +46,9 @@ def images(size):
             rs(3).randint(0, 256, shape).astype(np.uint8))
 
 
-def make_job(size, optimizer, device):
+def make_job(size, optimizer, device, precision='fp32'):
     content, style, init = images(size)
-    model = st2.HipModel(st2_weights.he_normal(st2.VGG19_TOPOLOGY, seed=0), device=device)
+    model = st2.HipModel(st2_weights.he_normal(st2.VGG19_TOPOLOGY, seed=0), device=device, precision=precision)
     job = st2.StyleTransfer(model)
     job.set_input(init)
     job.set_content(content)
@@ -91,6 +92,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--optimizer', default='adam', choices=['adam', 'lbfgs'])
+    ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
+                    help="bf16 = BASELINE configs[3] 'bf16 features / fp32 Gram'; the headline metric is fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-size', type=int, default=0, help='image size of the CPU sample (default: --size)')
     args = ap.parse_args()
@@ -98,7 +101,7 @@ def main():
     group = st2_dist.Group()
     rank, local_rank, world = group.rank, group.local_rank, group.world
 
-    job = make_job(args.size, args.optimizer, local_rank)
+    job = make_job(args.size, args.optimizer, local_rank, args.precision)
     elapsed = st2_dist.timed_region(group, job.step_async, args.steps, args.warmup, job.engine.sync)
 
     # per-kernel-class HIP-event timing of the same steps (separate leg so `value` carries no event overhead)
@@ -122,7 +125,8 @@ def main():
         # (FETCH_SIZE doubled for wide loads, WRITE_SIZE exact: tools/pmc_traffic.py); null when absent.
         traffic = None
         tpath = os.path.join(HERE, 'profiles', 'pmc_traffic.json')
-        if args.size == 1024 and os.path.exists(tpath):
+        peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
+        if args.size == 1024 and args.precision == 'fp32' and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath))['_conv3x3_mfma_f32_all']['hbm_bytes_per_launch']
             except (KeyError, ValueError):
@@ -131,15 +135,15 @@ def main():
             'metric': 'style-transfer iters/sec @%dpx VGG19' % args.size,
             'value': its, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16 conv operands, f32 accumulate/Gram/optimizer', 'data': 'synthetic',
             'images_per_hour': its * 3600.0 / ITERS_PER_IMAGE,
             'config': {'workload': 'configs[1]: %dx%d single image per GPU, VGG19 to conv5_1, content conv4_2 + 5 style '
-                                   'layers, %s fp32, %d iterations per image' % (args.size, args.size, args.optimizer,
-                                                                                  ITERS_PER_IMAGE),
+                                   'layers, %s %s, %d iterations per image' % (args.size, args.size, args.optimizer,
+                                                                                args.precision, ITERS_PER_IMAGE),
                        'jobs': world, 'parallelism': 'independent jobs, 1 per GPU, no collective'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_mfma_f32 (forward + dgrad launches)',
-                         'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_mfma_%s (forward + dgrad launches)' % ('f32' if args.precision == 'fp32' else 'bf16'),
+                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': traffic,
                          'flops_per_launch': flops / launches if launches else 0.0,
                          'avg_launch_ms': ms / launches if launches else 0.0,
                          'share_of_step': ms / total_ms if total_ms else 0.0},

@@ -45,6 +45,9 @@ int st_create(st_ctx** out, int device_id, const st_layer_desc* layers, int n_la
 int st_destroy(st_ctx* ctx);
 /* weights of one conv layer, Caffe layout (Cout, Cin, 3, 3) + bias (Cout)  [caffe.Net(weights=)] */
 int st_load_conv_weights(st_ctx* ctx, const char* layer, const float* w, const float* bias);
+/* 0 (default): fp32 throughout.  1: bf16 feature path (BASELINE config 3) -- conv operands (activations, weights,
+ * backward diffs) in bf16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate; blobs, Gram, losses, optimizer stay fp32. */
+int st_set_precision(st_ctx* ctx, int bf16_features);
 /* CaffeModel.layers (worker.py:73-75): blob names in network order, "data" first */
 int st_num_blobs(st_ctx* ctx);
 const char* st_blob_name(st_ctx* ctx, int index);

@@ -119,6 +119,14 @@ def conv3x3_backward_data(dy, w):
     return np.ascontiguousarray(dxp[:, 1:-1, 1:-1])
 
 
+def bf16_round(a):
+    """fp32 -> bf16 -> fp32 with round-to-nearest-even (no NaN/inf handling: blobs are finite).  Used to
+    emulate the bf16 feature path (BASELINE config 3): conv OPERANDS rounded, products/accumulation fp32."""
+    u = np.ascontiguousarray(a, F32).view(np.uint32)
+    r = (u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))) & np.uint32(0xFFFF0000)
+    return r.view(F32)
+
+
 def _windows(x, fill):
     c, h, w = x.shape
     ho, wo = pooled_size(h), pooled_size(w)
@@ -155,13 +163,19 @@ class NetOracle:
 
     mean = np.array((123.68, 116.779, 103.939), F32).reshape(3, 1, 1)  # worker.py:34
 
-    def __init__(self, topology=VGG19_TOPOLOGY, params=None, seed=0, full_forward=True):
+    def __init__(self, topology=VGG19_TOPOLOGY, params=None, seed=0, full_forward=True, operands='fp32'):
         self.topology = tuple(topology)
         self.params = params if params is not None else he_init_weights(self.topology, seed)
         self.blob_names = ['data'] + [layer[1] for layer in self.topology]
         # Caffe always runs the whole net (worker.py:86).  full_forward=False stops after the
         # deepest requested blob: identical results, used only to time a leaner CPU baseline.
         self.full_forward = full_forward
+        # operands='bf16': emulate the bf16 feature path -- a conv whose reduction depth (input channels forward,
+        # output channels backward) is a multiple of 8 sees its activation/diff and weight operands rounded to
+        # bf16; everything else (bias, ReLU, pooling, accumulation, the blobs themselves) stays fp32.
+        assert operands in ('fp32', 'bf16')
+        self.operands = operands
+        self._w16 = {}
         self._blobs = {}
         self._slots = {}
 
@@ -204,12 +218,20 @@ class NetOracle:
         for layer in self.topology[:last]:
             if layer[0] == 'conv':
                 w, b = self.params[layer[1]]
-                x = conv3x3_forward(x, w, b)
+                if self.operands == 'bf16' and layer[2] % 8 == 0:
+                    x = conv3x3_forward(bf16_round(x), self._weights16(layer[1]), b)
+                else:
+                    x = conv3x3_forward(x, w, b)
                 np.maximum(x, 0, out=x)            # in-place ReLU: the blob holds post-ReLU data
             else:
                 x, self._slots[layer[1]] = maxpool_forward(x)
             self._blobs[layer[1]] = x
         return OrderedDict((n, self._blobs[n][None]) for n in wanted)
+
+    def _weights16(self, name):
+        if name not in self._w16:
+            self._w16[name] = bf16_round(self.params[name][0])
+        return self._w16[name]
 
     def adopt_forward_state(self, blobs):
         """Replace the saved forward state (ReLU masks, pool arg-max) by that of another implementation's
@@ -253,7 +275,10 @@ class NetOracle:
                 inj = np.asarray(diffs[name], F32)[0]
                 g = inj.copy() if g is None else g + inj
             if layer[0] == 'conv':
-                g = conv3x3_backward_data(g, self.params[name][0])
+                if self.operands == 'bf16' and layer[3] % 8 == 0 and layer[2] > 4:
+                    g = conv3x3_backward_data(bf16_round(g), self._weights16(name))
+                else:
+                    g = conv3x3_backward_data(g, self.params[name][0])
             else:
                 below = self.blob_names[i - 1]
                 g = maxpool_backward(g, self._slots[name], self._blobs[below].shape)

@@ -19,6 +19,7 @@ ARCH = 'gfx950'
 # (source, extra flags)
 SOURCES = (
     ('conv3x3_mfma.hip', ()),
+    ('conv3x3_mfma_bf16.hip', ()),
     ('gram.hip', ()),
     ('passes.hip', ('-ffp-contract=off',)),      # NumPy-like one-rounding-per-operation arithmetic
     ('engine.cpp', ('-x', 'hip')),

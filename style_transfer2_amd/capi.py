@@ -33,6 +33,7 @@ PROTOTYPES = {
     'st_create': (c_int, [POINTER(c_void_p), c_int, POINTER(LayerDesc), c_int]),
     'st_destroy': (c_int, [c_void_p]),
     'st_load_conv_weights': (c_int, [c_void_p, c_char_p, c_void_p, c_void_p]),
+    'st_set_precision': (c_int, [c_void_p, c_int]),
     'st_num_blobs': (c_int, [c_void_p]),
     'st_blob_name': (c_char_p, [c_void_p, c_int]),
     'st_blob_shape': (c_int, [c_void_p, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)]),

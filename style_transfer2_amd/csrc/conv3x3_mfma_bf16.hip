@@ -1,0 +1,326 @@
+// conv3x3 (pad 1, stride 1) on the bf16 matrix cores: v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+// BASELINE config 3 ("bf16 features / fp32 Gram"): the operands of every conv (activations, weights, and the
+// diffs of the backward pass) are bf16; accumulation, bias/ReLU, ReLU-mask, injected diffs and everything outside
+// the convs (Gram, losses, TV, optimizer) stay fp32.  Each launch reads a bf16 channel-blocked copy of its input
+//      act16 [C/8][H][W][8]            (8 consecutive channels of one pixel = one 16-byte quad)
+// and writes the fp32 NCHW blob the rest of the engine uses plus, optionally, the bf16 copy for the next conv.
+//
+// Same pipeline as conv3x3_mfma.hip (LDS-DMA with buffer descriptors, double-buffered LDS, one barrier per chunk,
+// pinned issue order); what changes is the operand shape: K = 16 channels per MFMA, lane (l&31, l>>5) holds 8
+// consecutive channels (block l>>5 of the chunk) of output row / pixel l&31, so every fragment is ONE ds_read_b128:
+//      w_s  [9 taps][2 blocks][BM][8 bf16]      in_s [2 blocks][ROWS+2][34 px][8 bf16]
+// A chunk is 16 input channels x 9 taps = 9 k-steps; three operand register sets rotate (9 is odd).
+#include "st2_kernels.h"
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace st2 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int NT = 256;
+constexpr int PXW = 34;                       // staged pixels per row: x0-1 .. x0+32
+constexpr unsigned kOOB16 = 0xffffffffu;
+
+static unsigned short f2bf(float f)           // round-to-nearest-even, host side
+{
+    unsigned u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+size_t conv16_pack_elems(int K, int M) { return (size_t)((K + 15) / 16) * 9 * 2 * conv_mpad(M) * 8; }
+
+// packed[ch][tap][h][m][j] = w[m][ch*16 + h*8 + j][tap]
+void pack_conv_weights16_fwd(const float* w, int Cout, int Cin, unsigned short* dst)
+{
+    const int mpad = conv_mpad(Cout);
+    memset(dst, 0, conv16_pack_elems(Cin, Cout) * sizeof(unsigned short));
+    for (int m = 0; m < Cout; ++m)
+        for (int k = 0; k < Cin; ++k)
+            for (int tap = 0; tap < 9; ++tap)
+                dst[((((size_t)(k / 16) * 9 + tap) * 2 + (k % 16) / 8) * mpad + m) * 8 + (k % 8)] = f2bf(w[((size_t)m * Cin + k) * 9 + tap]);
+}
+
+// data gradient: m = Cin, k = Cout, taps flipped
+void pack_conv_weights16_dgrad(const float* w, int Cout, int Cin, unsigned short* dst)
+{
+    const int mpad = conv_mpad(Cin);
+    memset(dst, 0, conv16_pack_elems(Cout, Cin) * sizeof(unsigned short));
+    for (int k = 0; k < Cout; ++k)
+        for (int m = 0; m < Cin; ++m)
+            for (int tap = 0; tap < 9; ++tap)
+                dst[((((size_t)(k / 16) * 9 + tap) * 2 + (k % 16) / 8) * mpad + m) * 8 + (k % 8)] = f2bf(w[((size_t)k * Cin + m) * 9 + (8 - tap)]);
+}
+
+struct Conv16KArgs {
+    const unsigned short* in16; const unsigned short* wpack; const float* bias; float* out; unsigned short* out16;
+    const float* mask_src; const float* inject;
+    int K, M, MPad, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
+    unsigned in_bytes, w_bytes;
+};
+
+template <int BM, int ROWS, int WAVES_M, int WAVES_N>
+__device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
+{
+    constexpr int TM = BM / WAVES_M / 32;
+    constexpr int TN = ROWS / WAVES_N;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
+    constexpr int IN_ROWS = ROWS + 2;
+    constexpr int W_QUADS = 9 * 2 * BM;                          // 16-byte units of the weight slab
+    constexpr int I_QUADS = 2 * IN_ROWS * PXW;
+    constexpr int W_INSTR = W_QUADS / 64;
+    constexpr int I_INSTR = (I_QUADS + 63) / 64;
+    constexpr int I_QUADS_PAD = I_INSTR * 64;
+    constexpr int BUF_Q = W_QUADS + I_QUADS_PAD;                 // quads per LDS buffer
+    constexpr int W_PER_WAVE = (W_INSTR + 3) / 4;
+    constexpr int I_PER_WAVE = (I_INSTR + 3) / 4;
+    constexpr int NPIECE = W_PER_WAVE + I_PER_WAVE;
+    constexpr int NSTEP = 9;
+    constexpr int PPS = (NPIECE + NSTEP - 2) / (NSTEP - 1);
+    static_assert(W_QUADS % 64 == 0, "weight slab is a whole number of 1-KiB DMA pieces");
+
+    __shared__ __attribute__((aligned(16))) uint4 smem[2 * BUF_Q];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int mt = logical % a.n_mtiles;
+    const int pt = logical / a.n_mtiles;
+    const int tx = pt % a.tiles_x, ty = pt / a.tiles_x;
+    const int m0 = mt * BM, y0 = ty * ROWS, x0 = tx * 32;
+    const unsigned plane = (unsigned)a.H * a.W;
+
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in16, 0, a.in_bytes, 0x00020000);
+
+    unsigned ioff[I_PER_WAVE];
+#pragma unroll
+    for (int t = 0; t < I_PER_WAVE; ++t) {
+        const int f = (wave + 4 * t) * 64 + lane;                // quad index in the activation image
+        const int h = f / (IN_ROWS * PXW);
+        const int rem = f - h * (IN_ROWS * PXW);
+        const int rr = rem / PXW, col = rem - rr * PXW;
+        const int gy = y0 - 1 + rr, gx = x0 - 1 + col;
+        const bool ok = f < I_QUADS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        ioff[t] = ok ? ((unsigned)h * plane + (unsigned)gy * a.W + gx) * 16u : kOOB16;
+    }
+    unsigned woff[W_PER_WAVE];
+#pragma unroll
+    for (int t = 0; t < W_PER_WAVE; ++t) {
+        const int f = (wave + 4 * t) * 64 + lane;                // quad index in the weight slab: [tap][h][m]
+        const int th = f / BM, m = f - th * BM;
+        woff[t] = ((unsigned)th * a.MPad + m) * 16u;
+    }
+
+    auto dma_piece = [&](int t, int ch, int buf) {
+        uint4* dst = smem + buf * BUF_Q;
+        if (t < W_PER_WAVE) {
+            const int i = wave + 4 * t;
+            if (W_INSTR % 4 == 0 || i < W_INSTR) {
+                const unsigned coff = ((unsigned)ch * 18u * a.MPad + m0) * 16u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(dst + i * 64), 16, woff[t] + coff, 0, 0, 0);
+            }
+        } else {
+            const int u = t - W_PER_WAVE;
+            const int j = wave + 4 * u;
+            if (I_INSTR % 4 == 0 || j < I_INSTR) {
+                const unsigned coff = (unsigned)ch * 2u * plane * 16u;
+                const unsigned vo = ioff[u] == kOOB16 ? kOOB16 : ioff[u] + coff;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(dst + W_QUADS + j * 64), 16, vo, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int a_off = khalf * BM + wave_m * (TM * 32) + l31;                                   // + tap*2*BM + i*32
+    const int b_off = W_QUADS + khalf * IN_ROWS * PXW + (wave_n * TN) * PXW + l31;             // + (j+dy)*PXW + dx
+
+    bf16x8 av[3][TM], bv[3][TN];
+    auto fetch = [&](const uint4* base, int tap, bf16x8 (&ao)[TM], bf16x8 (&bo)[TN]) {
+        const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ao[i] = __builtin_bit_cast(bf16x8, base[a_off + tap * 2 * BM + i * 32]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bo[j] = __builtin_bit_cast(bf16x8, base[b_off + (j + dy) * PXW + dx]);
+    };
+
+#pragma unroll
+    for (int t = 0; t < NPIECE; ++t) dma_piece(t, 0, 0);
+    __syncthreads();
+    fetch(smem, 0, av[0], bv[0]);
+    for (int ch = 0; ch < a.nch; ++ch) {
+        const int cur = ch & 1;
+        const bool more = ch + 1 < a.nch;
+        const uint4* base = smem + cur * BUF_Q;
+        const uint4* next = smem + (cur ^ 1) * BUF_Q;
+#pragma unroll
+        for (int s2 = 0; s2 < NSTEP; ++s2) {
+#pragma unroll
+            for (int ij = 0; ij < TM * TN; ++ij) {
+                const int i = ij / TN, j = ij % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2 % 3][i], bv[s2 % 3][j], acc[i][j], 0, 0, 0);
+                if (ij == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s2 + 1 < NSTEP) {
+                        fetch(base, s2 + 1, av[(s2 + 1) % 3], bv[(s2 + 1) % 3]);
+                        if (more) {
+#pragma unroll
+                            for (int pp = 0; pp < PPS; ++pp)
+                                if (s2 * PPS + pp < NPIECE) dma_piece(s2 * PPS + pp, ch + 1, cur ^ 1);
+                        }
+                    } else if (more) {
+                        __syncthreads();
+                        fetch(next, 0, av[0], bv[0]);            // 9 % 3 == 0: the next chunk starts on set 0 again
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: fp32 blob (same as the fp32 kernel) + bf16 channel-blocked copy
+    const int gx = x0 + l31;
+    const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int gy = y0 + wave_n * TN + j;
+        if (gy >= a.H || gx >= a.W) continue;
+        const unsigned pix = (unsigned)gy * a.W + gx;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h;
+                float v[8];
+                unsigned off[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = mbase + (e & 3) + 8 * (e >> 2);
+                    off[e] = (unsigned)(m < a.M ? m : a.M - 1) * plane + pix;
+                    v[e] = acc[i][j][8 * h + e];
+                }
+                if (has_bias) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += a.bias[mbase + (e & 3) + 8 * (e >> 2)];
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                }
+                if (has_mask) {
+                    float mk[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) mk[e] = a.mask_src[off[e]];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.0f ? v[e] : 0.0f;
+                }
+                if (has_inj) {
+                    float ij[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ij[e] = a.inject[off[e]];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += ij[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[e];
+                if (a.out16) {
+                    // rows mbase..+3 and mbase+8..+11: two groups of 4 consecutive channels -> two 8-byte stores
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int mg = mbase + 8 * g;
+                        if (mg < a.M) {             // M is a multiple of 8 on this path (checked at launch)
+                            bf16x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[4 * g + e];
+                            *reinterpret_cast<bf16x4*>(a.out16 + ((size_t)(mg >> 3) * plane + pix) * 8 + (mg & 7)) = pk;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+#define ST2_CONV16_KERNEL(NAME, BM, ROWS, WM, WN, WPE) \
+    __global__ __launch_bounds__(NT, WPE) void NAME(const Conv16KArgs a) { conv16_body<BM, ROWS, WM, WN>(a); }
+ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x256, 64, 8, 1, 4, 2)
+ST2_CONV16_KERNEL(conv3x3_mfma_bf16_128x128, 128, 4, 2, 2, 1)
+ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x128, 64, 4, 1, 4, 3)
+
+hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
+{
+    if (p.MPad % kCoutQuantum != 0 || p.MPad < p.M) return hipErrorInvalidValue;
+    if (p.out16 && p.M % 8 != 0) return hipErrorInvalidValue;
+    const char* env = getenv("ST2_CONV16_CFG");             // forces one tile configuration (tests of every configuration)
+    const int forced = env && *env ? atoi(env) : -1;
+    const long long tx = (p.W + 31) / 32;
+    int cfg;                                               // 0: 64x256px, 1: 128x128px, 2: 64x128px
+    if (forced >= 0) cfg = forced;
+    else cfg = (tx * ((p.H + 7) / 8) * (p.MPad / 64) >= 512) ? 0 : 2;
+    if (cfg == 1 && p.MPad % 128 != 0) cfg = 0;
+    const int BM = cfg == 1 ? 128 : 64, ROWS = cfg == 0 ? 8 : 4;
+    Conv16KArgs k{};
+    k.in16 = p.in16; k.wpack = p.wpack16; k.bias = p.bias; k.out = p.out; k.out16 = p.out16;
+    k.mask_src = p.mask_src; k.inject = p.inject;
+    k.K = p.K; k.M = p.M; k.MPad = p.MPad; k.H = p.H; k.W = p.W;
+    k.nch = (p.K + 15) / 16;
+    k.tiles_x = (int)tx; k.tiles_y = (p.H + ROWS - 1) / ROWS; k.n_mtiles = p.MPad / BM; k.relu = p.relu;
+    const unsigned long long in_bytes = 16ull * ((p.K + 7) / 8) * p.H * p.W, w_bytes = 2ull * conv16_pack_elems(p.K, p.M);
+    const unsigned long long out_bytes = 4ull * p.M * p.H * p.W;
+    if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull || out_bytes >= 0xfffffff0ull) return hipErrorInvalidValue;
+    k.in_bytes = (unsigned)in_bytes; k.w_bytes = (unsigned)w_bytes;
+    const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (cfg == 0) conv3x3_mfma_bf16_64x256<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    else if (cfg == 1) conv3x3_mfma_bf16_128x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    else conv3x3_mfma_bf16_64x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    return hipGetLastError();
+}
+
+// fp32 [C][HW] -> bf16 channel-blocked [C/8][HW][8]; channels beyond C are written as zero
+__global__ __launch_bounds__(256) void pack_act16_k(const float* __restrict__ src, unsigned short* __restrict__ dst, int C, size_t hw)
+{
+    const size_t total = (size_t)((C + 7) / 8) * hw;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t p = idx % hw, cb = idx / hw;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = (int)cb * 8 + j;
+            v[j] = (__bf16)(c < C ? src[(size_t)c * hw + p] : 0.0f);
+        }
+        *reinterpret_cast<bf16x8*>(dst + idx * 8) = v;
+    }
+}
+
+hipError_t launch_pack_act16(const float* src, unsigned short* dst, int C, size_t hw, hipStream_t s)
+{
+    const size_t total = (size_t)((C + 7) / 8) * hw;
+    size_t grid = (total + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    pack_act16_k<<<(unsigned)grid, 256, 0, s>>>(src, dst, C, hw);
+    return hipGetLastError();
+}
+
+}  // namespace st2

@@ -56,6 +56,7 @@ struct Layer {
     std::string name;
     int cin = 0, cout = 0;
     float *w_fwd = nullptr, *w_bwd = nullptr, *w_raw = nullptr, *bias = nullptr;
+    unsigned short *w16_fwd = nullptr, *w16_bwd = nullptr;       // bf16 packs (bf16 feature path)
     bool loaded = false;
 };
 
@@ -63,6 +64,7 @@ struct ActSet {                    // activations of one forward geometry
     int H = 0, W = 0;
     std::vector<int> C, h, w;
     std::vector<float*> data;      // data[0] is borrowed (the image itself)
+    std::vector<unsigned short*> data16;   // bf16 channel-blocked copies of the blobs that feed a bf16 conv
     int valid_to = -1;
 };
 
@@ -81,6 +83,8 @@ static bool nonzero(float w) { return fabsf(w) > 1e-15f; }   // NaN compares fal
 struct st_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool bf16 = false;                             // conv operands in bf16 (BASELINE config 3)
+    unsigned short *diff16A = nullptr, *diff16B = nullptr;
     std::vector<Layer> topo;
     std::vector<std::string> blob_names;
     int nb = 0;                                    // number of blobs (= layers + 1)
@@ -170,6 +174,22 @@ static void dfree(float*& p)
     p = nullptr;
 }
 
+static int dmalloc16(unsigned short** p, size_t n)
+{
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(n, 8) * sizeof(unsigned short));
+    if (e != hipSuccess) return fail(ST_ERR_HIP, "hipMalloc(%zu bf16): %s", n, hipGetErrorString(e));
+    *p = (unsigned short*)q;
+    return ST_OK;
+}
+static void dfree16(unsigned short*& p)
+{
+    if (p && hipFree(p) != hipSuccess) (void)hipGetLastError();
+    p = nullptr;
+}
+static size_t act16_elems(int C, size_t hw) { return (size_t)((C + 7) / 8) * hw * 8; }
+static bool conv16_ok(const st_ctx* c, int K) ;
+
 struct ProfScope {
     st_ctx* c; int idx = -1;
     ProfScope(st_ctx* ctx, int cls, double flops, double bytes) : c(ctx)
@@ -194,6 +214,8 @@ struct ProfScope {
     }
 };
 
+static bool conv16_ok(const st_ctx* c, int K) { (void)c; return K >= 8 && K % 8 == 0; }
+
 static void shapes_for(const st_ctx* c, int H, int W, std::vector<int>& C, std::vector<int>& h, std::vector<int>& w)
 {
     C.assign(c->nb, 0); h.assign(c->nb, 0); w.assign(c->nb, 0);
@@ -208,7 +230,9 @@ static void shapes_for(const st_ctx* c, int H, int W, std::vector<int>& C, std::
 static void act_free(ActSet& a)
 {
     for (size_t i = 1; i < a.data.size(); ++i) dfree(a.data[i]);
+    for (size_t i = 0; i < a.data16.size(); ++i) dfree16(a.data16[i]);
     a.data.clear();
+    a.data16.clear();
     a.H = a.W = 0;
     a.valid_to = -1;
 }
@@ -219,6 +243,7 @@ static int act_ensure(st_ctx* c, ActSet& a, int H, int W)
     act_free(a);
     shapes_for(c, H, W, a.C, a.h, a.w);
     a.data.assign(c->nb, nullptr);
+    a.data16.assign(c->nb, nullptr);
     for (int i = 1; i < c->nb; ++i) ST_TRY(dmalloc(&a.data[i], (size_t)a.C[i] * a.h[i] * a.w[i]));
     a.H = H; a.W = W;
     return ST_OK;
@@ -231,16 +256,35 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
         const Layer& L = c->topo[i - 1];
         if (L.is_conv) {
             if (!L.loaded) return fail(ST_ERR_STATE, "weights of %s were never loaded", L.name.c_str());
-            ConvProblem p{};
-            p.in = a.data[i - 1]; p.wpack = L.w_fwd; p.bias = L.bias; p.out = a.data[i];
-            p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
             const double px = (double)a.h[i] * a.w[i];
-            ProfScope ps(c, P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
-            HIP_TRY(launch_conv3x3(p, c->stream));
+            // does the layer that consumes blob i run on the bf16 matrix cores?
+            const bool next16 = c->bf16 && i < last && c->topo[i].is_conv && conv16_ok(c, L.cout);
+            if (next16 && !a.data16[i]) ST_TRY(dmalloc16(&a.data16[i], act16_elems(a.C[i], (size_t)a.h[i] * a.w[i])));
+            if (c->bf16 && conv16_ok(c, L.cin) && a.data16[i - 1]) {
+                Conv16Problem p{};
+                p.in16 = a.data16[i - 1]; p.wpack16 = L.w16_fwd; p.bias = L.bias; p.out = a.data[i];
+                p.out16 = next16 ? a.data16[i] : nullptr;
+                p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
+                ProfScope ps(c, P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, px * (2.0 * L.cin + 4.0 * L.cout));
+                HIP_TRY(launch_conv3x3_bf16(p, c->stream));
+            } else {
+                ConvProblem p{};
+                p.in = a.data[i - 1]; p.wpack = L.w_fwd; p.bias = L.bias; p.out = a.data[i];
+                p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
+                { ProfScope ps(c, P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
+                  HIP_TRY(launch_conv3x3(p, c->stream)); }
+                if (next16) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
+            }
         } else {
             const double n_in = (double)a.C[i - 1] * a.h[i - 1] * a.w[i - 1];
-            ProfScope ps(c, P_POOL_FWD, 0, 4.0 * n_in * 1.25);
-            HIP_TRY(launch_maxpool_fwd(a.data[i - 1], a.data[i], a.C[i - 1], a.h[i - 1], a.w[i - 1], c->stream));
+            { ProfScope ps(c, P_POOL_FWD, 0, 4.0 * n_in * 1.25);
+              HIP_TRY(launch_maxpool_fwd(a.data[i - 1], a.data[i], a.C[i - 1], a.h[i - 1], a.w[i - 1], c->stream)); }
+            if (c->bf16 && i < last && c->topo[i].is_conv && conv16_ok(c, a.C[i])) {
+                const size_t hw = (size_t)a.h[i] * a.w[i];
+                if (!a.data16[i]) ST_TRY(dmalloc16(&a.data16[i], act16_elems(a.C[i], hw)));
+                ProfScope ps(c, P_MISC, 0, hw * 6.0 * a.C[i]);
+                HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], hw, c->stream));
+            }
         }
     }
     a.valid_to = last;
@@ -285,10 +329,16 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
 {
     const ActSet& a = c->act;
     const float* cur = top_diff;
+    const unsigned short* cur16 = nullptr;             // bf16 copy of `cur`, when a producer already made it
+    if (c->bf16 && !c->diff16A) {
+        const size_t cap = c->max_blob + 8 * (size_t)a.h[0] * a.w[0];
+        ST_TRY(dmalloc16(&c->diff16A, cap)); ST_TRY(dmalloc16(&c->diff16B, cap));
+    }
     for (int i = top; i >= 1; --i) {
         const Layer& L = c->topo[i - 1];
         const int below = i - 1;
         float* dst = (cur == c->diffA) ? c->diffB : c->diffA;
+        unsigned short* dst16 = (dst == c->diffA) ? c->diff16A : c->diff16B;
         const bool below_is_conv = below >= 1 && c->topo[below - 1].is_conv;
         const float* mask_src = below_is_conv ? a.data[below] : nullptr;
         const float* inject = inj[below];
@@ -297,7 +347,25 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
             ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
             if (!mask_src && conv_dgrad_smallM_ok(L.cout, L.cin)) {
                 HIP_TRY(launch_conv3x3_dgrad_smallM(cur, L.w_raw, dst, inject, L.cout, L.cin, a.h[i], a.w[i], c->stream));
+                cur16 = nullptr;
+            } else if (c->bf16 && conv16_ok(c, L.cout)) {
+                const size_t hw = (size_t)a.h[i] * a.w[i];
+                if (!cur16) {                                      // top diff / pool-backward output: make the bf16 copy
+                    unsigned short* tmp16 = (dst16 == c->diff16A) ? c->diff16B : c->diff16A;
+                    HIP_TRY(launch_pack_act16(cur, tmp16, L.cout, hw, c->stream));
+                    cur16 = tmp16;
+                }
+                // the layer below consumes this launch's output as bf16 iff it is itself a bf16 dgrad conv
+                const bool below16 = below >= 1 && c->topo[below - 1].is_conv && conv16_ok(c, L.cin) &&
+                                     !conv_dgrad_smallM_ok(c->topo[below - 1].cout, c->topo[below - 1].cin);
+                Conv16Problem p{};
+                p.in16 = cur16; p.wpack16 = L.w16_bwd; p.bias = nullptr; p.out = dst; p.out16 = below16 ? dst16 : nullptr;
+                p.mask_src = mask_src; p.inject = inject;
+                p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
+                HIP_TRY(launch_conv3x3_bf16(p, c->stream));
+                cur16 = below16 ? dst16 : nullptr;
             } else {
+                cur16 = nullptr;
                 ConvProblem p{};
                 p.in = cur; p.wpack = L.w_bwd; p.bias = nullptr; p.out = dst;
                 p.mask_src = mask_src; p.inject = inject;
@@ -308,6 +376,7 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
             const double n_in = (double)a.C[below] * a.h[below] * a.w[below];
             ProfScope ps(c, P_POOL_BWD, 0, 4.0 * n_in * 2.25);
             HIP_TRY(launch_maxpool_bwd(cur, a.data[below], dst, inject, mask_src != nullptr, a.C[below], a.h[below], a.w[below], c->stream));
+            cur16 = nullptr;
         }
         cur = dst;
     }
@@ -329,7 +398,7 @@ static int ensure_input_buffers(st_ctx* c, int H, int W)
     c->H = H; c->W = W; c->cur = 0;
     // work buffers that follow the input geometry
     for (auto& p : c->inject) dfree(p);
-    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp);
+    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree16(c->diff16A); dfree16(c->diff16B);
     std::vector<int> C, h, w;
     shapes_for(c, H, W, C, h, w);
     c->max_blob = 0;
@@ -639,7 +708,8 @@ int st_destroy(st_ctx* c)
     if (!c) return ST_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); }
+    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); }
+    dfree16(c->diff16A); dfree16(c->diff16B);
     act_free(c->act);
     for (int i = 0; i < 2; ++i) dfree(c->x[i]);
     dfree(c->grad); dfree(c->m); dfree(c->v); dfree(c->g_cur); dfree(c->pvec);
@@ -673,7 +743,16 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
         pack_conv_weights_fwd(w, L.cout, L.cin, pf.data());
         pack_conv_weights_dgrad(w, L.cout, L.cin, pb.data());
         if (bias) memcpy(bp.data(), bias, L.cout * sizeof(float));
-        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias);
+        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd);
+        {   // bf16 packs for the bf16 feature path
+            const size_t n16f = conv16_pack_elems(L.cin, L.cout), n16b = conv16_pack_elems(L.cout, L.cin);
+            std::vector<unsigned short> hf(n16f), hb(n16b);
+            pack_conv_weights16_fwd(w, L.cout, L.cin, hf.data());
+            pack_conv_weights16_dgrad(w, L.cout, L.cin, hb.data());
+            ST_TRY(dmalloc16(&L.w16_fwd, n16f)); ST_TRY(dmalloc16(&L.w16_bwd, n16b));
+            HIP_TRY(hipMemcpy(L.w16_fwd, hf.data(), n16f * 2, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(L.w16_bwd, hb.data(), n16b * 2, hipMemcpyHostToDevice));
+        }
         ST_TRY(dmalloc(&L.w_fwd, nf)); ST_TRY(dmalloc(&L.w_bwd, nb));
         ST_TRY(dmalloc(&L.w_raw, (size_t)L.cout * L.cin * 9)); ST_TRY(dmalloc(&L.bias, bp.size()));
         HIP_TRY(hipMemcpy(L.w_fwd, pf.data(), nf * sizeof(float), hipMemcpyHostToDevice));
@@ -684,6 +763,13 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
         return ST_OK;
     }
     return fail(ST_ERR_ARG, "no conv layer named %s", layer);
+}
+
+int st_set_precision(st_ctx* c, int bf16_features)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    c->bf16 = bf16_features != 0;
+    return ST_OK;
 }
 
 int st_num_blobs(st_ctx* c) { return c ? c->nb : 0; }

@@ -48,6 +48,22 @@ hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* d
                                        int Cout, int Cin, int H, int W, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
+// bf16 feature path (BASELINE config 3): conv operands in bf16 (v_mfma_f32_32x32x16_bf16), fp32 accumulate and
+// fp32 blobs.  Activations are read from a channel-blocked bf16 copy [C/8][H][W][8]; out16 (optional) is the copy
+// of this launch's output for the next conv.  Weight packs: [ceil(K/16)][9][2][MPad][8] bf16.
+// ------------------------------------------------------------------------------------------
+struct Conv16Problem {
+    const unsigned short* in16; const unsigned short* wpack16; const float* bias;
+    float* out; unsigned short* out16; const float* mask_src; const float* inject;
+    int K, M, MPad, H, W, relu;
+};
+size_t conv16_pack_elems(int K, int M);
+void pack_conv_weights16_fwd(const float* w, int Cout, int Cin, unsigned short* dst);
+void pack_conv_weights16_dgrad(const float* w, int Cout, int Cin, unsigned short* dst);
+hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s);
+hipError_t launch_pack_act16(const float* src, unsigned short* dst, int C, size_t hw, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------
 // max pool 2x2 stride 2, Caffe ceil mode, first-max arg-max (recomputed in backward).
 // ------------------------------------------------------------------------------------------
 int pooled_size(int n);

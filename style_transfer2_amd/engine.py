@@ -40,8 +40,9 @@ def _image_arg(image):
 
 
 class Engine:
-    def __init__(self, topology=None, device=0):
+    def __init__(self, topology=None, device=0, precision='fp32'):
         self.lib = capi.load_library()
+        self.precision = precision
         self._ctx = c_void_p()
         self.topology = tuple(topology) if topology is not None else VGG19_TOPOLOGY
         if topology is None:
@@ -56,6 +57,9 @@ class Engine:
                 d.name = name
                 d.cin, d.cout = (layer[2], layer[3]) if layer[0] == 'conv' else (0, 0)
             check(self.lib.st_create(byref(self._ctx), int(device), descs, len(self.topology)))
+        if precision not in ('fp32', 'bf16'):
+            raise ValueError('precision must be fp32 or bf16')
+        check(self.lib.st_set_precision(self._ctx, 1 if precision == 'bf16' else 0))
         n = self.lib.st_num_blobs(self._ctx)
         self.blob_names = [self.lib.st_blob_name(self._ctx, i).decode() for i in range(n)]
         self._index = {name: i for i, name in enumerate(self.blob_names)}

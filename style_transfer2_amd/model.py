@@ -18,8 +18,8 @@ F32 = np.float32
 class HipModel:
     mean = np.array((123.68, 116.779, 103.939), F32).reshape(3, 1, 1)   # reference worker.py:34
 
-    def __init__(self, params, topology=None, device=0, engine=None):
-        self.engine = engine if engine is not None else Engine(topology, device)
+    def __init__(self, params, topology=None, device=0, engine=None, precision='fp32'):
+        self.engine = engine if engine is not None else Engine(topology, device, precision)
         if params is not None:
             self.engine.load_weights(params)
 
