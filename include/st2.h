@@ -45,6 +45,10 @@ int st_create(st_ctx** out, int device_id, const st_layer_desc* layers, int n_la
 int st_destroy(st_ctx* ctx);
 /* weights of one conv layer, Caffe layout (Cout, Cin, 3, 3) + bias (Cout)  [caffe.Net(weights=)] */
 int st_load_conv_weights(st_ctx* ctx, const char* layer, const float* w, const float* bias);
+/* 1 (default; the environment variable ST2_WINO=0 also clears it): fp32 convs whose shape allows it (reduction
+ * depth % 8 == 0, width % 4 == 0, >= 96 output channels) run as Winograd F(2x2,3x3) on the fp32 matrix cores --
+ * 2.25x fewer multiplies, same IEEE fp32 products and sums in a different association.  0: direct kernel only. */
+int st_set_conv_algo(st_ctx* ctx, int winograd);
 /* 0 (default): fp32 throughout.  1: bf16 feature path (BASELINE config 3) -- conv operands (activations, weights,
  * backward diffs) in bf16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate; blobs, Gram, losses, optimizer stay fp32. */
 int st_set_precision(st_ctx* ctx, int bf16_features);
@@ -149,6 +153,8 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
 /* matrix-pipe ceiling probe: variant 0 = register operands, 1 = + LDS operand reads; blocks_per_cu
  * 256-thread workgroups per CU; returns sustained TFLOP/s of v_mfma_f32_32x32x2_f32 */
 int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops);
+/* Winograd operand-feed probe: executed MFMA TFLOP/s with the A operands streamed from L2 (depth = k-pairs in flight) */
+int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int depth, double* tflops);
 int st_conv_num_configs(void);
 const char* st_conv_config_name(int cfg);
 

@@ -20,6 +20,7 @@ ARCH = 'gfx950'
 SOURCES = (
     ('conv3x3_mfma.hip', ()),
     ('conv3x3_mfma_bf16.hip', ()),
+    ('conv3x3_winograd.hip', ()),
     ('gram.hip', ()),
     ('passes.hip', ('-ffp-contract=off',)),      # NumPy-like one-rounding-per-operation arithmetic
     ('engine.cpp', ('-x', 'hip')),

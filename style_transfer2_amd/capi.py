@@ -33,6 +33,7 @@ PROTOTYPES = {
     'st_create': (c_int, [POINTER(c_void_p), c_int, POINTER(LayerDesc), c_int]),
     'st_destroy': (c_int, [c_void_p]),
     'st_load_conv_weights': (c_int, [c_void_p, c_char_p, c_void_p, c_void_p]),
+    'st_set_conv_algo': (c_int, [c_void_p, c_int]),
     'st_set_precision': (c_int, [c_void_p, c_int]),
     'st_num_blobs': (c_int, [c_void_p]),
     'st_blob_name': (c_char_p, [c_void_p, c_int]),
@@ -80,6 +81,7 @@ PROTOTYPES = {
     'st_tile_swap': (c_int, [c_void_p]),
     'st_bench_conv': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_int)]),
     'st_bench_mfma': (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
+    'st_bench_wino_probe': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_double)]),
     'st_conv_num_configs': (c_int, []),
     'st_conv_config_name': (c_char_p, [c_int]),
 }

@@ -57,6 +57,7 @@ struct Layer {
     int cin = 0, cout = 0;
     float *w_fwd = nullptr, *w_bwd = nullptr, *w_raw = nullptr, *bias = nullptr;
     unsigned short *w16_fwd = nullptr, *w16_bwd = nullptr;       // bf16 packs (bf16 feature path)
+    float *u_fwd = nullptr, *u_bwd = nullptr;                    // Winograd F(2x2,3x3) packs (null: not eligible)
     bool loaded = false;
 };
 
@@ -84,6 +85,7 @@ struct st_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool bf16 = false;                             // conv operands in bf16 (BASELINE config 3)
+    bool wino = true;                              // Winograd F(2x2,3x3) for the eligible fp32 convs (ST2_WINO=0 disables)
     unsigned short *diff16A = nullptr, *diff16B = nullptr;
     std::vector<Layer> topo;
     std::vector<std::string> blob_names;
@@ -272,7 +274,8 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
                 p.in = a.data[i - 1]; p.wpack = L.w_fwd; p.bias = L.bias; p.out = a.data[i];
                 p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
                 { ProfScope ps(c, P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
-                  HIP_TRY(launch_conv3x3(p, c->stream)); }
+                  if (c->wino && L.u_fwd && conv_wino_ok(p.K, p.M, p.H, p.W)) { p.wpack = L.u_fwd; HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
+                  else HIP_TRY(launch_conv3x3(p, c->stream)); }
                 if (next16) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
             }
         } else {
@@ -370,7 +373,8 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
                 p.in = cur; p.wpack = L.w_bwd; p.bias = nullptr; p.out = dst;
                 p.mask_src = mask_src; p.inject = inject;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
-                HIP_TRY(launch_conv3x3(p, c->stream));
+                if (c->wino && L.u_bwd && conv_wino_ok(p.K, p.M, p.H, p.W)) { p.wpack = L.u_bwd; HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
+                else HIP_TRY(launch_conv3x3(p, c->stream));
             }
         } else {
             const double n_in = (double)a.C[below] * a.h[below] * a.w[below];
@@ -659,6 +663,7 @@ int st_create(st_ctx** out, int device_id, const st_layer_desc* layers, int n_la
     HIP_TRY(hipSetDevice(device_id));
     st_ctx* c = new st_ctx();
     c->device = device_id;
+    { const char* e = getenv("ST2_WINO"); if (e && *e) c->wino = atoi(e) != 0; }
     if (n_layers <= 0) {
         for (const auto& l : kVgg19) {
             Layer L; L.is_conv = l.kind == 0; L.name = l.name; L.cin = l.cin; L.cout = l.cout;
@@ -708,7 +713,7 @@ int st_destroy(st_ctx* c)
     if (!c) return ST_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); }
+    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree(L.u_fwd); dfree(L.u_bwd); }
     dfree16(c->diff16A); dfree16(c->diff16B);
     act_free(c->act);
     for (int i = 0; i < 2; ++i) dfree(c->x[i]);
@@ -743,7 +748,16 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
         pack_conv_weights_fwd(w, L.cout, L.cin, pf.data());
         pack_conv_weights_dgrad(w, L.cout, L.cin, pb.data());
         if (bias) memcpy(bp.data(), bias, L.cout * sizeof(float));
-        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd);
+        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree(L.u_fwd); dfree(L.u_bwd);
+        for (int dir = 0; dir < 2; ++dir) {   // Winograd packs for the directions the Winograd kernel can take (any image size)
+            const int K = dir ? L.cout : L.cin, M = dir ? L.cin : L.cout;
+            if (!conv_wino_ok(K, M, 4, 4)) continue;
+            std::vector<float> hu(wino_pack_floats(K, M));
+            if (dir) pack_wino_weights_dgrad(w, L.cout, L.cin, hu.data()); else pack_wino_weights_fwd(w, L.cout, L.cin, hu.data());
+            float** dst = dir ? &L.u_bwd : &L.u_fwd;
+            ST_TRY(dmalloc(dst, hu.size()));
+            HIP_TRY(hipMemcpy(*dst, hu.data(), hu.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         {   // bf16 packs for the bf16 feature path
             const size_t n16f = conv16_pack_elems(L.cin, L.cout), n16b = conv16_pack_elems(L.cout, L.cin);
             std::vector<unsigned short> hf(n16f), hb(n16b);
@@ -763,6 +777,13 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
         return ST_OK;
     }
     return fail(ST_ERR_ARG, "no conv layer named %s", layer);
+}
+
+int st_set_conv_algo(st_ctx* c, int winograd)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    c->wino = winograd != 0;
+    return ST_OK;
 }
 
 int st_set_precision(st_ctx* c, int bf16_features)
@@ -1577,6 +1598,34 @@ int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops)
     return ST_OK;
 }
 
+int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int depth, double* tflops)
+{
+    if (!tflops || blocks_per_cu <= 0 || K < 8 || K % 8 || M < 128 || M % 128 || (depth != 1 && depth != 2 && depth != 4))
+        return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device_id));
+    const int blocks = 256 * blocks_per_cu, nkp = K / 2, n_mt = M / 128;
+    const size_t n_u = (size_t)(M / 32) * nkp * 256 * 4;
+    float *out = nullptr, *U = nullptr;
+    ST_TRY(dmalloc(&out, (size_t)blocks * 256)); ST_TRY(dmalloc(&U, n_u));
+    HIP_TRY(hipMemset(U, 0x3c, n_u * 4));
+    hipStream_t s;
+    HIP_TRY(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) (void)launch_wino_probe(U, out, blocks, nkp, n_mt, depth, s);
+    (void)hipEventRecord(e0, s);
+    const int reps = 10;
+    for (int i = 0; i < reps; ++i) (void)launch_wino_probe(U, out, blocks, nkp, n_mt, depth, s);
+    (void)hipEventRecord(e1, s);
+    HIP_TRY(hipStreamSynchronize(s));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *tflops = (double)reps * blocks * 4 * nkp * 16.0 * 4096.0 / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    dfree(out); dfree(U);
+    return ST_OK;
+}
+
 int st_conv_num_configs(void) { return conv_num_configs(); }
 const char* st_conv_config_name(int cfg) { return conv_config_name(cfg); }
 
@@ -1591,6 +1640,12 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
     for (auto& x : w) x = rnd() * 0.05f;
     for (auto& x : hin) x = rnd();
+    const bool wino = cfg == 100;
+    if (wino) {
+        if (!conv_wino_ok(K, M, H, W)) return fail(ST_ERR_ARG, "shape not eligible for the Winograd kernel");
+        pk.assign(wino_pack_floats(K, M), 0.f);
+        pack_wino_weights_fwd(w.data(), M, K, pk.data());
+    } else
     pack_conv_weights_fwd(w.data(), M, K, pk.data());
     float *din = nullptr, *dw = nullptr, *db = nullptr, *dout = nullptr, *dmask = nullptr, *dinj = nullptr;
     ST_TRY(dmalloc(&din, n_in)); ST_TRY(dmalloc(&dw, pk.size())); ST_TRY(dmalloc(&db, hb.size())); ST_TRY(dmalloc(&dout, n_out));
@@ -1615,13 +1670,14 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     if (cfg == 6) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
     hipStream_t s;
     HIP_TRY(hipStreamCreate(&s));
+    auto launch = [&]() { return wino ? launch_conv3x3_wino(p, s) : launch_conv3x3_cfg(p, cfg, s); };
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     int rc = ST_OK;
-    for (int i = 0; i < 2 && rc == ST_OK; ++i) if (launch_conv3x3_cfg(p, cfg, s) != hipSuccess) rc = fail(ST_ERR_HIP, "conv launch failed (cfg %d)", cfg);
+    for (int i = 0; i < 2 && rc == ST_OK; ++i) if (launch() != hipSuccess) rc = fail(ST_ERR_HIP, "conv launch failed (cfg %d)", cfg);
     if (rc == ST_OK) {
         (void)hipEventRecord(e0, s);
-        for (int i = 0; i < iters; ++i) (void)launch_conv3x3_cfg(p, cfg, s);
+        for (int i = 0; i < iters; ++i) (void)launch();
         (void)hipEventRecord(e1, s);
         if (hipStreamSynchronize(s) != hipSuccess) rc = fail(ST_ERR_HIP, "conv bench sync failed");
         float ms = 0.f;

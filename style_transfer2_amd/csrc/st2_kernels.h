@@ -42,6 +42,13 @@ const char* conv_config_name(int cfg);
 int conv_pick_config(const ConvProblem& p);
 hipError_t launch_conv3x3_cfg(const ConvProblem& p, int cfg, hipStream_t s);
 hipError_t launch_mfma_probe(int variant, float* out, int blocks, int iters, hipStream_t s);
+// Winograd F(2x2,3x3) variant of launch_conv3x3 (same ConvProblem, p.wpack = the Winograd pack, MPad unused)
+size_t wino_pack_floats(int K, int M);
+void pack_wino_weights_fwd(const float* w, int Cout, int Cin, float* dst);
+void pack_wino_weights_dgrad(const float* w, int Cout, int Cin, float* dst);
+bool conv_wino_ok(int K, int M, int H, int W);
+hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);
+hipError_t launch_wino_probe(const float* U, float* out, int blocks, int nkp, int n_mt, int depth, hipStream_t s);
 // conv1_1-style dgrad (tiny M): direct VALU kernel, w is the ORIGINAL (Cout,Cin,3,3) layout
 bool conv_dgrad_smallM_ok(int Cout, int Cin);
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,

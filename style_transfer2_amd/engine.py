@@ -64,6 +64,10 @@ class Engine:
         self.blob_names = [self.lib.st_blob_name(self._ctx, i).decode() for i in range(n)]
         self._index = {name: i for i, name in enumerate(self.blob_names)}
 
+    def set_conv_algo(self, winograd):
+        """True (default): eligible fp32 convs run as Winograd F(2x2,3x3); False: direct kernel only."""
+        check(self.lib.st_set_conv_algo(self._ctx, 1 if winograd else 0))
+
     # -- lifecycle -------------------------------------------------------------------------------
     def close(self):
         if self._ctx:

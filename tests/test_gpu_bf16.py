@@ -143,4 +143,4 @@ def test_bf16_lbfgs_trajectory_tracks_fp32_reference_vectors():
     assert st.start()
     losses = [st.step()[1]['loss'] for _ in range(20)]
     assert np.allclose(losses[:5], g['lbfgs_losses'][:5], rtol=5e-2)    # 2.7e-2 measured at the third step
-    assert losses[-1] < 0.6 * losses[0]
+    assert np.isclose(losses[-1], g['lbfgs_losses'][-1], rtol=0.15), (losses[-1], g['lbfgs_losses'][-1])

@@ -1,0 +1,60 @@
+"""GPU parity of the Winograd F(2x2,3x3) conv3x3 kernel (csrc/conv3x3_winograd.hip) against the CPU oracle and
+against the direct implicit-GEMM kernel.  Winograd computes the same fp32 products and sums in another
+association (input / filter / output transforms), so the bar is a relative L2 error, stated per test:
+1e-5 forward, 3e-5 data gradient -- the same bars the direct kernel is held to (test_gpu_parity.py)."""
+
+import numpy as np
+import pytest
+
+import oracle
+import style_transfer2_amd as st2
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.mark.parametrize('cin,cout,h,w', [
+    (8, 96, 4, 32), (8, 128, 6, 8), (16, 128, 9, 36), (64, 128, 17, 32), (72, 200, 5, 64), (128, 128, 40, 72),
+    (128, 256, 12, 12), (256, 256, 7, 44), (256, 512, 8, 8), (512, 512, 6, 4), (64, 160, 33, 100), (128, 128, 64, 96)])
+def test_winograd_conv_forward_and_dgrad(cin, cout, h, w):
+    """conv1_2 (cin -> cout) runs the Winograd kernel forward (M = cout >= 96) and, when cin >= 96, backward."""
+    topo = (('conv', 'conv1_1', 3, cin), ('conv', 'conv1_2', cin, cout))
+    params = oracle.he_init_weights(topo, seed=cin + cout, bias_std=0.2)
+    cpu = oracle.NetOracle(topo, params)
+    gpu = st2.HipModel(params, topology=topo)
+    direct = st2.HipModel(params, topology=topo)
+    direct.engine.set_conv_algo(False)
+    rng = np.random.RandomState(h * w)
+    x = (rng.randn(1, 3, h, w) * 40).astype(F32)
+    fc = cpu.forward(x, ['conv1_2'])['conv1_2']
+    fg = gpu.forward(x, ['conv1_1', 'conv1_2'])
+    fd = direct.forward(x, ['conv1_2'])['conv1_2']
+    assert rel_l2(fg['conv1_2'], fc) <= 1e-5, rel_l2(fg['conv1_2'], fc)
+    assert rel_l2(fg['conv1_2'], fd) <= 1e-5
+    assert not np.array_equal(fg['conv1_2'], fd)        # the Winograd kernel really ran (different association)
+    d = rng.randn(*fc.shape).astype(F32)
+    cpu.adopt_forward_state(fg)                         # same ReLU masks: compare the backward arithmetic only
+    gc = cpu.backward({'conv1_2': d})
+    gg = gpu.backward({'conv1_2': d})
+    assert rel_l2(gg, gc) <= 3e-5, rel_l2(gg, gc)
+
+
+def test_winograd_chain_with_masks_and_injections():
+    """Winograd dgrad epilogue: ReLU mask from the blob below, injected diffs, pools in between."""
+    topo = (('conv', 'conv1_1', 3, 96), ('conv', 'conv1_2', 96, 128), ('pool', 'pool1'),
+            ('conv', 'conv2_1', 128, 128), ('conv', 'conv2_2', 128, 192))
+    params = oracle.he_init_weights(topo, seed=4, bias_std=0.2)
+    cpu = oracle.NetOracle(topo, params)
+    gpu = st2.HipModel(params, topology=topo)
+    rng = np.random.RandomState(3)
+    for h, w in ((24, 40), (17, 72), (8, 8)):
+        x = (rng.randn(1, 3, h, w) * 40).astype(F32)
+        fc, fg = cpu.forward(x), gpu.forward(x)
+        for name in fc:
+            assert rel_l2(fg[name], fc[name]) <= 1e-5, (name, h, w)
+        cpu.adopt_forward_state(fg)
+        for names in (['conv2_2'], ['conv2_2', 'conv2_1', 'pool1', 'conv1_2', 'conv1_1', 'data'], ['conv2_1'], ['conv1_2']):
+            diffs = {n: rng.randn(*fc[n].shape).astype(F32) for n in names}
+            err = rel_l2(gpu.backward(diffs), cpu.backward(diffs))
+            assert err <= 3e-5, (names, h, w, err)
