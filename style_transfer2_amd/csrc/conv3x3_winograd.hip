@@ -6,6 +6,7 @@
 // (global_load_dwordx4, packed in operand order, no LDS) while the matrix pipe stays busy.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "st2_kernels.h"
 
@@ -14,7 +15,7 @@ namespace st2 {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // U layout: [m32][kpair][posgroup 4][lane 64][4 floats]; one wave-load (dwordx4) = 1 KB contiguous
-template <int DEPTH>
+template <int DEPTH, int ROT>
 __global__ __launch_bounds__(256, 1) void wino_probe_k(const float4* __restrict__ U, float* out, int nkp, int n_mt)
 {
     __shared__ float vs[2][16 * 64];
@@ -28,6 +29,7 @@ __global__ __launch_bounds__(256, 1) void wino_probe_k(const float4* __restrict_
     const int xcd = blockIdx.x & 7;
     const int mt = (xcd * 2 + ((blockIdx.x >> 3) & 1)) % n_mt;          // the blocks of one XCD share two 128-m slices
     const float4* up = U + (size_t)(mt * 4 + wave) * nkp * 256 + lane;
+    const int rot = ROT ? (int)((blockIdx.x >> 4) & 7) * (nkp / 8) : 0;      // staggered start of the k walk
     f32x16 acc[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
@@ -39,7 +41,7 @@ __global__ __launch_bounds__(256, 1) void wino_probe_k(const float4* __restrict_
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) ua[d][g] = up[(size_t)(d * 4 + g) * 64];
+        for (int g = 0; g < 4; ++g) ua[d][g] = up[(size_t)(((d + rot) % nkp) * 4 + g) * 64];
     asm volatile("" ::: "memory");
     for (int kp = 0; kp < nkp; kp += DEPTH) {
 #pragma unroll
@@ -47,7 +49,7 @@ __global__ __launch_bounds__(256, 1) void wino_probe_k(const float4* __restrict_
             float4 cur[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) cur[g] = ua[d][g];
-            const int nxt = kp + d + DEPTH < nkp ? kp + d + DEPTH : kp + d;     // tail: reload (harmless)
+            const int nxt = ((kp + d + DEPTH < nkp ? kp + d + DEPTH : kp + d) + rot) % nkp;     // tail: reload (harmless)
 #pragma unroll
             for (int g = 0; g < 4; ++g) ua[d][g] = up[((size_t)nxt * 4 + g) * 64];
             asm volatile("" ::: "memory");
@@ -77,9 +79,10 @@ hipError_t launch_wino_probe(const float* U, float* out, int blocks, int nkp, in
     if (nkp <= 0 || nkp % 4 != 0) return hipErrorInvalidValue;
     const float4* u4 = reinterpret_cast<const float4*>(U);
     switch (depth) {
-    case 1: wino_probe_k<1><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;
-    case 2: wino_probe_k<2><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;
-    case 4: wino_probe_k<4><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;
+    case 1: wino_probe_k<1, 0><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;
+    case 2: wino_probe_k<2, 0><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;
+    case 4: wino_probe_k<4, 0><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;
+    case 12: wino_probe_k<2, 1><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;     // depth 2, staggered k walk
     default: return hipErrorInvalidValue;      // nkp must be a multiple of depth (the ring is unrolled by it)
     }
     return hipGetLastError();
@@ -114,10 +117,8 @@ hipError_t launch_wino_probe(const float* U, float* out, int blocks, int nkp, in
 // ===========================================================================================================
 
 constexpr int WN_CH = 8;                         // input channels per chunk (4 k-pairs)
-constexpr int WN_ROWS = 6, WN_IW = 40;           // staged rows y0-1 .. y0+4, columns x0-4 .. x0+35
-constexpr int WN_PLANE = WN_ROWS * WN_IW;        // 240
-constexpr int WN_RAW = 2048;                     // floats per raw buffer (8 wave-DMAs of 64 quads; 1920 used)
-constexpr int WN_V = 4 * 16 * 64;                // floats per V buffer
+constexpr int WN_IW = 40;                        // staged columns x0-4 .. x0+35 (10 aligned quads)
+constexpr int WN_V = 4 * 16 * 64;                // floats per V image (one 32-tile group, one chunk)
 
 size_t wino_pack_floats(int K, int M) { return (size_t)((M + 127) / 128 * 4) * (K / 2) * 1024; }
 
@@ -156,17 +157,33 @@ constexpr unsigned kOOB = 0xffffffffu;
 
 __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
-__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKArgs a)
+// WM waves along m (32 channels each) x TG tile groups (32 tiles = 4 rows x 32 columns each), WM * TG = 4:
+//   <4,1>: 128 channels x  4 rows x 32 columns      <2,2>: 64 channels x 8 rows x 32 columns
+// With TG = 2 the two waves that share a channel slice load the same U lines together (one L2 fetch), and every
+// thread transforms two (tile, channel) pairs per chunk.
+template <int WM, int TG>
+__device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
-    __shared__ __attribute__((aligned(16))) float raw_s[2][WN_RAW];
-    __shared__ __attribute__((aligned(16))) float v_s[2][WN_V];
+    static_assert(WM * TG == 4 && (TG == 1 || TG == 2), "4 waves");
+    constexpr int BM = 32 * WM;
+    constexpr int PROWS = 4 * TG;                        // pixel rows per block
+    constexpr int IN_ROWS = PROWS + 2;
+    constexpr int PLANE = IN_ROWS * WN_IW;
+    constexpr int N_RAW = WN_CH * PLANE;                 // floats staged per chunk
+    constexpr int I_PER_WAVE = (N_RAW / 4 + 255) / 256;  // wave-DMAs (64 quads) per wave
+    constexpr int RAW = I_PER_WAVE * 1024;               // floats per raw buffer
+    constexpr int NU = 4 * TG;                           // transform units of 4 LDS ops (reads, writes); 2 * NU of 4 VALU ops
+
+    __shared__ __attribute__((aligned(16))) float raw_s[2][RAW];
+    __shared__ __attribute__((aligned(16))) float v_s[2][TG][WN_V];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave / TG, wave_g = wave % TG;
 
     // XCD-aware bijective block -> tile map, pixel tile fastest: the co-resident blocks of one XCD work on the
-    // same 128-channel slice of U (the dominant stream) and on neighbouring pixel tiles.
+    // same channel slice of U (the dominant stream) and on neighbouring pixel tiles.
     const int nwg = gridDim.x, orig = blockIdx.x;
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
@@ -175,39 +192,63 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKAr
     const int pt = logical - mt * n_pt;
     const int tx = pt % a.tiles_x;
     const int ty = pt / a.tiles_x;
-    const int y0 = ty * 4, x0 = tx * 32;
+    const int y0 = ty * PROWS, x0 = tx * 32;
     const unsigned plane = (unsigned)a.H * a.W;
     const int nkp = a.K >> 1;
 
     const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
-    unsigned ioff[2];
+    unsigned ioff[I_PER_WAVE];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < I_PER_WAVE; ++t) {
         const int e = ((wave + 4 * t) * 64 + lane) * 4;
-        const int c = e / WN_PLANE;
-        const int rem = e - c * WN_PLANE;
+        const int c = e / PLANE;
+        const int rem = e - c * PLANE;
         const int rr = rem / WN_IW;
         const int col = rem - rr * WN_IW;
         const int gy = y0 - 1 + rr, gx = x0 - 4 + col;
-        const bool ok = e < WN_CH * WN_PLANE && gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W;
+        const bool ok = e < N_RAW && gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W;
         ioff[t] = ok ? ((unsigned)c * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
     }
     auto dma_raw = [&](int ch, int buf) {
         const unsigned coff = (unsigned)ch * WN_CH * plane * 4u;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < I_PER_WAVE; ++t) {
             const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + coff;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s[buf] + (wave + 4 * t) * 256), 16, vo, 0, 0, 0);
         }
     };
 
-    // input transform: this thread owns tile xt of channel xch of every chunk
+    // input transform: this thread owns tile xt of channel xch, in every tile group, of every chunk
     const int xt = tid & 31, xch = tid >> 5;
-    const int x_raw = xch * WN_PLANE + (2 * (xt >> 4)) * WN_IW + 2 * (xt & 15) + 3;       // column 3 = pixel x0 - 1
+    const int x_raw = xch * PLANE + (2 * (xt >> 4)) * WN_IW + 2 * (xt & 15) + 3;          // column 3 = pixel x0 - 1
     const int x_v = ((xch >> 1) * 16) * 64 + (xch & 1) * 32 + xt;
-    float d[16], wv[16];
+    float d[TG][16], wv[TG][16];
+    // unit u of the three transform phases (each unit = 4 instructions), u in [0, NU) / [0, 2 NU) / [0, NU)
+    auto xf_read = [&](const float* rp, int u) {
+        const int g = u >> 2, i = u & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[g][4 * i + j] = rp[(4 * g + i) * WN_IW + j];
+    };
+    auto xf_math = [&](int u) {
+        const int g = u >> 3, h = u & 7;
+        if (h < 4) {
+            const int j = h;
+            wv[g][j] = d[g][j] - d[g][8 + j]; wv[g][4 + j] = d[g][4 + j] + d[g][8 + j];
+            wv[g][8 + j] = d[g][8 + j] - d[g][4 + j]; wv[g][12 + j] = d[g][4 + j] - d[g][12 + j];
+        } else {
+            const int i = h - 4;
+            const float v0 = wv[g][4 * i] - wv[g][4 * i + 2], v1 = wv[g][4 * i + 1] + wv[g][4 * i + 2];
+            const float v2 = wv[g][4 * i + 2] - wv[g][4 * i + 1], v3 = wv[g][4 * i + 1] - wv[g][4 * i + 3];
+            d[g][4 * i] = v0; d[g][4 * i + 1] = v1; d[g][4 * i + 2] = v2; d[g][4 * i + 3] = v3;
+        }
+    };
+    auto xf_write = [&](float* vp, int u) {
+        const int g = u >> 2, i = u & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vp[g * WN_V + (4 * i + j) * 64] = d[g][4 * i + j];
+    };
 
-    const float4* up = a.upack + ((size_t)(mt * 4 + wave) * nkp) * 256 + lane;
+    const float4* up = a.upack + ((size_t)(mt * WM + wave_m) * nkp) * 256 + lane;
     auto u_load = [&](int kp, int g) -> float4 {
         const int kk = kp < nkp ? kp : nkp - 1;                 // tail: a harmless reload
         return up[((size_t)kk * 4 + g) * 64];
@@ -229,35 +270,24 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKAr
         for (int g = 0; g < 4; ++g) ua[s2][g] = u_load(s2, g);
     asm volatile("" ::: "memory");
     __syncthreads();
-    {
-        const float* rp = raw_s[0] + x_raw;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int u = 0; u < NU; ++u) xf_read(raw_s[0] + x_raw, u);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) d[4 * i + j] = rp[i * WN_IW + j];
+    for (int u = 0; u < 2 * NU; ++u) xf_math(u);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wv[j] = d[j] - d[8 + j]; wv[4 + j] = d[4 + j] + d[8 + j]; wv[8 + j] = d[8 + j] - d[4 + j]; wv[12 + j] = d[4 + j] - d[12 + j];
-        }
-        float* vp = v_s[0] + x_v;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vp[(4 * i + 0) * 64] = wv[4 * i] - wv[4 * i + 2];
-            vp[(4 * i + 1) * 64] = wv[4 * i + 1] + wv[4 * i + 2];
-            vp[(4 * i + 2) * 64] = wv[4 * i + 2] - wv[4 * i + 1];
-            vp[(4 * i + 3) * 64] = wv[4 * i + 1] - wv[4 * i + 3];
-        }
-    }
+    for (int u = 0; u < NU; ++u) xf_write(&v_s[0][0][0] + x_v, u);
     __syncthreads();
     float bv[2][16];
 #pragma unroll
-    for (int p = 0; p < 16; ++p) bv[0][p] = v_s[0][p * 64 + lane];
+    for (int p = 0; p < 16; ++p) bv[0][p] = v_s[0][wave_g][p * 64 + lane];
 
     for (int c = 0; c < a.nch; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < a.nch, more2 = c + 2 < a.nch;
         const float* rp = raw_s[cur ^ 1] + x_raw;
-        float* vp = v_s[cur ^ 1] + x_v;
+        float* vp = &v_s[cur ^ 1][0][0] + x_v;
+        const float* bcur = v_s[cur][wave_g] + lane;
+        const float* bnxt = v_s[cur ^ 1][wave_g] + lane;
 #pragma unroll
         for (int kpl = 0; kpl < 4; ++kpl) {
             const int kp = 4 * c + kpl;
@@ -275,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKAr
                 if (kpl < 3) {
                     if (p >= 1 && p <= 4) {
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) bv[set ^ 1][4 * (p - 1) + jj] = v_s[cur][((kpl + 1) * 16 + 4 * (p - 1) + jj) * 64 + lane];
+                        for (int jj = 0; jj < 4; ++jj) bv[set ^ 1][4 * (p - 1) + jj] = bcur[((kpl + 1) * 16 + 4 * (p - 1) + jj) * 64];
                     }
                 } else if (more) {
                     if (p == 0) {
@@ -284,29 +314,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKAr
                     }
                     if (p >= 1 && p <= 4) {
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) bv[0][4 * (p - 1) + jj] = v_s[cur ^ 1][(4 * (p - 1) + jj) * 64 + lane];
+                        for (int jj = 0; jj < 4; ++jj) bv[0][4 * (p - 1) + jj] = bnxt[(4 * (p - 1) + jj) * 64];
                     }
                 }
-                // --- input transform of chunk c+1, spread over k-pairs 0..2; raw DMA of chunk c+2 ---
+                // --- input transform of chunk c+1: reads in k-pair 0, arithmetic in 1, writes in 2; raw DMA of chunk c+2 ---
                 if (more) {
-                    if (kpl == 0 && p >= 5 && p <= 8) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) d[4 * (p - 5) + j] = rp[(p - 5) * WN_IW + j];
-                    }
-                    if (kpl == 1 && p >= 5 && p <= 8) {
-                        const int j = p - 5;
-                        wv[j] = d[j] - d[8 + j]; wv[4 + j] = d[4 + j] + d[8 + j]; wv[8 + j] = d[8 + j] - d[4 + j]; wv[12 + j] = d[4 + j] - d[12 + j];
-                    }
-                    if (kpl == 1 && p >= 9 && p <= 12) {
-                        const int i = p - 9;
-                        const float v0 = wv[4 * i] - wv[4 * i + 2], v1 = wv[4 * i + 1] + wv[4 * i + 2];
-                        const float v2 = wv[4 * i + 2] - wv[4 * i + 1], v3 = wv[4 * i + 1] - wv[4 * i + 3];
-                        d[4 * i] = v0; d[4 * i + 1] = v1; d[4 * i + 2] = v2; d[4 * i + 3] = v3;
-                    }
-                    if (kpl == 2 && p >= 5 && p <= 8) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) vp[(4 * (p - 5) + j) * 64] = d[4 * (p - 5) + j];
-                    }
+                    if (kpl == 0 && p >= 5 && p < 5 + NU) xf_read(rp, p - 5);
+                    if (kpl == 1 && TG == 1 && p >= 5 && p < 13) xf_math(p - 5);
+                    if (kpl == 1 && TG == 2) xf_math(p);
+                    if (kpl == 2 && p >= 5 && p < 5 + NU) xf_write(vp, p - 5);
                 }
                 if (more2 && kpl == 1 && p == 13) dma_raw(c + 2, cur);
                 __builtin_amdgcn_sched_barrier(0);
@@ -314,63 +330,97 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKAr
         }
     }
 
-    // ---- epilogue: output transform (in-lane), then bias / ReLU / mask / inject, float2 stores ----
+    // ---- epilogue: output transform (in-lane), then bias / ReLU / mask / inject, float2 stores.
+    // Four accumulator rows at a time: their mask / inject loads are issued together, ahead of the arithmetic.
     const int t31 = lane & 31, khalf = lane >> 5;
-    const int gy0 = y0 + 2 * (t31 >> 4), gx = x0 + 2 * (t31 & 15);
+    const int gy0 = y0 + 4 * wave_g + 2 * (t31 >> 4), gx = x0 + 2 * (t31 & 15);
     const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
-    if (gx >= a.W) return;
-    const int mw = mt * 128 + wave * 32 + 4 * khalf;
+    if (gx >= a.W || gy0 >= a.H) return;
+    const bool row1 = gy0 + 1 < a.H;
+    const int mw = mt * BM + wave_m * 32 + 4 * khalf;
+    const unsigned pix0 = (unsigned)gy0 * a.W + gx, pix1 = row1 ? pix0 + a.W : pix0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int m = mw + (e & 3) + 8 * (e >> 2);
-        if (m >= a.M) continue;
-        float tt[2][4];
+    for (int eb = 0; eb < 4; ++eb) {
+        const int mb = mw + 8 * eb;                         // rows mb .. mb+3 (e = 4 eb + 0..3)
+        unsigned off[4];
+        float2 mk[4][2], ij[4][2];
+        float bs[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            tt[0][j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
-            tt[1][j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
+        for (int ee = 0; ee < 4; ++ee) {
+            const int m = mb + ee < a.M ? mb + ee : a.M - 1;
+            off[ee] = (unsigned)m * plane;
+            bs[ee] = has_bias ? a.bias[m] : 0.f;
         }
-        const float bias = has_bias ? a.bias[m] : 0.f;
+        if (has_mask) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int gy = gy0 + i;
-            if (gy >= a.H) continue;
-            float o0 = tt[i][0] + tt[i][1] + tt[i][2] + bias;
-            float o1 = tt[i][1] - tt[i][2] - tt[i][3] + bias;
-            if (a.relu) { o0 = o0 > 0.f ? o0 : 0.f; o1 = o1 > 0.f ? o1 : 0.f; }
-            const size_t off = (size_t)m * plane + (size_t)gy * a.W + gx;
-            if (has_mask) {
-                const float2 mk = *reinterpret_cast<const float2*>(a.mask_src + off);
-                o0 = mk.x > 0.f ? o0 : 0.f; o1 = mk.y > 0.f ? o1 : 0.f;
+            for (int ee = 0; ee < 4; ++ee) {
+                mk[ee][0] = *reinterpret_cast<const float2*>(a.mask_src + off[ee] + pix0);
+                mk[ee][1] = *reinterpret_cast<const float2*>(a.mask_src + off[ee] + pix1);
             }
-            if (has_inj) {
-                const float2 ij = *reinterpret_cast<const float2*>(a.inject + off);
-                o0 += ij.x; o1 += ij.y;
+        }
+        if (has_inj) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                ij[ee][0] = *reinterpret_cast<const float2*>(a.inject + off[ee] + pix0);
+                ij[ee][1] = *reinterpret_cast<const float2*>(a.inject + off[ee] + pix1);
             }
-            *reinterpret_cast<float2*>(a.out + off) = make_float2(o0, o1);
+        }
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 4 * eb + ee;
+            float tt[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tt[0][j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
+                tt[1][j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float o0 = tt[i][0] + tt[i][1] + tt[i][2] + bs[ee];
+                float o1 = tt[i][1] - tt[i][2] - tt[i][3] + bs[ee];
+                if (a.relu) { o0 = o0 > 0.f ? o0 : 0.f; o1 = o1 > 0.f ? o1 : 0.f; }
+                if (has_mask) { o0 = mk[ee][i].x > 0.f ? o0 : 0.f; o1 = mk[ee][i].y > 0.f ? o1 : 0.f; }
+                if (has_inj) { o0 += ij[ee][i].x; o1 += ij[ee][i].y; }
+                if (mb + ee < a.M && (i == 0 || row1))
+                    *reinterpret_cast<float2*>(a.out + off[ee] + (i ? pix1 : pix0)) = make_float2(o0, o1);
+            }
         }
     }
 }
 
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKArgs a) { conv3x3_wino_body<4, 1>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256(const WinoKArgs a) { conv3x3_wino_body<2, 2>(a); }
+
 bool conv_wino_ok(int K, int M, int H, int W)
 {
-    return K >= 8 && K % 8 == 0 && W % 4 == 0 && M >= 96 && H >= 1 && 4ull * K * H * W < 0xfffffff0ull && 4ull * M * H * W < 0xfffffff0ull;
+    return K >= 8 && K % 8 == 0 && W % 4 == 0 && M >= 48 && H >= 1 && 4ull * K * H * W < 0xfffffff0ull && 4ull * M * H * W < 0xfffffff0ull;
 }
 
+// variant: 0 = 128 channels x 4x32 pixels, 1 = 64 channels x 8x32 pixels, -1 = choose
 // p.wpack = the Winograd pack (pack_wino_weights_*); p.bias may be any length >= M
-hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s)
+hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s)
 {
     if (!conv_wino_ok(p.K, p.M, p.H, p.W) || (reinterpret_cast<uintptr_t>(p.in) & 15) != 0) return hipErrorInvalidValue;
+    if (variant < 0) {
+        const char* env = getenv("ST2_WINO_CFG");            // forces a variant (tests of both variants on every shape)
+        const int forced = env && *env ? atoi(env) : -1;
+        const int pad128 = (p.M + 127) / 128 * 128, pad64 = (p.M + 63) / 64 * 64;
+        variant = forced >= 0 ? forced : (pad64 < pad128 ? 1 : 0);
+    }
+    const int bm = variant == 1 ? 64 : 128, prows = variant == 1 ? 8 : 4;
     WinoKArgs k{};
     k.in = p.in; k.upack = reinterpret_cast<const float4*>(p.wpack); k.bias = p.bias; k.out = p.out;
     k.mask_src = p.mask_src; k.inject = p.inject;
     k.K = p.K; k.M = p.M; k.H = p.H; k.W = p.W; k.nch = p.K / WN_CH;
-    k.tiles_x = (p.W + 31) / 32; k.tiles_y = (p.H + 3) / 4; k.n_mtiles = (p.M + 127) / 128; k.relu = p.relu;
+    k.tiles_x = (p.W + 31) / 32; k.tiles_y = (p.H + prows - 1) / prows; k.n_mtiles = (p.M + bm - 1) / bm; k.relu = p.relu;
     k.in_bytes = (unsigned)(4ull * p.K * p.H * p.W);
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    conv3x3_wino_f32_128x128<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+    if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+    else conv3x3_wino_f32_128x128<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     return hipGetLastError();
 }
+
+hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s) { return launch_conv3x3_wino_cfg(p, -1, s); }
 
 }  // namespace st2

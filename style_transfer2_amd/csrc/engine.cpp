@@ -1600,7 +1600,7 @@ int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops)
 
 int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int depth, double* tflops)
 {
-    if (!tflops || blocks_per_cu <= 0 || K < 8 || K % 8 || M < 128 || M % 128 || (depth != 1 && depth != 2 && depth != 4))
+    if (!tflops || blocks_per_cu <= 0 || K < 8 || K % 8 || M < 128 || M % 128 || (depth != 1 && depth != 2 && depth != 4 && depth != 12))
         return fail(ST_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(device_id));
     const int blocks = 256 * blocks_per_cu, nkp = K / 2, n_mt = M / 128;
@@ -1640,7 +1640,7 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
     for (auto& x : w) x = rnd() * 0.05f;
     for (auto& x : hin) x = rnd();
-    const bool wino = cfg == 100;
+    const bool wino = cfg >= 100;      // 100: choose, 101: 128 ch x 4x32 px, 102: 64 ch x 8x32 px
     if (wino) {
         if (!conv_wino_ok(K, M, H, W)) return fail(ST_ERR_ARG, "shape not eligible for the Winograd kernel");
         pk.assign(wino_pack_floats(K, M), 0.f);
@@ -1670,7 +1670,7 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     if (cfg == 6) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
     hipStream_t s;
     HIP_TRY(hipStreamCreate(&s));
-    auto launch = [&]() { return wino ? launch_conv3x3_wino(p, s) : launch_conv3x3_cfg(p, cfg, s); };
+    auto launch = [&]() { return wino ? launch_conv3x3_wino_cfg(p, cfg - 101, s) : launch_conv3x3_cfg(p, cfg, s); };
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     int rc = ST_OK;

@@ -3,6 +3,8 @@ against the direct implicit-GEMM kernel.  Winograd computes the same fp32 produc
 association (input / filter / output transforms), so the bar is a relative L2 error, stated per test:
 1e-5 forward, 3e-5 data gradient -- the same bars the direct kernel is held to (test_gpu_parity.py)."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -14,11 +16,27 @@ pytestmark = pytest.mark.gpu
 F32 = np.float32
 
 
+@pytest.fixture(params=['auto', '0', '1'])
+def wino_cfg(request):
+    """ST2_WINO_CFG: 0 = 128 channels x 4x32 pixels per workgroup, 1 = 64 channels x 8x32 pixels, unset = chosen by shape"""
+    old = os.environ.get('ST2_WINO_CFG')
+    if request.param == 'auto':
+        os.environ.pop('ST2_WINO_CFG', None)
+    else:
+        os.environ['ST2_WINO_CFG'] = request.param
+    yield request.param
+    if old is None:
+        os.environ.pop('ST2_WINO_CFG', None)
+    else:
+        os.environ['ST2_WINO_CFG'] = old
+
+
 @pytest.mark.parametrize('cin,cout,h,w', [
     (8, 96, 4, 32), (8, 128, 6, 8), (16, 128, 9, 36), (64, 128, 17, 32), (72, 200, 5, 64), (128, 128, 40, 72),
-    (128, 256, 12, 12), (256, 256, 7, 44), (256, 512, 8, 8), (512, 512, 6, 4), (64, 160, 33, 100), (128, 128, 64, 96)])
-def test_winograd_conv_forward_and_dgrad(cin, cout, h, w):
-    """conv1_2 (cin -> cout) runs the Winograd kernel forward (M = cout >= 96) and, when cin >= 96, backward."""
+    (128, 256, 12, 12), (256, 256, 7, 44), (256, 512, 8, 8), (512, 512, 6, 4), (64, 160, 33, 100), (128, 128, 64, 96),
+    (64, 64, 19, 40), (8, 48, 3, 4), (64, 64, 64, 96)])
+def test_winograd_conv_forward_and_dgrad(cin, cout, h, w, wino_cfg):
+    """conv1_2 (cin -> cout) runs the Winograd kernel forward (M = cout >= 48) and, when cin >= 48, backward."""
     topo = (('conv', 'conv1_1', 3, cin), ('conv', 'conv1_2', cin, cout))
     params = oracle.he_init_weights(topo, seed=cin + cout, bias_std=0.2)
     cpu = oracle.NetOracle(topo, params)
@@ -40,7 +58,7 @@ def test_winograd_conv_forward_and_dgrad(cin, cout, h, w):
     assert rel_l2(gg, gc) <= 3e-5, rel_l2(gg, gc)
 
 
-def test_winograd_chain_with_masks_and_injections():
+def test_winograd_chain_with_masks_and_injections(wino_cfg):
     """Winograd dgrad epilogue: ReLU mask from the blob below, injected diffs, pools in between."""
     topo = (('conv', 'conv1_1', 3, 96), ('conv', 'conv1_2', 96, 128), ('pool', 'pool1'),
             ('conv', 'conv2_1', 128, 128), ('conv', 'conv2_2', 128, 192))

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from style_transfer2_amd import capi
 lib = capi.load_library()
 for K, M in ((512, 512), (256, 256), (128, 128)):
-    for depth in (1, 2, 4):
+    for depth in (1, 2, 12):
         for bpc in (2, 4):
             tf = ctypes.c_double()
             rc = lib.st_bench_wino_probe(0, bpc, K, M, depth, ctypes.byref(tf))
