@@ -114,12 +114,17 @@ def main():
 
     if rank == 0:
         its = world * args.steps / elapsed
-        conv = [prof.get('conv3x3_fwd_mfma_f32'), prof.get('conv3x3_dgrad_mfma_f32')]
-        conv = [c for c in conv if c]
+        # the dominant kernel = every conv3x3 launch on the matrix cores (direct implicit GEMM and Winograd F(2x2,3x3));
+        # `flops` are ALGORITHMIC (direct-convolution: 2*9*Cin*Cout*H*W per launch) for both; the Winograd
+        # launches execute 4/9 of them on the MFMA pipe, which `executed` accounts for.
+        direct = [prof[k] for k in ('conv3x3_fwd_mfma_f32', 'conv3x3_dgrad_mfma_f32') if k in prof]
+        wino = [prof[k] for k in ('conv3x3_fwd_wino_f32', 'conv3x3_dgrad_wino_f32') if k in prof]
+        conv = direct + wino
         flops = sum(c['flops'] for c in conv)
         ms = sum(c['ms'] for c in conv)
         launches = sum(c['launches'] for c in conv)
         achieved = flops / (ms * 1e-3) / 1e12 if ms else 0.0
+        executed = (sum(c['flops'] for c in direct) + sum(c['flops'] for c in wino) * 4.0 / 9.0) / (ms * 1e-3) / 1e12 if ms else 0.0
         total_ms = sum(v['ms'] for v in prof.values())
         # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command
         # (FETCH_SIZE doubled for wide loads, WRITE_SIZE exact: tools/pmc_traffic.py); null when absent.
@@ -128,7 +133,7 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
         if args.size == 1024 and args.precision == 'fp32' and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath))['_conv3x3_mfma_f32_all']['hbm_bytes_per_launch']
+                traffic = json.load(open(tpath))['_conv3x3_all']['hbm_bytes_per_launch']
             except (KeyError, ValueError):
                 traffic = None
         out = {
@@ -141,9 +146,13 @@ def main():
                                    'layers, %s %s, %d iterations per image' % (args.size, args.size, args.optimizer,
                                                                                 args.precision, ITERS_PER_IMAGE),
                        'jobs': world, 'parallelism': 'independent jobs, 1 per GPU, no collective'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3_mfma_%s (forward + dgrad launches)' % ('f32' if args.precision == 'fp32' else 'bf16'),
+            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3 on the %s matrix cores (forward + dgrad launches; %d of %d launches Winograd F(2x2,3x3))'
+                                   % ('f32' if args.precision == 'fp32' else 'bf16', sum(c['launches'] for c in wino), launches),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
+                         'executed': executed, 'executed_frac': executed / peak,
+                         'note': 'achieved = algorithmic direct-conv flops / kernel time, so frac can exceed 1 where Winograd '
+                                 'runs; executed = flops the MFMA pipe actually performs (Winograd: 4/9 of algorithmic)',
                          'flops_per_launch': flops / launches if launches else 0.0,
                          'avg_launch_ms': ms / launches if launches else 0.0,
                          'share_of_step': ms / total_ms if total_ms else 0.0},

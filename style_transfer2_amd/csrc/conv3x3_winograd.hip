@@ -8,11 +8,13 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include "st2_kernels.h"
 
 namespace st2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // U layout: [m32][kpair][posgroup 4][lane 64][4 floats]; one wave-load (dwordx4) = 1 KB contiguous
 template <int DEPTH, int ROT>
@@ -74,6 +76,59 @@ __global__ __launch_bounds__(256, 1) void wino_probe_k(const float4* __restrict_
     out[(size_t)blockIdx.x * 256 + threadIdx.x] = r;
 }
 
+// Issue-rate probe: one wave per SIMD (256 accumulators), 16 independent MFMAs per iteration with register operands,
+// NAUX independent VALU / NLDS ds_read instructions pinned after each; reports shader cycles per MFMA.
+template <int NAUX, int NLDS>
+__global__ __launch_bounds__(256, 1) void wino_issue_probe_k(float* out, unsigned long long* cycles, int iters, float seed)
+{
+    __shared__ float lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = seed + i;
+    __syncthreads();
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+    float a0 = seed + threadIdx.x * 1e-3f, b0 = 1.f - a0;
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = seed * (j + 1);
+    float ld[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* lp = lds + (threadIdx.x & 63);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[p], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NAUX; ++j) x[j & 7] = x[j & 7] * 1.0001f + seed;
+#pragma unroll
+            for (int j = 0; j < NLDS; ++j) ld[j & 3] += lp[(p * 4 + j) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r += acc[p][e];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r += x[j];
+    r += ld[0] + ld[1] + ld[2] + ld[3];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = r;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+hipError_t launch_wino_issue_probe(int naux, int nlds, float* out, unsigned long long* cycles, int blocks, int iters, hipStream_t s)
+{
+#define ST2_IP(A, L) if (naux == A && nlds == L) { wino_issue_probe_k<A, L><<<blocks, 256, 0, s>>>(out, cycles, iters, 0.37f); return hipGetLastError(); }
+    ST2_IP(0, 0) ST2_IP(2, 0) ST2_IP(4, 0) ST2_IP(8, 0) ST2_IP(12, 0) ST2_IP(0, 2) ST2_IP(0, 4) ST2_IP(4, 2) ST2_IP(4, 4)
+#undef ST2_IP
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_wino_probe(const float* U, float* out, int blocks, int nkp, int n_mt, int depth, hipStream_t s)
 {
     if (nkp <= 0 || nkp % 4 != 0) return hipErrorInvalidValue;
@@ -103,7 +158,7 @@ hipError_t launch_wino_probe(const float* U, float* out, int blocks, int nkp, in
 // which is why the kernel runs one wave per SIMD and everything below is software-pipelined by hand.
 //   U (host-transformed weights) never touches LDS: it is packed in MFMA A-operand order
 //       [m/32][k/2][pos/4][lane][pos%4]   (lane&31 -> m, lane>>5 -> k parity)
-//     and streamed L2 -> VGPR with global_load_dwordx4, two k-pairs ahead (16 B/clk/CU; the blocks that share
+//     and streamed L2 -> VGPR with global_load_dwordx4, four k-pairs (one chunk) ahead (16 B/clk/CU; the blocks that share
 //     an XCD walk the same 128-channel slice in step, so the stream is served by that XCD's L2);
 //   raw activations: LDS-DMA, 8 channels x 6 rows x 40 floats per chunk (zero fill outside the image = padding),
 //     double-buffered, issued two chunks ahead;
@@ -150,6 +205,7 @@ struct WinoKArgs {
     const float* mask_src; const float* inject;
     int K, M, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
     unsigned in_bytes;
+    unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -161,7 +217,7 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 //   <4,1>: 128 channels x  4 rows x 32 columns      <2,2>: 64 channels x 8 rows x 32 columns
 // With TG = 2 the two waves that share a channel slice load the same U lines together (one L2 fetch), and every
 // thread transforms two (tile, channel) pairs per chunk.
-template <int WM, int TG>
+template <int WM, int TG, int DIAG = 0>
 __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
     static_assert(WM * TG == 4 && (TG == 1 || TG == 2), "4 waves");
@@ -218,41 +274,72 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         }
     };
 
-    // input transform: this thread owns tile xt of channel xch, in every tile group, of every chunk
+    // input transform: this thread owns tile xt of channel xch, in every tile group, of every chunk.
+    // V image of one (chunk, tile group): [k-pair 4][pos/4][k parity * 32 + tile][pos%4] -- the B operands of four
+    // positions are one ds_read_b128, a transformed row is one ds_write_b128.
     const int xt = tid & 31, xch = tid >> 5;
     const int x_raw = xch * PLANE + (2 * (xt >> 4)) * WN_IW + 2 * (xt & 15) + 3;          // column 3 = pixel x0 - 1
-    const int x_v = ((xch >> 1) * 16) * 64 + (xch & 1) * 32 + xt;
-    float d[TG][16], wv[TG][16];
-    // unit u of the three transform phases (each unit = 4 instructions), u in [0, NU) / [0, 2 NU) / [0, NU)
-    auto xf_read = [&](const float* rp, int u) {
-        const int g = u >> 2, i = u & 3;
+    const int x_v = (((xch >> 1) * 4) * 64 + (xch & 1) * 32 + xt) * 4;
+    float d[TG][16];
+    // Empty asm with the 16 values as in/out operands: arithmetic on them cannot be scheduled across it, which is
+    // what keeps the transform inside its clump (sched_barrier alone orders only instructions with side effects).
+    auto pin = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[g][4 * i + j] = rp[(4 * g + i) * WN_IW + j];
-    };
-    auto xf_math = [&](int u) {
-        const int g = u >> 3, h = u & 7;
-        if (h < 4) {
-            const int j = h;
-            wv[g][j] = d[g][j] - d[g][8 + j]; wv[g][4 + j] = d[g][4 + j] + d[g][8 + j];
-            wv[g][8 + j] = d[g][8 + j] - d[g][4 + j]; wv[g][12 + j] = d[g][4 + j] - d[g][12 + j];
-        } else {
-            const int i = h - 4;
-            const float v0 = wv[g][4 * i] - wv[g][4 * i + 2], v1 = wv[g][4 * i + 1] + wv[g][4 * i + 2];
-            const float v2 = wv[g][4 * i + 2] - wv[g][4 * i + 1], v3 = wv[g][4 * i + 1] - wv[g][4 * i + 3];
-            d[g][4 * i] = v0; d[g][4 * i + 1] = v1; d[g][4 * i + 2] = v2; d[g][4 * i + 3] = v3;
+        for (int g = 0; g < TG; ++g) {
+            asm volatile("" : "+v"(d[g][0]), "+v"(d[g][1]), "+v"(d[g][2]), "+v"(d[g][3]), "+v"(d[g][4]), "+v"(d[g][5]), "+v"(d[g][6]), "+v"(d[g][7]));
+            asm volatile("" : "+v"(d[g][8]), "+v"(d[g][9]), "+v"(d[g][10]), "+v"(d[g][11]), "+v"(d[g][12]), "+v"(d[g][13]), "+v"(d[g][14]), "+v"(d[g][15]));
         }
     };
-    auto xf_write = [&](float* vp, int u) {
-        const int g = u >> 2, i = u & 3;
+    auto xf_read = [&](const float* rp) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vp[g * WN_V + (4 * i + j) * 64] = d[g][4 * i + j];
+        for (int g = 0; g < TG; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[g][4 * i + j] = rp[(4 * g + i) * WN_IW + j];
+    };
+    auto xf_math = [&]() {
+#pragma unroll
+        for (int g = 0; g < TG; ++g) {
+            float wv[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wv[j] = d[g][j] - d[g][8 + j]; wv[4 + j] = d[g][4 + j] + d[g][8 + j];
+                wv[8 + j] = d[g][8 + j] - d[g][4 + j]; wv[12 + j] = d[g][4 + j] - d[g][12 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[g][4 * i] = wv[4 * i] - wv[4 * i + 2]; d[g][4 * i + 1] = wv[4 * i + 1] + wv[4 * i + 2];
+                d[g][4 * i + 2] = wv[4 * i + 2] - wv[4 * i + 1]; d[g][4 * i + 3] = wv[4 * i + 1] - wv[4 * i + 3];
+            }
+        }
+    };
+    auto xf_write = [&](float* vp) {
+#pragma unroll
+        for (int g = 0; g < TG; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                *reinterpret_cast<float4*>(vp + g * WN_V + i * 256) = make_float4(d[g][4 * i], d[g][4 * i + 1], d[g][4 * i + 2], d[g][4 * i + 3]);
     };
 
-    const float4* up = a.upack + ((size_t)(mt * WM + wave_m) * nkp) * 256 + lane;
-    auto u_load = [&](int kp, int g) -> float4 {
-        const int kk = kp < nkp ? kp : nkp - 1;                 // tail: a harmless reload
-        return up[((size_t)kk * 4 + g) * 64];
+    const f32x4* up = reinterpret_cast<const f32x4*>(a.upack) + ((size_t)(mt * WM + wave_m) * nkp) * 256 + lane;
+    f32x4 ua[4][4];                     // U ring: set kp % 4 holds k-pair kp, refilled three k-pairs ahead
+    auto u_fill = [&](int kp) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ua[kp & 3][g] = up[((size_t)kp * 4 + g) * 64];
+        asm volatile("" ::: "memory");   // keeps the loads here (no folding into "load at use")
     };
+    // makes the compiler wait for a whole U set at one place (inside a clump) instead of before each group of four MFMAs
+    auto u_pin = [&](int set) {
+        asm volatile("" : "+v"(ua[set][0]), "+v"(ua[set][1]), "+v"(ua[set][2]), "+v"(ua[set][3]));
+    };
+    f32x4 bq[2][4];                     // B operands of two k-pairs, four positions per quad
+    auto b_fetch = [&](const float* vimg, int kpl, int set) {
+#pragma unroll
+        for (int pg = 0; pg < 4; ++pg) bq[set][pg] = *reinterpret_cast<const f32x4*>(vimg + ((kpl * 4 + pg) * 64 + lane) * 4);
+    };
+    // one wait for the rest of a B set (its first quad is awaited by the k-pair's first MFMA) instead of one per quad
+    auto b_pin = [&](int set) { asm volatile("" : "+v"(bq[set][1]), "+v"(bq[set][2]), "+v"(bq[set][3])); };
 
     f32x16 acc[16];
 #pragma unroll
@@ -260,76 +347,73 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
 
-    // ---- prologue: raw chunks 0 and 1, U of k-pairs 0 and 1, V of chunk 0 ----
+    // ---- prologue: raw chunks 0 and 1, U of k-pairs 0..2, V of chunk 0 ----
     dma_raw(0, 0);
     if (a.nch > 1) dma_raw(1, 1);
-    float4 ua[2][4];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) ua[s2][g] = u_load(s2, g);
-    asm volatile("" ::: "memory");
+    u_fill(0); u_fill(1); u_fill(2);
     __syncthreads();
-#pragma unroll
-    for (int u = 0; u < NU; ++u) xf_read(raw_s[0] + x_raw, u);
-#pragma unroll
-    for (int u = 0; u < 2 * NU; ++u) xf_math(u);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) xf_write(&v_s[0][0][0] + x_v, u);
+    xf_read(raw_s[0] + x_raw);
+    xf_math();
+    xf_write(&v_s[0][0][0] + x_v);
     __syncthreads();
-    float bv[2][16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p) bv[0][p] = v_s[0][wave_g][p * 64 + lane];
+    b_fetch(v_s[0][wave_g], 0, 0);
 
-    for (int c = 0; c < a.nch; ++c) {
+    unsigned long long t0 = 0, r0 = 0;
+    if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    // One chunk = 4 k-pairs x 16 MFMAs.  With one wave per SIMD nothing this wave issues overlaps its own MFMAs
+    // (measured: a bare MFMA stream runs at 64.0 cycles each, every instruction in between adds ~3 cycles plus ~9 per
+    // interrupted MFMA pair), so the auxiliary work is kept minimal and CLUMPED: one clump per k-pair, right after
+    // its first MFMA, then 15 MFMAs back to back.
+    //   every clump : B operands of the next k-pair (4 ds_read_b128), U of k-pair +3 (4 global_load_dwordx4)
+    //   k-pair 0    : + raw reads of chunk c+1 (issued, consumed one clump later), raw DMA of chunk c+2
+    //   k-pair 1    : + transform arithmetic        k-pair 2: + V writes
+    //   k-pair 3    : wait own V writes / raw DMA, s_barrier, then the fetch from the next chunk's V image
+    auto chunk = [&](const int c, auto more_t, auto more2_t) {
+        constexpr bool MORE = decltype(more_t)::value, MORE2 = decltype(more2_t)::value;
         const int cur = c & 1;
-        const bool more = c + 1 < a.nch, more2 = c + 2 < a.nch;
-        const float* rp = raw_s[cur ^ 1] + x_raw;
-        float* vp = &v_s[cur ^ 1][0][0] + x_v;
-        const float* bcur = v_s[cur][wave_g] + lane;
-        const float* bnxt = v_s[cur ^ 1][wave_g] + lane;
 #pragma unroll
         for (int kpl = 0; kpl < 4; ++kpl) {
             const int kp = 4 * c + kpl;
             const int set = kpl & 1;
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(ua[set][p >> 2], p & 3), bv[set][p], acc[p], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                // --- U stream: group g of k-pair kp+2 replaces the group the last four MFMAs consumed ---
-                if ((p & 3) == 3) {
-                    ua[set][p >> 2] = u_load(kp + 2, p >> 2);
-                    asm volatile("" ::: "memory");
-                }
-                // --- B operands of the next k-pair (after the chunk barrier when it is the next chunk's first) ---
-                if (kpl < 3) {
-                    if (p >= 1 && p <= 4) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) bv[set ^ 1][4 * (p - 1) + jj] = bcur[((kpl + 1) * 16 + 4 * (p - 1) + jj) * 64];
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[kpl][p >> 2][p & 3], bq[set][p >> 2][p & 3], acc[p], 0, 0, 0);
+                if (p == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    b_pin(set);
+                    if (kpl < 3) b_fetch(v_s[cur][wave_g], kpl + 1, set ^ 1);
+                    else if (MORE) {
+                        // own V writes done (lgkmcnt), own raw DMA landed (the 8 U loads of k-pairs 1 and 2 came after it)
+                        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        b_fetch(v_s[cur ^ 1][wave_g], 0, 0);
                     }
-                } else if (more) {
-                    if (p == 0) {
-                        // own V writes done (lgkmcnt), own raw DMA landed (>= 4 U loads were issued after it), all waves here
-                        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (MORE || kpl == 0) u_fill(kp + 3);
+                    if (MORE) {
+                        if (kpl == 0) xf_read(raw_s[cur ^ 1] + x_raw);
+                        if (kpl == 1) { pin(); xf_math(); pin(); }
+                        if (kpl == 2) xf_write(&v_s[cur ^ 1][0][0] + x_v);
                     }
-                    if (p >= 1 && p <= 4) {
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) bv[0][4 * (p - 1) + jj] = bnxt[(4 * (p - 1) + jj) * 64];
-                    }
+                    if (MORE2 && kpl == 0) dma_raw(c + 2, cur);
+                    if (MORE || kpl < 3) u_pin((kpl + 1) & 3);        // the next k-pair's U (loaded three k-pairs ago)
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // --- input transform of chunk c+1: reads in k-pair 0, arithmetic in 1, writes in 2; raw DMA of chunk c+2 ---
-                if (more) {
-                    if (kpl == 0 && p >= 5 && p < 5 + NU) xf_read(rp, p - 5);
-                    if (kpl == 1 && TG == 1 && p >= 5 && p < 13) xf_math(p - 5);
-                    if (kpl == 1 && TG == 2) xf_math(p);
-                    if (kpl == 2 && p >= 5 && p < 5 + NU) xf_write(vp, p - 5);
-                }
-                if (more2 && kpl == 1 && p == 13) dma_raw(c + 2, cur);
-                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    {
+        using T = std::true_type; using F = std::false_type;
+        int c = 0;
+        for (; c + 2 < a.nch; ++c) chunk(c, T{}, T{});
+        if (c + 1 < a.nch) { chunk(c, T{}, F{}); ++c; }
+        chunk(c, F{}, F{});
     }
 
+    if (DIAG) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && a.stamps) { a.stamps[2 * blockIdx.x] = t1 - t0; a.stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    }
     // ---- epilogue: output transform (in-lane), then bias / ReLU / mask / inject, float2 stores.
     // Four accumulator rows at a time: their mask / inject loads are issued together, ahead of the arithmetic.
     const int t31 = lane & 31, khalf = lane >> 5;
@@ -390,6 +474,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKArgs a) { conv3x3_wino_body<4, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256(const WinoKArgs a) { conv3x3_wino_body<2, 2>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
 
 bool conv_wino_ok(int K, int M, int H, int W)
 {
@@ -407,16 +492,18 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
         const int pad128 = (p.M + 127) / 128 * 128, pad64 = (p.M + 63) / 64 * 64;
         variant = forced >= 0 ? forced : (pad64 < pad128 ? 1 : 0);
     }
-    const int bm = variant == 1 ? 64 : 128, prows = variant == 1 ? 8 : 4;
+    const int bm = variant == 1 ? 64 : 128, prows = variant == 1 ? 8 : 4;       // variant 2: variant 0 with cycle stamps (p.stamps)
     WinoKArgs k{};
     k.in = p.in; k.upack = reinterpret_cast<const float4*>(p.wpack); k.bias = p.bias; k.out = p.out;
     k.mask_src = p.mask_src; k.inject = p.inject;
     k.K = p.K; k.M = p.M; k.H = p.H; k.W = p.W; k.nch = p.K / WN_CH;
     k.tiles_x = (p.W + 31) / 32; k.tiles_y = (p.H + prows - 1) / prows; k.n_mtiles = (p.M + bm - 1) / bm; k.relu = p.relu;
     k.in_bytes = (unsigned)(4ull * p.K * p.H * p.W);
+    k.stamps = p.stamps;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+    if (variant == 2) conv3x3_wino_f32_128x128_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+    else if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     else conv3x3_wino_f32_128x128<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     return hipGetLastError();
 }

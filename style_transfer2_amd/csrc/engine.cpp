@@ -44,10 +44,10 @@ extern "C" const char* st_last_error(void) { return g_err; }
 
 // --------------------------------------------------------------------------------------- profiling
 enum ProfClass { P_CONV_FWD, P_CONV_DGRAD, P_POOL_FWD, P_POOL_BWD, P_GRAM, P_GRAM_REDUCE, P_STYLE_GRAD,
-                 P_LAYER_ELEM, P_IMAGE_PASS, P_FINALIZE, P_VECTOR, P_MISC, P_COUNT };
+                 P_LAYER_ELEM, P_IMAGE_PASS, P_FINALIZE, P_VECTOR, P_MISC, P_CONV_FWD_WINO, P_CONV_DGRAD_WINO, P_COUNT };
 static const char* kProfNames[P_COUNT] = {"conv3x3_fwd_mfma_f32", "conv3x3_dgrad_mfma_f32", "maxpool_fwd", "maxpool_bwd",
                                           "gram_partial_mfma_f32", "gram_reduce", "style_grad_mfma_f32", "layer_elem",
-                                          "image_pass", "finalize", "vector_ops", "misc"};
+                                          "image_pass", "finalize", "vector_ops", "misc", "conv3x3_fwd_wino_f32", "conv3x3_dgrad_wino_f32"};
 struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
 
 // ------------------------------------------------------------------------------------------- types
@@ -273,8 +273,10 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
                 ConvProblem p{};
                 p.in = a.data[i - 1]; p.wpack = L.w_fwd; p.bias = L.bias; p.out = a.data[i];
                 p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
-                { ProfScope ps(c, P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
-                  if (c->wino && L.u_fwd && conv_wino_ok(p.K, p.M, p.H, p.W)) { p.wpack = L.u_fwd; HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
+                { const bool wino = c->wino && L.u_fwd && conv_wino_ok(p.K, p.M, p.H, p.W);
+                  // flops are the ALGORITHMIC (direct-convolution) count in both classes; Winograd executes 4/9 of them
+                  ProfScope ps(c, wino ? P_CONV_FWD_WINO : P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
+                  if (wino) { p.wpack = L.u_fwd; HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
                   else HIP_TRY(launch_conv3x3(p, c->stream)); }
                 if (next16) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
             }
@@ -347,8 +349,10 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
         const float* inject = inj[below];
         if (L.is_conv) {
             const double px = (double)a.h[i] * a.w[i];
-            ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
-            if (!mask_src && conv_dgrad_smallM_ok(L.cout, L.cin)) {
+            const bool small_m = !mask_src && conv_dgrad_smallM_ok(L.cout, L.cin);
+            const bool wino_bwd = !small_m && !(c->bf16 && conv16_ok(c, L.cout)) && c->wino && L.u_bwd && conv_wino_ok(L.cout, L.cin, a.h[i], a.w[i]);
+            ProfScope ps(c, wino_bwd ? P_CONV_DGRAD_WINO : P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
+            if (small_m) {
                 HIP_TRY(launch_conv3x3_dgrad_smallM(cur, L.w_raw, dst, inject, L.cout, L.cin, a.h[i], a.w[i], c->stream));
                 cur16 = nullptr;
             } else if (c->bf16 && conv16_ok(c, L.cout)) {
@@ -373,7 +377,7 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
                 p.in = cur; p.wpack = L.w_bwd; p.bias = nullptr; p.out = dst;
                 p.mask_src = mask_src; p.inject = inject;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
-                if (c->wino && L.u_bwd && conv_wino_ok(p.K, p.M, p.H, p.W)) { p.wpack = L.u_bwd; HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
+                if (wino_bwd) { p.wpack = L.u_bwd; HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
                 else HIP_TRY(launch_conv3x3(p, c->stream));
             }
         } else {
@@ -1598,12 +1602,38 @@ int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops)
     return ST_OK;
 }
 
+int st_bench_issue_probe(int device_id, int naux, int nlds, double* cycles_per_mfma)
+{
+    if (!cycles_per_mfma) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device_id));
+    const int blocks = 256, iters = 20000;
+    float* out = nullptr;
+    unsigned long long* cyc = nullptr;
+    ST_TRY(dmalloc(&out, (size_t)blocks * 256));
+    HIP_TRY(hipMalloc((void**)&cyc, blocks * sizeof(unsigned long long)));
+    hipStream_t s;
+    HIP_TRY(hipStreamCreate(&s));
+    int rc = ST_OK;
+    for (int i = 0; i < 2 && rc == ST_OK; ++i)
+        if (launch_wino_issue_probe(naux, nlds, out, cyc, blocks, iters, s) != hipSuccess) rc = fail(ST_ERR_ARG, "no such probe variant");
+    if (rc == ST_OK) {
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(blocks);
+        HIP_TRY(hipMemcpy(h.data(), cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        *cycles_per_mfma = (double)h[blocks / 2] / ((double)iters * 16.0);
+    }
+    (void)hipStreamDestroy(s);
+    dfree(out); (void)hipFree(cyc);
+    return rc;
+}
+
 int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int depth, double* tflops)
 {
-    if (!tflops || blocks_per_cu <= 0 || K < 8 || K % 8 || M < 128 || M % 128 || (depth != 1 && depth != 2 && depth != 4 && depth != 12))
+    if (!tflops || blocks_per_cu == 0 || K < 8 || K % 8 || M < 128 || M % 128 || (depth != 1 && depth != 2 && depth != 4 && depth != 12))
         return fail(ST_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(device_id));
-    const int blocks = 256 * blocks_per_cu, nkp = K / 2, n_mt = M / 128;
+    const int blocks = blocks_per_cu > 0 ? 256 * blocks_per_cu : -blocks_per_cu, nkp = K / 2, n_mt = M / 128;   // < 0: absolute block count
     const size_t n_u = (size_t)(M / 32) * nkp * 256 * 4;
     float *out = nullptr, *U = nullptr;
     ST_TRY(dmalloc(&out, (size_t)blocks * 256)); ST_TRY(dmalloc(&U, n_u));
@@ -1667,7 +1697,7 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     if (cfg_used) *cfg_used = cfg;
     unsigned long long* dstamps = nullptr;
     const size_t max_blocks = (size_t)((W + 31) / 32) * ((H + 3) / 4) * (p.MPad / 64);
-    if (cfg == 6) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
+    if (cfg == 6 || cfg == 103) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
     hipStream_t s;
     HIP_TRY(hipStreamCreate(&s));
     auto launch = [&]() { return wino ? launch_conv3x3_wino_cfg(p, cfg - 101, s) : launch_conv3x3_cfg(p, cfg, s); };
@@ -1691,7 +1721,7 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
             if (!cyc.empty()) {
                 std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
                 fprintf(stderr, "[stamps] blocks=%zu loop cycles median=%.0f (min %.0f max %.0f) in-kernel clock median=%.3f GHz; chunks=%d -> %.0f cycles/chunk\n",
-                        cyc.size(), cyc[cyc.size() / 2], cyc.front(), cyc.back(), clk[clk.size() / 2], (K + 3) / 4, cyc[cyc.size() / 2] / ((K + 3) / 4));
+                        cyc.size(), cyc[cyc.size() / 2], cyc.front(), cyc.back(), clk[clk.size() / 2], wino ? K / 8 : (K + 3) / 4, cyc[cyc.size() / 2] / (wino ? K / 8 : (K + 3) / 4));
             }
         }
     }

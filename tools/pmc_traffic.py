@@ -30,16 +30,16 @@ for name in sorted(set(fetch) | set(write)):
     n = fetch[name][0] or write[name][0]
     rd = fetch[name][1] * 1024 / max(1, fetch[name][0])
     wr = write[name][1] * 1024 / max(1, write[name][0])
-    wide = ('mfma' in name) or ('rocclr' in name)          # dwordx4 / LDS-DMA x4 readers
+    wide = ('mfma' in name) or ('wino' in name) or ('rocclr' in name)          # dwordx4 / LDS-DMA x4 readers
     rd_corr = rd * (2 if wide else 1)
     out[name] = dict(launches=n, fetch_bytes_per_launch_raw=rd, fetch_bytes_per_launch=rd_corr,
                      write_bytes_per_launch=wr, read_correction='x2 (gfx950 wide loads)' if wide else 'none')
-    if name.startswith('conv3x3_mfma'):
+    if name.startswith('conv3x3_mfma') or name.startswith('conv3x3_wino'):
         conv_n += n; conv_rd += rd_corr * n; conv_wr += wr * n
     print('%-44s n=%-4d read %8.1f MB (raw %8.1f)  write %8.1f MB' % (name[:44], n, rd_corr / 1e6, rd / 1e6, wr / 1e6))
-out['_conv3x3_mfma_f32_all'] = dict(launches=conv_n, hbm_bytes_per_launch=(conv_rd + conv_wr) / max(1, conv_n),
+out['_conv3x3_all'] = dict(launches=conv_n, hbm_bytes_per_launch=(conv_rd + conv_wr) / max(1, conv_n),
                                     read_bytes_per_launch=conv_rd / max(1, conv_n), write_bytes_per_launch=conv_wr / max(1, conv_n))
-print('conv3x3 MFMA launches: %.1f MB read + %.1f MB written per launch (avg over %d launches)' % (
+print('conv3x3 matrix-core launches (direct + Winograd): %.1f MB read + %.1f MB written per launch (avg over %d launches)' % (
     conv_rd / max(1, conv_n) / 1e6, conv_wr / max(1, conv_n) / 1e6, conv_n))
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], 'w'), indent=1)

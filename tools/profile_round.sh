@@ -1,0 +1,22 @@
+#!/bin/bash
+# One-shot profiling of the headline bench on the GPU box: kernel-trace stats + the two PMC passes (FETCH_SIZE, WRITE_SIZE).
+# Outputs under gpurun_out/prof_$1/.  Usage: tools/profile_round.sh <tag> [bench args...]
+set -e
+TAG=$1; shift
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $OUT/bench_stats.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_fetch.json 2> $OUT/fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python3 $ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline "$@" > $OUT/bench_write.json 2> $OUT/write.log
+cd $ROOT
+F=$(find $OUT/fetch -name '*counter_collection.csv' | head -1)
+W=$(find $OUT/write -name '*counter_collection.csv' | head -1)
+python3 tools/pmc_traffic.py $F $W $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt
+S=$(find $OUT/stats -name '*kernel_stats.csv' | head -1)
+cp $S $OUT/kernel_stats.csv
+# the raw traces are large: keep the summaries only
+rm -rf $OUT/fetch $OUT/write
+find $OUT/stats -name '*kernel_trace.csv' -delete
