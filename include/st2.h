@@ -156,6 +156,8 @@ int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops)
 /* Winograd operand-feed probe: executed MFMA TFLOP/s with the A operands streamed from L2 (depth = k-pairs in flight) */
 /* issue-rate probe: shader cycles per v_mfma_f32_32x32x2_f32 at one wave per SIMD with naux VALU + nlds ds_read between MFMAs */
 int st_bench_issue_probe(int device_id, int naux, int nlds, double* cycles_per_mfma);
+/* feed probe of the LDS-staged-U Winograd design: shader cycles per k-pair (16 MFMAs = 1024 cycles ideal) */
+int st_bench_lds_feed_probe(int device_id, int extra_dma, int K, int blocks, double* cycles_per_kpair);
 int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int depth, double* tflops);
 int st_conv_num_configs(void);
 const char* st_conv_config_name(int cfg);

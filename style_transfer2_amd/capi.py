@@ -82,6 +82,7 @@ PROTOTYPES = {
     'st_bench_conv': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_int)]),
     'st_bench_mfma': (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
     'st_bench_issue_probe': (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
+    'st_bench_lds_feed_probe': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_double)]),
     'st_bench_wino_probe': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_double)]),
     'st_conv_num_configs': (c_int, []),
     'st_conv_config_name': (c_char_p, [c_int]),

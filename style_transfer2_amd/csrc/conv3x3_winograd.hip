@@ -121,6 +121,93 @@ __global__ __launch_bounds__(256, 1) void wino_issue_probe_k(float* out, unsigne
     if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
+// Feed probe for the LDS-staged U design: 64 channels x 64 tiles per workgroup; per k-pair every wave issues 2 LDS-DMA
+// pieces (its share of the 8-KiB U slab) + EXTRA_DMA more (standing in for the raw activation tile), one barrier,
+// 8 ds_read_b128 (A and B operands of the next k-pair), 16 MFMAs.  Reports shader cycles per k-pair.
+typedef __attribute__((address_space(3))) void* lptr_probe_t;
+template <int EXTRA_DMA>
+__global__ __launch_bounds__(256, 1) void wino_lds_probe_k(const float* __restrict__ U, unsigned u_bytes, float* out,
+                                                           unsigned long long* cycles, int nkp)
+{
+    __shared__ __attribute__((aligned(16))) float u_s[4][2048];
+    __shared__ __attribute__((aligned(16))) float v_s[2][1024];
+    __shared__ __attribute__((aligned(16))) float junk[4][256];
+    for (int i = threadIdx.x; i < 2048; i += 256) (&v_s[0][0])[i] = 0.001f * i;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_m = wave >> 1;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, u_bytes, 0x00020000);
+    const unsigned mt = (blockIdx.x & 7);                      // one 64-channel slab per XCD
+    const unsigned lane_off = (unsigned)lane * 16u;
+    auto dma_u = [&](int kp) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int piece = wave + 4 * t;                    // 8 pieces of 1 KiB: slice = piece / 4, quarter = piece % 4
+            const unsigned src = ((mt * 2 + piece / 4) * (unsigned)nkp + (unsigned)kp) * 4096u + (piece % 4) * 1024u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_probe_t)(u_s[kp & 3] + piece * 256), 16, lane_off, src, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < EXTRA_DMA; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_probe_t)(junk[wave]), 16, lane_off, (unsigned)(kp * 4 + t) * 1024u, 0, 0);
+    };
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+    f32x4 aq[2][4], bq[2][4];
+    dma_u(0); dma_u(1);
+    __syncthreads();
+#pragma unroll
+    for (int pg = 0; pg < 4; ++pg) {
+        aq[0][pg] = *reinterpret_cast<const f32x4*>(&u_s[0][wave_m * 1024 + (pg * 64 + lane) * 4]);
+        bq[0][pg] = *reinterpret_cast<const f32x4*>(&v_s[0][(pg * 64 + lane) * 4]);
+    }
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int kp0 = 0; kp0 < nkp; kp0 += 4) {
+#pragma unroll
+        for (int kpl = 0; kpl < 4; ++kpl) {
+            const int kp = kp0 + kpl, set = kpl & 1;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[set][p >> 2][p & 3], bq[set][p >> 2][p & 3], acc[p], 0, 0, 0);
+                if (p == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                    for (int pg = 0; pg < 4; ++pg) {
+                        aq[set ^ 1][pg] = *reinterpret_cast<const f32x4*>(&u_s[(kpl + 1) & 3][wave_m * 1024 + (pg * 64 + lane) * 4]);
+                        bq[set ^ 1][pg] = *reinterpret_cast<const f32x4*>(&v_s[set ^ 1][(pg * 64 + lane) * 4]);
+                    }
+                    dma_u(kp + 2 < nkp ? kp + 2 : kp);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    float r = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) r += acc[p][e];
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = r + junk[0][threadIdx.x & 255];
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+hipError_t launch_wino_lds_probe(int extra_dma, const float* U, unsigned u_bytes, float* out, unsigned long long* cycles,
+                                 int blocks, int nkp, hipStream_t s)
+{
+    if (nkp < 4 || nkp % 4) return hipErrorInvalidValue;
+    switch (extra_dma) {
+    case 0: wino_lds_probe_k<0><<<blocks, 256, 0, s>>>(U, u_bytes, out, cycles, nkp); break;
+    case 1: wino_lds_probe_k<1><<<blocks, 256, 0, s>>>(U, u_bytes, out, cycles, nkp); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_wino_issue_probe(int naux, int nlds, float* out, unsigned long long* cycles, int blocks, int iters, hipStream_t s)
 {
 #define ST2_IP(A, L) if (naux == A && nlds == L) { wino_issue_probe_k<A, L><<<blocks, 256, 0, s>>>(out, cycles, iters, 0.37f); return hipGetLastError(); }
@@ -204,7 +291,7 @@ struct WinoKArgs {
     const float* in; const float4* upack; const float* bias; float* out;
     const float* mask_src; const float* inject;
     int K, M, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
-    unsigned in_bytes;
+    unsigned in_bytes, u_bytes;
     unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
 };
 
@@ -472,6 +559,237 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     }
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// Two waves per SIMD: 8 waves = 2 channel slices (32) x 2 tile groups (32 tiles) x 2 POSITION HALVES.
+// A wave keeps 8 of the 16 positions of its 32x32 accumulator block (128 AGPRs), so two waves fit on a SIMD and one
+// wave's operand fetches, DMA issue, transform arithmetic and barrier waits run under the other's MFMAs (with one
+// wave per SIMD nothing overlaps the wave's own MFMAs).  Workgroup tile: 64 channels x (8 rows x 32 columns).
+//   U: staged ONCE per workgroup in LDS by LDS-DMA (8 KiB per k-pair, one 1-KiB piece per wave, 4-stage ring) and
+//      read by the four waves that share the slice: 11 KiB of vector-memory ingest per k-pair instead of 18;
+//   raw / V / transform: as above, one (tile, channel) pair per thread per chunk;
+//   one `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier` per k-pair (8 MFMAs per wave) orders every LDS producer/consumer;
+//   epilogue: the output transform is linear in the positions, so each half finishes partial outputs, the halves
+//   swap one output row through LDS and each stores one of the two rows of every tile.
+template <int DIAG>
+__device__ __forceinline__ void conv3x3_wino2_body(const WinoKArgs& a)
+{
+    constexpr int PROWS = 8, IN_ROWS = PROWS + 2, PLANE = IN_ROWS * WN_IW, N_RAW = WN_CH * PLANE;
+    constexpr int RAW = 4096;                            // 16 wave-DMAs of 64 quads (3200 floats used)
+    constexpr int U_STAGE = 2048;                        // floats per U stage: 2 slices x [4][64][4]
+    __shared__ __attribute__((aligned(16))) float lds[2 * RAW + 4 * WN_V + 4 * U_STAGE];     // 128 KiB
+    float* const raw_s = lds;                            // [2][RAW]
+    float* const v_s = lds + 2 * RAW;                    // [2][tile group 2][WN_V]
+    float* const u_s = lds + 2 * RAW + 4 * WN_V;         // [4][U_STAGE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ph = wave & 1, tg = (wave >> 1) & 1, wm = wave >> 2;
+
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int n_pt = a.tiles_x * a.tiles_y;
+    const int mt = logical / n_pt;
+    const int pt = logical - mt * n_pt;
+    const int tx = pt % a.tiles_x;
+    const int ty = pt / a.tiles_x;
+    const int y0 = ty * PROWS, x0 = tx * 32;
+    const unsigned plane = (unsigned)a.H * a.W;
+    const int nkp = a.K >> 1;
+
+    const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)a.upack, 0, a.u_bytes, 0x00020000);
+    unsigned ioff[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int e = ((wave + 8 * t) * 64 + lane) * 4;
+        const int c = e / PLANE;
+        const int rem = e - c * PLANE;
+        const int rr = rem / WN_IW;
+        const int col = rem - rr * WN_IW;
+        const int gy = y0 - 1 + rr, gx = x0 - 4 + col;
+        const bool ok = e < N_RAW && gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W;
+        ioff[t] = ok ? ((unsigned)c * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
+    }
+    auto dma_raw = [&](int ch, int buf) {
+        const unsigned coff = (unsigned)ch * WN_CH * plane * 4u;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + coff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s + buf * RAW + (wave + 8 * t) * 256), 16, vo, 0, 0, 0);
+        }
+    };
+    // U piece of this wave: slice = wave / 4, quarter (pos / 4) = wave % 4; pack = [m/32][k/2][pos/4][lane][4]
+    const unsigned u_voff = (unsigned)lane * 16u + ((unsigned)(mt * 2 + (wave >> 2)) * (unsigned)nkp) * 4096u + (unsigned)(wave & 3) * 1024u;
+    auto dma_u = [&](int kp, int stage) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lptr_t)(u_s + stage * U_STAGE + wave * 256), 16, u_voff, (unsigned)kp * 4096u, 0, 0);
+    };
+
+    const int xt = tid & 31, xch = (tid >> 5) & 7, xg = tid >> 8;
+    const int x_raw = xch * PLANE + (4 * xg + 2 * (xt >> 4)) * WN_IW + 2 * (xt & 15) + 3;
+    const int x_v = xg * WN_V + (((xch >> 1) * 4) * 64 + (xch & 1) * 32 + xt) * 4;
+    float d[16];
+    auto xf_read = [&](const float* rp) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[4 * i + j] = rp[i * WN_IW + j];
+    };
+    auto xf_math = [&]() {
+        float wv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wv[j] = d[j] - d[8 + j]; wv[4 + j] = d[4 + j] + d[8 + j];
+            wv[8 + j] = d[8 + j] - d[4 + j]; wv[12 + j] = d[4 + j] - d[12 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[4 * i] = wv[4 * i] - wv[4 * i + 2]; d[4 * i + 1] = wv[4 * i + 1] + wv[4 * i + 2];
+            d[4 * i + 2] = wv[4 * i + 2] - wv[4 * i + 1]; d[4 * i + 3] = wv[4 * i + 1] - wv[4 * i + 3];
+        }
+    };
+    auto xf_write = [&](float* vp) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<float4*>(vp + i * 256) = make_float4(d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]);
+    };
+
+    f32x4 aq[2][2], bq[2][2];           // operands of two k-pairs: this wave's 8 positions = 2 quads
+    auto fetch = [&](int stage, const float* vimg, int kpl, int set) {
+#pragma unroll
+        for (int qd = 0; qd < 2; ++qd) {
+            aq[set][qd] = *reinterpret_cast<const f32x4*>(u_s + stage * U_STAGE + wm * 1024 + ((2 * ph + qd) * 64 + lane) * 4);
+            bq[set][qd] = *reinterpret_cast<const f32x4*>(vimg + tg * WN_V + ((kpl * 4 + 2 * ph + qd) * 64 + lane) * 4);
+        }
+    };
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+
+    dma_raw(0, 0);
+    if (a.nch > 1) dma_raw(1, 1);
+    dma_u(0, 0); dma_u(1, 1); dma_u(2, 2);
+    __syncthreads();
+    xf_read(raw_s + x_raw);
+    xf_math();
+    xf_write(v_s + x_v);
+    __syncthreads();
+    fetch(0, v_s, 0, 0);
+
+    unsigned long long t0 = 0, r0 = 0;
+    if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+
+    auto chunk = [&](const int c, auto more_t, auto more2_t) {
+        constexpr bool MORE = decltype(more_t)::value, MORE2 = decltype(more2_t)::value;
+        const int cur = c & 1;
+#pragma unroll
+        for (int kpl = 0; kpl < 4; ++kpl) {
+            const int kp = 4 * c + kpl;
+            const int set = kpl & 1;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[set][p >> 2][p & 3], bq[set][p >> 2][p & 3], acc[p], 0, 0, 0);
+                if (p == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    // Everything this wave issued up to the clump before the previous one has landed (the previous clump's
+                    // DMAs -- 1 U piece, after k-pair 0 also 2 raw pieces -- may still fly), its LDS writes are done, and all
+                    // eight waves are here: U of k-pair kp+1 (issued two k-pairs ago), V of the next chunk, raw of c+2.
+                    if (kpl == 1 && MORE2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (kpl < 3) fetch((kpl + 1) & 3, v_s + cur * 2 * WN_V, kpl + 1, set ^ 1);
+                    else if (MORE) fetch(0, v_s + (cur ^ 1) * 2 * WN_V, 0, 0);
+                    if (MORE || kpl == 0) dma_u(kp + 3, (kpl + 3) & 3);      // that stage held k-pair kp-1, consumed two barriers ago
+                    if (MORE) {
+                        if (kpl == 0) xf_read(raw_s + (cur ^ 1) * RAW + x_raw);
+                        if (kpl == 1) xf_math();
+                        if (kpl == 2) xf_write(v_s + (cur ^ 1) * 2 * WN_V + x_v);
+                    }
+                    if (MORE2 && kpl == 0) dma_raw(c + 2, cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    {
+        using T = std::true_type; using F = std::false_type;
+        int c = 0;
+        for (; c + 2 < a.nch; ++c) chunk(c, T{}, T{});
+        if (c + 1 < a.nch) { chunk(c, T{}, F{}); ++c; }
+        chunk(c, F{}, F{});
+    }
+    if (DIAG) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && a.stamps) { a.stamps[2 * blockIdx.x] = t1 - t0; a.stamps[2 * blockIdx.x + 1] = r1 - r0; }
+    }
+
+    // ---- epilogue.  Partial output transform over this wave's positions (pos = 4 xi + nu; xi = 2 ph + p / 4, nu = p % 4):
+    //   A^T = [1 1 1 0; 0 1 -1 -1]  ->  ph 0: tt0 = S0 + S1, tt1 = S1;   ph 1: tt0 = S2, tt1 = -S2 - S3
+    // The wave keeps output row i = ph and hands row 1 - ph to its partner (wave ^ 1) through LDS.
+    __syncthreads();                                     // everyone is done with the staged tiles: LDS is free
+    float keep[16][2];
+    float* const xs = lds + wave * 2048 + lane;          // [e * 2 + j][64 lanes]
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float t0v[4], t1v[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            if (ph == 0) { t0v[nu] = acc[nu][e] + acc[4 + nu][e]; t1v[nu] = acc[4 + nu][e]; }
+            else { t0v[nu] = acc[nu][e]; t1v[nu] = -acc[nu][e] - acc[4 + nu][e]; }
+        }
+        const float y00 = t0v[0] + t0v[1] + t0v[2], y01 = t0v[1] - t0v[2] - t0v[3];
+        const float y10 = t1v[0] + t1v[1] + t1v[2], y11 = t1v[1] - t1v[2] - t1v[3];
+        keep[e][0] = ph == 0 ? y00 : y10; keep[e][1] = ph == 0 ? y01 : y11;
+        xs[(2 * e) * 64] = ph == 0 ? y10 : y00; xs[(2 * e + 1) * 64] = ph == 0 ? y11 : y01;
+    }
+    __syncthreads();
+    const float* const xr = lds + (wave ^ 1) * 2048 + lane;
+    const int t31 = lane & 31, khalf = lane >> 5;
+    const int gy = y0 + 4 * tg + 2 * (t31 >> 4) + ph, gx = x0 + 2 * (t31 & 15);
+    const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
+    if (gx >= a.W || gy >= a.H) return;
+    const int mw = mt * 64 + wm * 32 + 4 * khalf;
+    const unsigned pix = (unsigned)gy * a.W + gx;
+#pragma unroll
+    for (int eb = 0; eb < 4; ++eb) {
+        const int mb = mw + 8 * eb;
+        unsigned off[4];
+        float2 mk[4], ij[4], part[4];
+        float bs[4];
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int m = mb + ee < a.M ? mb + ee : a.M - 1;
+            off[ee] = (unsigned)m * plane + pix;
+            bs[ee] = has_bias ? a.bias[m] : 0.f;
+            part[ee] = make_float2(xr[(2 * (4 * eb + ee)) * 64], xr[(2 * (4 * eb + ee) + 1) * 64]);
+        }
+        if (has_mask) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) mk[ee] = *reinterpret_cast<const float2*>(a.mask_src + off[ee]);
+        }
+        if (has_inj) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) ij[ee] = *reinterpret_cast<const float2*>(a.inject + off[ee]);
+        }
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            float o0 = keep[4 * eb + ee][0] + part[ee].x + bs[ee];
+            float o1 = keep[4 * eb + ee][1] + part[ee].y + bs[ee];
+            if (a.relu) { o0 = o0 > 0.f ? o0 : 0.f; o1 = o1 > 0.f ? o1 : 0.f; }
+            if (has_mask) { o0 = mk[ee].x > 0.f ? o0 : 0.f; o1 = mk[ee].y > 0.f ? o1 : 0.f; }
+            if (has_inj) { o0 += ij[ee].x; o1 += ij[ee].y; }
+            if (mb + ee < a.M) *reinterpret_cast<float2*>(a.out + off[ee]) = make_float2(o0, o1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_64x256_2w(const WinoKArgs a) { conv3x3_wino2_body<0>(a); }
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_64x256_2w_stamped(const WinoKArgs a) { conv3x3_wino2_body<1>(a); }
+
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKArgs a) { conv3x3_wino_body<4, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256(const WinoKArgs a) { conv3x3_wino_body<2, 2>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
@@ -492,17 +810,23 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
         const int pad128 = (p.M + 127) / 128 * 128, pad64 = (p.M + 63) / 64 * 64;
         variant = forced >= 0 ? forced : (pad64 < pad128 ? 1 : 0);
     }
-    const int bm = variant == 1 ? 64 : 128, prows = variant == 1 ? 8 : 4;       // variant 2: variant 0 with cycle stamps (p.stamps)
+    // variants: 0 = 128 ch x 4x32 px (one wave/SIMD), 1 = 64 ch x 8x32 px (one wave/SIMD), 2 = 0 with cycle stamps,
+    //           3 = 64 ch x 8x32 px, two waves/SIMD with U staged in LDS, 4 = 3 with cycle stamps
+    const bool small = variant == 1 || variant >= 3;
+    const int bm = small ? 64 : 128, prows = small ? 8 : 4;
     WinoKArgs k{};
     k.in = p.in; k.upack = reinterpret_cast<const float4*>(p.wpack); k.bias = p.bias; k.out = p.out;
     k.mask_src = p.mask_src; k.inject = p.inject;
     k.K = p.K; k.M = p.M; k.H = p.H; k.W = p.W; k.nch = p.K / WN_CH;
     k.tiles_x = (p.W + 31) / 32; k.tiles_y = (p.H + prows - 1) / prows; k.n_mtiles = (p.M + bm - 1) / bm; k.relu = p.relu;
     k.in_bytes = (unsigned)(4ull * p.K * p.H * p.W);
+    k.u_bytes = (unsigned)(4ull * wino_pack_floats(p.K, p.M));
     k.stamps = p.stamps;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (variant == 2) conv3x3_wino_f32_128x128_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+    if (variant == 3) conv3x3_wino_f32_64x256_2w<<<dim3((unsigned)nblk), dim3(512), 0, s>>>(k);
+    else if (variant == 4) conv3x3_wino_f32_64x256_2w_stamped<<<dim3((unsigned)nblk), dim3(512), 0, s>>>(k);
+    else if (variant == 2) conv3x3_wino_f32_128x128_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     else if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     else conv3x3_wino_f32_128x128<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     return hipGetLastError();

@@ -1602,6 +1602,34 @@ int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops)
     return ST_OK;
 }
 
+int st_bench_lds_feed_probe(int device_id, int extra_dma, int K, int blocks, double* cycles_per_kpair)
+{
+    if (!cycles_per_kpair || K < 8 || K % 8 || blocks <= 0) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device_id));
+    const int nkp = K / 2;
+    const size_t n_u = (size_t)16 * nkp * 1024;             // 8 slabs of 2 x 32 channels
+    float *out = nullptr, *U = nullptr;
+    unsigned long long* cyc = nullptr;
+    ST_TRY(dmalloc(&out, (size_t)blocks * 256)); ST_TRY(dmalloc(&U, n_u));
+    HIP_TRY(hipMemset(U, 0x3c, n_u * 4));
+    HIP_TRY(hipMalloc((void**)&cyc, blocks * sizeof(unsigned long long)));
+    hipStream_t s;
+    HIP_TRY(hipStreamCreate(&s));
+    int rc = ST_OK;
+    for (int i = 0; i < 20 && rc == ST_OK; ++i)
+        if (launch_wino_lds_probe(extra_dma, U, (unsigned)(n_u * 4), out, cyc, blocks, nkp, s) != hipSuccess) rc = fail(ST_ERR_ARG, "no such probe variant");
+    if (rc == ST_OK) {
+        HIP_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h(blocks);
+        HIP_TRY(hipMemcpy(h.data(), cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        *cycles_per_kpair = (double)h[blocks / 2] / nkp;
+    }
+    (void)hipStreamDestroy(s);
+    dfree(out); dfree(U); (void)hipFree(cyc);
+    return rc;
+}
+
 int st_bench_issue_probe(int device_id, int naux, int nlds, double* cycles_per_mfma)
 {
     if (!cycles_per_mfma) return fail(ST_ERR_ARG, "bad argument");
@@ -1697,7 +1725,7 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     if (cfg_used) *cfg_used = cfg;
     unsigned long long* dstamps = nullptr;
     const size_t max_blocks = (size_t)((W + 31) / 32) * ((H + 3) / 4) * (p.MPad / 64);
-    if (cfg == 6 || cfg == 103) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
+    if (cfg == 6 || cfg == 103 || cfg == 105) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
     hipStream_t s;
     HIP_TRY(hipStreamCreate(&s));
     auto launch = [&]() { return wino ? launch_conv3x3_wino_cfg(p, cfg - 101, s) : launch_conv3x3_cfg(p, cfg, s); };

@@ -49,6 +49,8 @@ void pack_wino_weights_dgrad(const float* w, int Cout, int Cin, float* dst);
 bool conv_wino_ok(int K, int M, int H, int W);
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);
 hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s);   // 0: 128 ch x 4x32 px, 1: 64 ch x 8x32 px
+hipError_t launch_wino_lds_probe(int extra_dma, const float* U, unsigned u_bytes, float* out, unsigned long long* cycles,
+                                 int blocks, int nkp, hipStream_t s);
 hipError_t launch_wino_issue_probe(int naux, int nlds, float* out, unsigned long long* cycles, int blocks, int iters, hipStream_t s);
 hipError_t launch_wino_probe(const float* U, float* out, int blocks, int nkp, int n_mt, int depth, hipStream_t s);
 // conv1_1-style dgrad (tiny M): direct VALU kernel, w is the ORIGINAL (Cout,Cin,3,3) layout
