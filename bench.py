@@ -31,6 +31,7 @@ from style_transfer2_amd import weights as st2_weights  # noqa: E402
 from style_transfer2_amd import distributed as st2_dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E
 PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (8 passes x 4 cyc)
 WEIGHTS = {'content': {'conv4_2': 0.08},
            'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
@@ -157,6 +158,14 @@ def main():
                          'avg_launch_ms': ms / launches if launches else 0.0,
                          'share_of_step': ms / total_ms if total_ms else 0.0},
             'kernel_ms_per_step': {k: round(v['ms'] / prof_steps, 4) for k, v in sorted(prof.items())},
+            # every kernel class against its own roofline (algorithmic flops / bytes recorded by the engine per launch):
+            # matrix-core classes in TFLOP/s vs the MFMA peak of the operand type, streaming passes in GB/s vs HBM 8 TB/s
+            'kernel_rooflines': {k: ({'TFLOP/s': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
+                                      'frac_mfma': round(v['flops'] / (v['ms'] * 1e-3) / 1e12 / (peak if k.startswith('conv3x3') else PEAK_F32_MFMA_TFLOPS), 3)}
+                                     if v['flops'] > 0 else
+                                     {'GB/s': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
+                                      'frac_hbm': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)})
+                                 for k, v in sorted(prof.items()) if v['ms'] > 0},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_size or args.size, args.optimizer)

@@ -496,15 +496,17 @@ hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float 
 
 // ------------------------------------------------------------------------------------------
 // dgrad with a tiny output-channel count (conv1_1 -> image, M = 3): not GEMM shaped, so a direct
-// VALU kernel.  One thread per output pixel, all M (<= 4) channels; weights (Cout*M*9 floats) in LDS.
+// VALU kernel.  One thread per 4 consecutive output pixels, all M (<= 4) channels; weights via scalar loads.
 // dx[m][y][x] = sum_{co,ky,kx} w[co][m][ky][kx] * dy[co][y-ky+1][x-kx+1]  (+ inject)
 // ------------------------------------------------------------------------------------------
 constexpr int SM_MAXM = 4;
-constexpr int SM_TX = 32, SM_TY = 8, SM_CH = 8;
+constexpr int SM_PX = 4;                              // consecutive pixels per thread (register blocking along x)
+constexpr int SM_TX = 32 * SM_PX, SM_TY = 8, SM_CH = 4;
 
 // Weights are wave-uniform: they are read with scalar loads straight from the original
 // (Cout, M, 3, 3) layout (27 consecutive floats per input channel for M = 3), so the LDS only
-// serves the activation tile: 9 ds_read_b32 + 9*M v_fmac (SGPR operand) per channel and pixel.
+// serves the activation tile.  A thread owns 4 consecutive pixels of a row: per channel and tile row it reads
+// 6 floats for 4 pixels x 3 taps (18 ds_read per 4 pixels instead of 36), then 9*M v_fmac (SGPR operand) per pixel.
 template <int M>
 __global__ __launch_bounds__(256) void conv3x3_dgrad_smallM(const float* __restrict__ dy, const float* __restrict__ w,
                                                             float* __restrict__ dx, const float* __restrict__ inject,
@@ -514,11 +516,13 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_smallM(const float* __restr
     __shared__ float t_s[2][SM_CH * TH * TW];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * SM_TX, y0 = blockIdx.y * SM_TY;
-    const int lx = tid % SM_TX, ly = tid / SM_TX;
+    const int lx = (tid & 31) * SM_PX, ly = tid >> 5;
     const size_t plane = (size_t)H * W;
-    float acc[M];
+    float acc[SM_PX][M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = 0.f;
+    for (int q = 0; q < SM_PX; ++q)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[q][m] = 0.f;
 
     constexpr int NE = SM_CH * TH * TW, PER_T = (NE + 255) / 256;
     int toff[PER_T];                          // tile element -> offset inside one channel plane (or -1)
@@ -556,14 +560,18 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_smallM(const float* __restr
             if (c0 + c < Cout) {
                 const float* wc = w + (size_t)(c0 + c) * M * 9;      // uniform -> s_load
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int ky = 0; ky < 3; ++ky) {
+                    // source pixel (y - ky + 1, x - kx + 1) -> tile coords (ly + 2 - ky, lx + q + 2 - kx)
+                    float g[SM_PX + 2];
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        // source pixel (y - ky + 1, x - kx + 1) -> tile coords (ly + 2 - ky, lx + 2 - kx)
-                        const float g = tile[(c * TH + (ly + 2 - ky)) * TW + (lx + 2 - kx)];
+                    for (int j = 0; j < SM_PX + 2; ++j) g[j] = tile[(c * TH + (ly + 2 - ky)) * TW + lx + j];
 #pragma unroll
-                        for (int m = 0; m < M; ++m) acc[m] += wc[m * 9 + ky * 3 + kx] * g;
-                    }
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int q = 0; q < SM_PX; ++q)
+#pragma unroll
+                            for (int m = 0; m < M; ++m) acc[q][m] += wc[m * 9 + ky * 3 + kx] * g[q + 2 - kx];
+                }
             }
         }
         if (more) {
@@ -572,12 +580,17 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_smallM(const float* __restr
             buf ^= 1;
         }
     }
-    const int gx = x0 + lx, gy = y0 + ly;
-    if (gx < W && gy < H)
+    const int gy = y0 + ly;
+    if (gy < H)
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-            const size_t idx = (size_t)m * plane + (size_t)gy * W + gx;
-            dx[idx] = acc[m] + (inject ? inject[idx] : 0.f);
+        for (int q = 0; q < SM_PX; ++q) {
+            const int gx = x0 + lx + q;
+            if (gx >= W) continue;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const size_t idx = (size_t)m * plane + (size_t)gy * W + gx;
+                dx[idx] = acc[q][m] + (inject ? inject[idx] : 0.f);
+            }
         }
 }
 

@@ -9,6 +9,7 @@
 // kernel sums in a fixed order (bitwise reproducible, no float atomics).
 #include "st2_kernels.h"
 #include "reduce.cuh"
+#include <stdlib.h>
 
 namespace st2 {
 
@@ -23,8 +24,9 @@ GramPlan gram_plan(int C, int hw)
     GramPlan p;
     p.bt = C > 64 ? 128 : 64;
     const int t = (C + p.bt - 1) / p.bt;
-    p.tiles = t * t;
-    int want = (1024 + p.tiles - 1) / p.tiles;             // ~4 workgroups per CU
+    p.tiles = t * (t + 1) / 2;                             // G is symmetric: upper-triangular tiles only, mirrored on store
+    static const int target_blocks = [] { const char* e = getenv("ST2_GRAM_BLOCKS"); return e && *e ? atoi(e) : 512; }();
+    int want = (target_blocks + p.tiles - 1) / p.tiles;    // ~2 workgroups per CU (swept: tools/gram_blocks_sweep.sh)
     const int max_splits = (hw + 4 * GKT - 1) / (4 * GKT); // at least 128 K per slab
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;
@@ -47,9 +49,12 @@ __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = blockIdx.x % (tiles_1d * tiles_1d);
-    const int split = blockIdx.x / (tiles_1d * tiles_1d);
-    const int ti = tile / tiles_1d, tj = tile % tiles_1d;
+    const int n_ut = tiles_1d * (tiles_1d + 1) / 2;
+    int tile = blockIdx.x % n_ut;
+    const int split = blockIdx.x / n_ut;
+    int ti = 0;
+    while (tile >= tiles_1d - ti) { tile -= tiles_1d - ti; ++ti; }      // row ti of the upper triangle holds tiles_1d - ti tiles
+    const int tj = ti + tile;
     const int i0 = ti * BT, j0 = tj * BT;
     const bool diag = ti == tj;
     const int kbeg = split * kslab;
@@ -122,7 +127,10 @@ __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = i0 + wm * (T * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                if (row < C && col < C) dst[(size_t)row * C + col] = acc[i][j][e];
+                if (row < C && col < C) {
+                    dst[(size_t)row * C + col] = acc[i][j][e];
+                    if (!diag) dst[(size_t)col * C + row] = acc[i][j][e];       // the mirrored tile (same products, same order)
+                }
             }
         }
 }
