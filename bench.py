@@ -62,6 +62,22 @@ def make_job(size, optimizer, device, precision='fp32'):
     return job
 
 
+def class_roofline(name, rec, conv_peak):
+    """One kernel class against its rooflines: TFLOP/s vs the MFMA peak of its operand type when the engine recorded
+    algorithmic flops for it, GB/s vs HBM when it recorded algorithmic bytes (both for classes that have both)."""
+    sec = rec['ms'] * 1e-3
+    out = {}
+    if rec['flops'] > 0:
+        tf = rec['flops'] / sec / 1e12
+        out['TFLOP/s'] = round(tf, 1)
+        out['frac_mfma'] = round(tf / (conv_peak if name.startswith('conv3x3') else PEAK_F32_MFMA_TFLOPS), 3)
+    if rec['bytes'] > 0:
+        gbs = rec['bytes'] / sec / 1e9
+        out['GB/s'] = round(gbs, 1)
+        out['frac_hbm'] = round(gbs / PEAK_HBM_GBS, 3)
+    return out
+
+
 def cpu_baseline(size, optimizer):
     """The CPU oracle ("port") on this host: setup, one untimed step (norm capture), one timed step."""
     import oracle
@@ -160,12 +176,7 @@ def main():
             'kernel_ms_per_step': {k: round(v['ms'] / prof_steps, 4) for k, v in sorted(prof.items())},
             # every kernel class against its own roofline (algorithmic flops / bytes recorded by the engine per launch):
             # matrix-core classes in TFLOP/s vs the MFMA peak of the operand type, streaming passes in GB/s vs HBM 8 TB/s
-            'kernel_rooflines': {k: ({'TFLOP/s': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1),
-                                      'frac_mfma': round(v['flops'] / (v['ms'] * 1e-3) / 1e12 / (peak if k.startswith('conv3x3') else PEAK_F32_MFMA_TFLOPS), 3)}
-                                     if v['flops'] > 0 else
-                                     {'GB/s': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9, 1),
-                                      'frac_hbm': round(v['bytes'] / (v['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)})
-                                 for k, v in sorted(prof.items()) if v['ms'] > 0},
+            'kernel_rooflines': {k: class_roofline(k, v, peak) for k, v in sorted(prof.items()) if v['ms'] > 0},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.cpu_size or args.size, args.optimizer)

@@ -71,7 +71,9 @@ def build_lib(force=False, verbose=False):
             if verbose and err:
                 print(err, file=sys.stderr)
     if jobs or force or _stale(LIB, objs):
-        run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs)
+        # -z defs: an unresolved symbol (e.g. a kernel host stub the compiler dropped) fails the LINK, here,
+        # instead of the first dlopen on the GPU box
+        run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-Wl,-z,defs', '-o', LIB] + objs)
     return LIB
 
 

@@ -339,6 +339,8 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     const unsigned plane = (unsigned)a.H * a.W;
     const int nkp = a.K >> 1;
 
+    const unsigned long long t_begin = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
+
     const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
     unsigned ioff[I_PER_WAVE];
 #pragma unroll
@@ -497,44 +499,45 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         chunk(c, F{}, F{});
     }
 
+    unsigned long long t_loop_end = 0;
     if (DIAG) {
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        t_loop_end = t1;
         if (tid == 0 && a.stamps) { a.stamps[2 * blockIdx.x] = t1 - t0; a.stamps[2 * blockIdx.x + 1] = r1 - r0; }
     }
-    // ---- epilogue: output transform (in-lane), then bias / ReLU / mask / inject, float2 stores.
+    // ---- epilogue: output transform (in-lane), then bias / ReLU / mask / inject.
+    // A lane holds the 2x2 outputs of one tile; tiles of neighbouring lanes are neighbours in x.  Each lane PAIR swaps
+    // one row (two DPP moves per accumulator element) so that the even lane owns row 0 and the odd lane row 1 of the
+    // pair's 4 consecutive pixels: one 16-byte load / store per lane instead of two 8-byte ones -- the epilogue is
+    // bound by vector-memory instruction issue (64 KiB per workgroup), not by arithmetic.
     // Four accumulator rows at a time: their mask / inject loads are issued together, ahead of the arithmetic.
     const int t31 = lane & 31, khalf = lane >> 5;
-    const int gy0 = y0 + 4 * wave_g + 2 * (t31 >> 4), gx = x0 + 2 * (t31 & 15);
+    const int odd = lane & 1;
+    const int gy = y0 + 4 * wave_g + 2 * (t31 >> 4) + odd;          // this lane's row after the swap
+    const int gx4 = x0 + 2 * (t31 & 14);                            // first of the pair's 4 pixels (16-byte aligned)
     const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
-    if (gx >= a.W || gy0 >= a.H) return;
-    const bool row1 = gy0 + 1 < a.H;
+    const bool live = gx4 < a.W && gy < a.H;
     const int mw = mt * BM + wave_m * 32 + 4 * khalf;
-    const unsigned pix0 = (unsigned)gy0 * a.W + gx, pix1 = row1 ? pix0 + a.W : pix0;
+    const unsigned pix = live ? (unsigned)gy * a.W + gx4 : 0u;
 #pragma unroll
     for (int eb = 0; eb < 4; ++eb) {
         const int mb = mw + 8 * eb;                         // rows mb .. mb+3 (e = 4 eb + 0..3)
         unsigned off[4];
-        float2 mk[4][2], ij[4][2];
+        float4 mk[4], ij[4];
         float bs[4];
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) {
             const int m = mb + ee < a.M ? mb + ee : a.M - 1;
-            off[ee] = (unsigned)m * plane;
+            off[ee] = (unsigned)m * plane + pix;
             bs[ee] = has_bias ? a.bias[m] : 0.f;
         }
         if (has_mask) {
 #pragma unroll
-            for (int ee = 0; ee < 4; ++ee) {
-                mk[ee][0] = *reinterpret_cast<const float2*>(a.mask_src + off[ee] + pix0);
-                mk[ee][1] = *reinterpret_cast<const float2*>(a.mask_src + off[ee] + pix1);
-            }
+            for (int ee = 0; ee < 4; ++ee) mk[ee] = *reinterpret_cast<const float4*>(a.mask_src + off[ee]);
         }
         if (has_inj) {
 #pragma unroll
-            for (int ee = 0; ee < 4; ++ee) {
-                ij[ee][0] = *reinterpret_cast<const float2*>(a.inject + off[ee] + pix0);
-                ij[ee][1] = *reinterpret_cast<const float2*>(a.inject + off[ee] + pix1);
-            }
+            for (int ee = 0; ee < 4; ++ee) ij[ee] = *reinterpret_cast<const float4*>(a.inject + off[ee]);
         }
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) {
@@ -545,17 +548,32 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
                 tt[0][j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
                 tt[1][j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
             }
+            const float y00 = tt[0][0] + tt[0][1] + tt[0][2], y01 = tt[0][1] - tt[0][2] - tt[0][3];
+            const float y10 = tt[1][0] + tt[1][1] + tt[1][2], y11 = tt[1][1] - tt[1][2] - tt[1][3];
+            // give away the row this lane does not keep, receive the partner's part of the row it keeps (quad_perm 1,0,3,2)
+            const float s0 = odd ? y00 : y10, s1 = odd ? y01 : y11;
+            const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xf, 0xf, true));
+            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xf, 0xf, true));
+            float o[4];
+            o[0] = odd ? r0 : y00; o[1] = odd ? r1 : y01; o[2] = odd ? y10 : r0; o[3] = odd ? y11 : r1;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float o0 = tt[i][0] + tt[i][1] + tt[i][2] + bs[ee];
-                float o1 = tt[i][1] - tt[i][2] - tt[i][3] + bs[ee];
-                if (a.relu) { o0 = o0 > 0.f ? o0 : 0.f; o1 = o1 > 0.f ? o1 : 0.f; }
-                if (has_mask) { o0 = mk[ee][i].x > 0.f ? o0 : 0.f; o1 = mk[ee][i].y > 0.f ? o1 : 0.f; }
-                if (has_inj) { o0 += ij[ee][i].x; o1 += ij[ee][i].y; }
-                if (mb + ee < a.M && (i == 0 || row1))
-                    *reinterpret_cast<float2*>(a.out + off[ee] + (i ? pix1 : pix0)) = make_float2(o0, o1);
+            for (int j = 0; j < 4; ++j) {
+                o[j] += bs[ee];
+                if (a.relu) o[j] = o[j] > 0.f ? o[j] : 0.f;
             }
+            if (has_mask) {
+                o[0] = mk[ee].x > 0.f ? o[0] : 0.f; o[1] = mk[ee].y > 0.f ? o[1] : 0.f;
+                o[2] = mk[ee].z > 0.f ? o[2] : 0.f; o[3] = mk[ee].w > 0.f ? o[3] : 0.f;
+            }
+            if (has_inj) { o[0] += ij[ee].x; o[1] += ij[ee].y; o[2] += ij[ee].z; o[3] += ij[ee].w; }
+            if (live && mb + ee < a.M) *reinterpret_cast<float4*>(a.out + off[ee]) = make_float4(o[0], o[1], o[2], o[3]);
         }
+    }
+    if (DIAG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && a.stamps && blockIdx.x == 300)
+            printf("[wino stamps] block 300: prologue %llu, loop %llu, epilogue (stores drained) %llu cycles\n", t0 - t_begin, t_loop_end - t0, t2 - t_loop_end);
     }
 }
 
@@ -698,7 +716,9 @@ __device__ __forceinline__ void conv3x3_wino2_body(const WinoKArgs& a)
                     // Everything this wave issued up to the clump before the previous one has landed (the previous clump's
                     // DMAs -- 1 U piece, after k-pair 0 also 2 raw pieces -- may still fly), its LDS writes are done, and all
                     // eight waves are here: U of k-pair kp+1 (issued two k-pairs ago), V of the next chunk, raw of c+2.
-                    if (kpl == 1 && MORE2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    // (the last chunk issues no U piece after its first k-pair, so nothing may stay in flight there)
+                    if (!MORE && kpl >= 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    else if (kpl == 1 && MORE2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     if (kpl < 3) fetch((kpl + 1) & 3, v_s + cur * 2 * WN_V, kpl + 1, set ^ 1);
                     else if (MORE) fetch(0, v_s + (cur ^ 1) * 2 * WN_V, 0, 0);
@@ -793,6 +813,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_64x256_2w_stamped(con
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKArgs a) { conv3x3_wino_body<4, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256(const WinoKArgs a) { conv3x3_wino_body<2, 2>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1>(a); }
 
 bool conv_wino_ok(int K, int M, int H, int W)
 {
@@ -812,7 +833,7 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     }
     // variants: 0 = 128 ch x 4x32 px (one wave/SIMD), 1 = 64 ch x 8x32 px (one wave/SIMD), 2 = 0 with cycle stamps,
     //           3 = 64 ch x 8x32 px, two waves/SIMD with U staged in LDS, 4 = 3 with cycle stamps
-    const bool small = variant == 1 || variant >= 3;
+    const bool small = variant == 1 || variant >= 3;       // 5 = 1 with cycle stamps
     const int bm = small ? 64 : 128, prows = small ? 8 : 4;
     WinoKArgs k{};
     k.in = p.in; k.upack = reinterpret_cast<const float4*>(p.wpack); k.bias = p.bias; k.out = p.out;
@@ -824,7 +845,8 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     k.stamps = p.stamps;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (variant == 3) conv3x3_wino_f32_64x256_2w<<<dim3((unsigned)nblk), dim3(512), 0, s>>>(k);
+    if (variant == 5) conv3x3_wino_f32_64x256_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+    else if (variant == 3) conv3x3_wino_f32_64x256_2w<<<dim3((unsigned)nblk), dim3(512), 0, s>>>(k);
     else if (variant == 4) conv3x3_wino_f32_64x256_2w_stamped<<<dim3((unsigned)nblk), dim3(512), 0, s>>>(k);
     else if (variant == 2) conv3x3_wino_f32_128x128_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     else if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);

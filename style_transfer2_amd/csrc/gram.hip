@@ -9,6 +9,7 @@
 // kernel sums in a fixed order (bitwise reproducible, no float atomics).
 #include "st2_kernels.h"
 #include "reduce.cuh"
+#include <stdint.h>
 #include <stdlib.h>
 
 namespace st2 {
@@ -135,12 +136,147 @@ __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ 
         }
 }
 
+// ------------------------------------------------------------------ Gram partials, LDS-DMA pipeline
+// Same contract as gram_partial_k for a whole blob with hw % 32 == 0 (every VGG blob of a power-of-two image): the
+// operand rows are staged by LDS-DMA (no VGPR round trip), double-buffered, 32 pixels of K per step.
+// An LDS-DMA piece lands as 64 consecutive quads, so padding is impossible; instead the QUAD SLOT of a row is
+// swizzled, slot = quad ^ ((row >> 1) & 7), by choosing which global quad each lane fetches.  The MFMA operands are
+// then read as one ds_read_b128 per row and four K (two k-pairs; the lane half selects .x/.z or .y/.w): the 16 lanes
+// of a b128 phase (16 consecutive rows) hit 16 distinct bank quads -- conflict-free, and 4x fewer LDS instructions
+// than the dword reads of the register-staged kernel.
+typedef __attribute__((address_space(3))) void* gram_lptr_t;
+typedef float gf32x4 __attribute__((ext_vector_type(4)));
+
+template <int BT>
+__device__ __forceinline__ void gram_partial_dma_body(const float* __restrict__ F, unsigned f_bytes, float* __restrict__ slabs,
+                                                      int C, int hw, int tiles_1d, int kslab)
+{
+    constexpr int T = BT / 64;                       // 32x32 MFMA tiles per wave per dimension
+    constexpr int IMG = BT * 32;                     // floats per operand image (BT rows x 32 K)
+    constexpr int PIECES = IMG / 256;                // wave-DMAs (64 quads) per operand image
+    constexpr int PPW = PIECES / 4;                  // per wave
+    __shared__ __attribute__((aligned(16))) float smem[2][2][IMG];       // [stage][A/B]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_ut = tiles_1d * (tiles_1d + 1) / 2;
+    int tile = blockIdx.x % n_ut;
+    const int split = blockIdx.x / n_ut;
+    int ti = 0;
+    while (tile >= tiles_1d - ti) { tile -= tiles_1d - ti; ++ti; }
+    const int tj = ti + tile;
+    const int i0 = ti * BT, j0 = tj * BT;
+    const bool diag = ti == tj;
+    const int kbeg = split * kslab;
+    const int kend = min(hw, kbeg + kslab);
+    const int nsteps = (kend - kbeg) / 32;
+
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)F, 0, f_bytes, 0x00020000);
+    unsigned aoff[PPW], boff[PPW];
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+        const int slot = (wave + 4 * t) * 64 + lane;          // LDS quad slot: row = slot / 8, swizzled quad = slot % 8
+        const int r = slot >> 3, q = (slot & 7) ^ ((r >> 1) & 7);
+        aoff[t] = i0 + r < C ? ((unsigned)(i0 + r) * (unsigned)hw + (unsigned)kbeg + 4u * q) * 4u : 0xffffffffu;
+        boff[t] = j0 + r < C ? ((unsigned)(j0 + r) * (unsigned)hw + (unsigned)kbeg + 4u * q) * 4u : 0xffffffffu;
+    }
+    auto dma = [&](int step, int stage) {
+        const unsigned so = (unsigned)step * 128u;             // 32 floats further along every row
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (gram_lptr_t)(smem[stage][0] + (wave + 4 * t) * 256), 16,
+                                                     aoff[t] == 0xffffffffu ? aoff[t] : aoff[t] + so, 0, 0, 0);
+            if (!diag)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (gram_lptr_t)(smem[stage][1] + (wave + 4 * t) * 256), 16,
+                                                         boff[t] == 0xffffffffu ? boff[t] : boff[t] + so, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[T][T];
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int l31 = lane & 31;
+    const bool hi = lane >= 32;
+    int arow[T], brow[T];                            // float offset of this lane's row in an operand image, and its swizzle key
+#pragma unroll
+    for (int i = 0; i < T; ++i) { arow[i] = wm * (T * 32) + i * 32 + l31; brow[i] = wn * (T * 32) + i * 32 + l31; }
+
+    if (nsteps > 0) dma(0, 0);
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // step st has landed for every wave; stage cur^1 is free again
+        if (st + 1 < nsteps) dma(st + 1, cur ^ 1);
+        const float* As = smem[cur][0];
+        const float* Bs = diag ? smem[cur][0] : smem[cur][1];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float a0[T], a1[T], b0[T], b1[T];
+#pragma unroll
+            for (int i = 0; i < T; ++i) {
+                const gf32x4 v = *reinterpret_cast<const gf32x4*>(As + (arow[i] * 8 + (q ^ ((arow[i] >> 1) & 7))) * 4);
+                a0[i] = hi ? v.y : v.x; a1[i] = hi ? v.w : v.z;
+            }
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                const gf32x4 v = *reinterpret_cast<const gf32x4*>(Bs + (brow[j] * 8 + (q ^ ((brow[j] >> 1) & 7))) * 4);
+                b0[j] = hi ? v.y : v.x; b1[j] = hi ? v.w : v.z;
+            }
+#pragma unroll
+            for (int i = 0; i < T; ++i)
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+
+    const int khalf = lane >> 5;
+    float* dst = slabs + (size_t)split * C * C;
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int col = j0 + wn * (T * 32) + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i0 + wm * (T * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (row < C && col < C) {
+                    dst[(size_t)row * C + col] = acc[i][j][e];
+                    if (!diag) dst[(size_t)col * C + row] = acc[i][j][e];
+                }
+            }
+        }
+}
+
+// non-template entry points (a template kernel with a waves-per-SIMD launch bound loses its host stub)
+__global__ __launch_bounds__(256, 2) void gram_partial_dma_128(const float* F, unsigned f_bytes, float* slabs, int C, int hw, int tiles_1d, int kslab)
+{ gram_partial_dma_body<128>(F, f_bytes, slabs, C, hw, tiles_1d, kslab); }
+__global__ __launch_bounds__(256, 2) void gram_partial_dma_64(const float* F, unsigned f_bytes, float* slabs, int C, int hw, int tiles_1d, int kslab)
+{ gram_partial_dma_body<64>(F, f_bytes, slabs, C, hw, tiles_1d, kslab); }
+
 hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s,
                                const GramRoi* roi_in)
 {
     const int t1 = (C + pl.bt - 1) / pl.bt;
     const unsigned grid = (unsigned)(pl.tiles * pl.splits);
     GramRoi roi = roi_in ? *roi_in : GramRoi{0, 0, hw, hw, (size_t)hw};   // default: one "row" of hw pixels
+    // whole blob, 32-pixel steps, 16-byte aligned rows, 32-bit buffer offsets: the LDS-DMA pipeline
+    static const bool no_dma = [] { const char* e = getenv("ST2_GRAM_DMA"); return e && *e == '0'; }();
+    if (!roi_in && !no_dma && hw % 32 == 0 && pl.kslab % 32 == 0 && (reinterpret_cast<uintptr_t>(F) & 15) == 0 &&
+        4ull * C * hw < 0xfffffff0ull) {
+        const unsigned fb = (unsigned)(4ull * C * hw);
+        if (pl.bt == 128) gram_partial_dma_128<<<grid, 256, 0, s>>>(F, fb, slabs, C, hw, t1, pl.kslab);
+        else gram_partial_dma_64<<<grid, 256, 0, s>>>(F, fb, slabs, C, hw, t1, pl.kslab);
+        return hipGetLastError();
+    }
     if (pl.bt == 128) gram_partial_k<128><<<grid, 256, 0, s>>>(F, slabs, C, hw, t1, pl.kslab, roi);
     else gram_partial_k<64><<<grid, 256, 0, s>>>(F, slabs, C, hw, t1, pl.kslab, roi);
     return hipGetLastError();

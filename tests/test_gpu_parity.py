@@ -91,6 +91,23 @@ def test_gram_matches_oracle():
         assert np.allclose(g, g.T, rtol=1e-5, atol=1e-7 * np.abs(g).max())
 
 
+@pytest.mark.parametrize('h,w', [(32, 64), (64, 96), (8, 4), (96, 128)])
+def test_gram_dma_pipeline_matches_oracle_and_register_staged_kernel(h, w, monkeypatch):
+    """h*w % 32 == 0 takes the LDS-DMA Gram kernel (swizzled quads, b128 operand reads); every C-tile shape:
+    64 (one 64-tile), 128, 200 (ragged 128-tiles), 512 (upper-triangular tiles mirrored on store)."""
+    topo = (('conv', 'conv1_1', 3, 64), ('conv', 'conv1_2', 64, 128), ('conv', 'conv1_3', 128, 200), ('conv', 'conv1_4', 200, 512))
+    cpu, gpu = make_models(topo, seed=12)
+    x = (np.random.RandomState(h + w).randn(1, 3, h, w) * 40).astype(F32)
+    fc = cpu.forward(x)
+    gpu.forward(x)
+    for name in fc:
+        if name == 'data':
+            continue
+        g = gpu.engine.gram(name)
+        assert rel_l2(g, oracle.gram(fc[name])) <= 1e-5, name
+        assert np.array_equal(g, g.T), name              # mirrored tiles: exactly symmetric
+
+
 # ------------------------------------------------- oracle objective on top of the HIP model (B2 seam)
 def test_oracle_objective_over_hip_model_matches_golden():
     g = load('transfer_tiny.npz')
