@@ -292,6 +292,7 @@ struct WinoKArgs {
     const float* mask_src; const float* inject;
     int K, M, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
     unsigned in_bytes, u_bytes;
+    int splits; float* scratch;   // split-K (few workgroups, deep K): split s accumulates chunks [s, s+1) * nch / splits into scratch[s]
     unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
 };
 
@@ -327,7 +328,9 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 
     // XCD-aware bijective block -> tile map, pixel tile fastest: the co-resident blocks of one XCD work on the
     // same channel slice of U (the dominant stream) and on neighbouring pixel tiles.
-    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int nwg = gridDim.x / a.splits;
+    const int split = blockIdx.x / nwg, orig = blockIdx.x - split * nwg;
+    const int nch = a.nch / a.splits, c_first = split * nch;       // this workgroup's chunks of the K loop
     const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     const int n_pt = a.tiles_x * a.tiles_y;
@@ -352,7 +355,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         const int col = rem - rr * WN_IW;
         const int gy = y0 - 1 + rr, gx = x0 - 4 + col;
         const bool ok = e < N_RAW && gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W;
-        ioff[t] = ok ? ((unsigned)c * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
+        ioff[t] = ok ? ((unsigned)(c_first * WN_CH + c) * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
     }
     auto dma_raw = [&](int ch, int buf) {
         const unsigned coff = (unsigned)ch * WN_CH * plane * 4u;
@@ -411,7 +414,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
                 *reinterpret_cast<float4*>(vp + g * WN_V + i * 256) = make_float4(d[g][4 * i], d[g][4 * i + 1], d[g][4 * i + 2], d[g][4 * i + 3]);
     };
 
-    const f32x4* up = reinterpret_cast<const f32x4*>(a.upack) + ((size_t)(mt * WM + wave_m) * nkp) * 256 + lane;
+    const f32x4* up = reinterpret_cast<const f32x4*>(a.upack) + ((size_t)(mt * WM + wave_m) * nkp + 4 * c_first) * 256 + lane;
     f32x4 ua[4][4];                     // U ring: set kp % 4 holds k-pair kp, refilled three k-pairs ahead
     auto u_fill = [&](int kp) {
 #pragma unroll
@@ -438,7 +441,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 
     // ---- prologue: raw chunks 0 and 1, U of k-pairs 0..2, V of chunk 0 ----
     dma_raw(0, 0);
-    if (a.nch > 1) dma_raw(1, 1);
+    if (nch > 1) dma_raw(1, 1);
     u_fill(0); u_fill(1); u_fill(2);
     __syncthreads();
     xf_read(raw_s[0] + x_raw);
@@ -494,8 +497,8 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     {
         using T = std::true_type; using F = std::false_type;
         int c = 0;
-        for (; c + 2 < a.nch; ++c) chunk(c, T{}, T{});
-        if (c + 1 < a.nch) { chunk(c, T{}, F{}); ++c; }
+        for (; c + 2 < nch; ++c) chunk(c, T{}, T{});
+        if (c + 1 < nch) { chunk(c, T{}, F{}); ++c; }
         chunk(c, F{}, F{});
     }
 
@@ -515,7 +518,11 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     const int odd = lane & 1;
     const int gy = y0 + 4 * wave_g + 2 * (t31 >> 4) + odd;          // this lane's row after the swap
     const int gx4 = x0 + 2 * (t31 & 14);                            // first of the pair's 4 pixels (16-byte aligned)
-    const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
+    // split-K: raw partial sums go to scratch[split]; bias / ReLU / mask / inject are applied by wino_combine_k
+    const bool part = a.splits > 1;
+    const bool has_bias = !part && a.bias != nullptr, has_mask = !part && a.mask_src != nullptr, has_inj = !part && a.inject != nullptr;
+    const bool relu = !part && a.relu;
+    float* const outp = part ? a.scratch + (size_t)split * a.M * plane : a.out;
     const bool live = gx4 < a.W && gy < a.H;
     const int mw = mt * BM + wave_m * 32 + 4 * khalf;
     const unsigned pix = live ? (unsigned)gy * a.W + gx4 : 0u;
@@ -559,14 +566,14 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 o[j] += bs[ee];
-                if (a.relu) o[j] = o[j] > 0.f ? o[j] : 0.f;
+                if (relu) o[j] = o[j] > 0.f ? o[j] : 0.f;
             }
             if (has_mask) {
                 o[0] = mk[ee].x > 0.f ? o[0] : 0.f; o[1] = mk[ee].y > 0.f ? o[1] : 0.f;
                 o[2] = mk[ee].z > 0.f ? o[2] : 0.f; o[3] = mk[ee].w > 0.f ? o[3] : 0.f;
             }
             if (has_inj) { o[0] += ij[ee].x; o[1] += ij[ee].y; o[2] += ij[ee].z; o[3] += ij[ee].w; }
-            if (live && mb + ee < a.M) *reinterpret_cast<float4*>(a.out + off[ee]) = make_float4(o[0], o[1], o[2], o[3]);
+            if (live && mb + ee < a.M) *reinterpret_cast<float4*>(outp + off[ee]) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
     if (DIAG) {
@@ -577,243 +584,50 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     }
 }
 
-// -----------------------------------------------------------------------------------------------------------
-// Two waves per SIMD: 8 waves = 2 channel slices (32) x 2 tile groups (32 tiles) x 2 POSITION HALVES.
-// A wave keeps 8 of the 16 positions of its 32x32 accumulator block (128 AGPRs), so two waves fit on a SIMD and one
-// wave's operand fetches, DMA issue, transform arithmetic and barrier waits run under the other's MFMAs (with one
-// wave per SIMD nothing overlaps the wave's own MFMAs).  Workgroup tile: 64 channels x (8 rows x 32 columns).
-//   U: staged ONCE per workgroup in LDS by LDS-DMA (8 KiB per k-pair, one 1-KiB piece per wave, 4-stage ring) and
-//      read by the four waves that share the slice: 11 KiB of vector-memory ingest per k-pair instead of 18;
-//   raw / V / transform: as above, one (tile, channel) pair per thread per chunk;
-//   one `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier` per k-pair (8 MFMAs per wave) orders every LDS producer/consumer;
-//   epilogue: the output transform is linear in the positions, so each half finishes partial outputs, the halves
-//   swap one output row through LDS and each stores one of the two rows of every tile.
-template <int DIAG>
-__device__ __forceinline__ void conv3x3_wino2_body(const WinoKArgs& a)
-{
-    constexpr int PROWS = 8, IN_ROWS = PROWS + 2, PLANE = IN_ROWS * WN_IW, N_RAW = WN_CH * PLANE;
-    constexpr int RAW = 4096;                            // 16 wave-DMAs of 64 quads (3200 floats used)
-    constexpr int U_STAGE = 2048;                        // floats per U stage: 2 slices x [4][64][4]
-    __shared__ __attribute__((aligned(16))) float lds[2 * RAW + 4 * WN_V + 4 * U_STAGE];     // 128 KiB
-    float* const raw_s = lds;                            // [2][RAW]
-    float* const v_s = lds + 2 * RAW;                    // [2][tile group 2][WN_V]
-    float* const u_s = lds + 2 * RAW + 4 * WN_V;         // [4][U_STAGE]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ph = wave & 1, tg = (wave >> 1) & 1, wm = wave >> 2;
-
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    const int n_pt = a.tiles_x * a.tiles_y;
-    const int mt = logical / n_pt;
-    const int pt = logical - mt * n_pt;
-    const int tx = pt % a.tiles_x;
-    const int ty = pt / a.tiles_x;
-    const int y0 = ty * PROWS, x0 = tx * 32;
-    const unsigned plane = (unsigned)a.H * a.W;
-    const int nkp = a.K >> 1;
-
-    const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_u = __builtin_amdgcn_make_buffer_rsrc((void*)a.upack, 0, a.u_bytes, 0x00020000);
-    unsigned ioff[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int e = ((wave + 8 * t) * 64 + lane) * 4;
-        const int c = e / PLANE;
-        const int rem = e - c * PLANE;
-        const int rr = rem / WN_IW;
-        const int col = rem - rr * WN_IW;
-        const int gy = y0 - 1 + rr, gx = x0 - 4 + col;
-        const bool ok = e < N_RAW && gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W;
-        ioff[t] = ok ? ((unsigned)c * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
-    }
-    auto dma_raw = [&](int ch, int buf) {
-        const unsigned coff = (unsigned)ch * WN_CH * plane * 4u;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + coff;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s + buf * RAW + (wave + 8 * t) * 256), 16, vo, 0, 0, 0);
-        }
-    };
-    // U piece of this wave: slice = wave / 4, quarter (pos / 4) = wave % 4; pack = [m/32][k/2][pos/4][lane][4]
-    const unsigned u_voff = (unsigned)lane * 16u + ((unsigned)(mt * 2 + (wave >> 2)) * (unsigned)nkp) * 4096u + (unsigned)(wave & 3) * 1024u;
-    auto dma_u = [&](int kp, int stage) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_u, (lptr_t)(u_s + stage * U_STAGE + wave * 256), 16, u_voff, (unsigned)kp * 4096u, 0, 0);
-    };
-
-    const int xt = tid & 31, xch = (tid >> 5) & 7, xg = tid >> 8;
-    const int x_raw = xch * PLANE + (4 * xg + 2 * (xt >> 4)) * WN_IW + 2 * (xt & 15) + 3;
-    const int x_v = xg * WN_V + (((xch >> 1) * 4) * 64 + (xch & 1) * 32 + xt) * 4;
-    float d[16];
-    auto xf_read = [&](const float* rp) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d[4 * i + j] = rp[i * WN_IW + j];
-    };
-    auto xf_math = [&]() {
-        float wv[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wv[j] = d[j] - d[8 + j]; wv[4 + j] = d[4 + j] + d[8 + j];
-            wv[8 + j] = d[8 + j] - d[4 + j]; wv[12 + j] = d[4 + j] - d[12 + j];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            d[4 * i] = wv[4 * i] - wv[4 * i + 2]; d[4 * i + 1] = wv[4 * i + 1] + wv[4 * i + 2];
-            d[4 * i + 2] = wv[4 * i + 2] - wv[4 * i + 1]; d[4 * i + 3] = wv[4 * i + 1] - wv[4 * i + 3];
-        }
-    };
-    auto xf_write = [&](float* vp) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<float4*>(vp + i * 256) = make_float4(d[4 * i], d[4 * i + 1], d[4 * i + 2], d[4 * i + 3]);
-    };
-
-    f32x4 aq[2][2], bq[2][2];           // operands of two k-pairs: this wave's 8 positions = 2 quads
-    auto fetch = [&](int stage, const float* vimg, int kpl, int set) {
-#pragma unroll
-        for (int qd = 0; qd < 2; ++qd) {
-            aq[set][qd] = *reinterpret_cast<const f32x4*>(u_s + stage * U_STAGE + wm * 1024 + ((2 * ph + qd) * 64 + lane) * 4);
-            bq[set][qd] = *reinterpret_cast<const f32x4*>(vimg + tg * WN_V + ((kpl * 4 + 2 * ph + qd) * 64 + lane) * 4);
-        }
-    };
-
-    f32x16 acc[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-
-    dma_raw(0, 0);
-    if (a.nch > 1) dma_raw(1, 1);
-    dma_u(0, 0); dma_u(1, 1); dma_u(2, 2);
-    __syncthreads();
-    xf_read(raw_s + x_raw);
-    xf_math();
-    xf_write(v_s + x_v);
-    __syncthreads();
-    fetch(0, v_s, 0, 0);
-
-    unsigned long long t0 = 0, r0 = 0;
-    if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
-
-    auto chunk = [&](const int c, auto more_t, auto more2_t) {
-        constexpr bool MORE = decltype(more_t)::value, MORE2 = decltype(more2_t)::value;
-        const int cur = c & 1;
-#pragma unroll
-        for (int kpl = 0; kpl < 4; ++kpl) {
-            const int kp = 4 * c + kpl;
-            const int set = kpl & 1;
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[set][p >> 2][p & 3], bq[set][p >> 2][p & 3], acc[p], 0, 0, 0);
-                if (p == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    // Everything this wave issued up to the clump before the previous one has landed (the previous clump's
-                    // DMAs -- 1 U piece, after k-pair 0 also 2 raw pieces -- may still fly), its LDS writes are done, and all
-                    // eight waves are here: U of k-pair kp+1 (issued two k-pairs ago), V of the next chunk, raw of c+2.
-                    // (the last chunk issues no U piece after its first k-pair, so nothing may stay in flight there)
-                    if (!MORE && kpl >= 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    else if (kpl == 1 && MORE2) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                    if (kpl < 3) fetch((kpl + 1) & 3, v_s + cur * 2 * WN_V, kpl + 1, set ^ 1);
-                    else if (MORE) fetch(0, v_s + (cur ^ 1) * 2 * WN_V, 0, 0);
-                    if (MORE || kpl == 0) dma_u(kp + 3, (kpl + 3) & 3);      // that stage held k-pair kp-1, consumed two barriers ago
-                    if (MORE) {
-                        if (kpl == 0) xf_read(raw_s + (cur ^ 1) * RAW + x_raw);
-                        if (kpl == 1) xf_math();
-                        if (kpl == 2) xf_write(v_s + (cur ^ 1) * 2 * WN_V + x_v);
-                    }
-                    if (MORE2 && kpl == 0) dma_raw(c + 2, cur);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    {
-        using T = std::true_type; using F = std::false_type;
-        int c = 0;
-        for (; c + 2 < a.nch; ++c) chunk(c, T{}, T{});
-        if (c + 1 < a.nch) { chunk(c, T{}, F{}); ++c; }
-        chunk(c, F{}, F{});
-    }
-    if (DIAG) {
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-        if (tid == 0 && a.stamps) { a.stamps[2 * blockIdx.x] = t1 - t0; a.stamps[2 * blockIdx.x + 1] = r1 - r0; }
-    }
-
-    // ---- epilogue.  Partial output transform over this wave's positions (pos = 4 xi + nu; xi = 2 ph + p / 4, nu = p % 4):
-    //   A^T = [1 1 1 0; 0 1 -1 -1]  ->  ph 0: tt0 = S0 + S1, tt1 = S1;   ph 1: tt0 = S2, tt1 = -S2 - S3
-    // The wave keeps output row i = ph and hands row 1 - ph to its partner (wave ^ 1) through LDS.
-    __syncthreads();                                     // everyone is done with the staged tiles: LDS is free
-    float keep[16][2];
-    float* const xs = lds + wave * 2048 + lane;          // [e * 2 + j][64 lanes]
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float t0v[4], t1v[4];
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            if (ph == 0) { t0v[nu] = acc[nu][e] + acc[4 + nu][e]; t1v[nu] = acc[4 + nu][e]; }
-            else { t0v[nu] = acc[nu][e]; t1v[nu] = -acc[nu][e] - acc[4 + nu][e]; }
-        }
-        const float y00 = t0v[0] + t0v[1] + t0v[2], y01 = t0v[1] - t0v[2] - t0v[3];
-        const float y10 = t1v[0] + t1v[1] + t1v[2], y11 = t1v[1] - t1v[2] - t1v[3];
-        keep[e][0] = ph == 0 ? y00 : y10; keep[e][1] = ph == 0 ? y01 : y11;
-        xs[(2 * e) * 64] = ph == 0 ? y10 : y00; xs[(2 * e + 1) * 64] = ph == 0 ? y11 : y01;
-    }
-    __syncthreads();
-    const float* const xr = lds + (wave ^ 1) * 2048 + lane;
-    const int t31 = lane & 31, khalf = lane >> 5;
-    const int gy = y0 + 4 * tg + 2 * (t31 >> 4) + ph, gx = x0 + 2 * (t31 & 15);
-    const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
-    if (gx >= a.W || gy >= a.H) return;
-    const int mw = mt * 64 + wm * 32 + 4 * khalf;
-    const unsigned pix = (unsigned)gy * a.W + gx;
-#pragma unroll
-    for (int eb = 0; eb < 4; ++eb) {
-        const int mb = mw + 8 * eb;
-        unsigned off[4];
-        float2 mk[4], ij[4], part[4];
-        float bs[4];
-#pragma unroll
-        for (int ee = 0; ee < 4; ++ee) {
-            const int m = mb + ee < a.M ? mb + ee : a.M - 1;
-            off[ee] = (unsigned)m * plane + pix;
-            bs[ee] = has_bias ? a.bias[m] : 0.f;
-            part[ee] = make_float2(xr[(2 * (4 * eb + ee)) * 64], xr[(2 * (4 * eb + ee) + 1) * 64]);
-        }
-        if (has_mask) {
-#pragma unroll
-            for (int ee = 0; ee < 4; ++ee) mk[ee] = *reinterpret_cast<const float2*>(a.mask_src + off[ee]);
-        }
-        if (has_inj) {
-#pragma unroll
-            for (int ee = 0; ee < 4; ++ee) ij[ee] = *reinterpret_cast<const float2*>(a.inject + off[ee]);
-        }
-#pragma unroll
-        for (int ee = 0; ee < 4; ++ee) {
-            float o0 = keep[4 * eb + ee][0] + part[ee].x + bs[ee];
-            float o1 = keep[4 * eb + ee][1] + part[ee].y + bs[ee];
-            if (a.relu) { o0 = o0 > 0.f ? o0 : 0.f; o1 = o1 > 0.f ? o1 : 0.f; }
-            if (has_mask) { o0 = mk[ee].x > 0.f ? o0 : 0.f; o1 = mk[ee].y > 0.f ? o1 : 0.f; }
-            if (has_inj) { o0 += ij[ee].x; o1 += ij[ee].y; }
-            if (mb + ee < a.M) *reinterpret_cast<float2*>(a.out + off[ee]) = make_float2(o0, o1);
-        }
-    }
-}
-
-__global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_64x256_2w(const WinoKArgs a) { conv3x3_wino2_body<0>(a); }
-__global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_64x256_2w_stamped(const WinoKArgs a) { conv3x3_wino2_body<1>(a); }
+// (A two-waves-per-SIMD variant -- 8 waves, each keeping 8 of the 16 positions, U staged once in LDS, one barrier per
+// k-pair -- was built and measured in round 1: 5 531 cycles per chunk against 4 888-5 324 for this kernel, because the
+// per-k-pair barrier re-aligns the two waves of a SIMD and their auxiliary clumps then collide.  Removed)
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKArgs a) { conv3x3_wino_body<4, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256(const WinoKArgs a) { conv3x3_wino_body<2, 2>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1>(a); }
+
+// out = sum_s scratch[s] (+ bias) -> ReLU -> mask -> + inject, float4 per thread (plane % 4 == 0 because W % 4 == 0)
+__global__ __launch_bounds__(256) void wino_combine_k(const float* __restrict__ scratch, int splits, const float* __restrict__ bias, int relu,
+                                                      const float* __restrict__ mask_src, const float* __restrict__ inject,
+                                                      float* __restrict__ out, int M, unsigned plane)
+{
+    const size_t n4 = (size_t)M * plane / 4, per = (size_t)M * plane;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        float4 v = *reinterpret_cast<const float4*>(scratch + 4 * i);
+        for (int sp = 1; sp < splits; ++sp) {
+            const float4 w = *reinterpret_cast<const float4*>(scratch + sp * per + 4 * i);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        if (bias) { const float b = bias[(4 * i) / plane]; v.x += b; v.y += b; v.z += b; v.w += b; }
+        if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+        if (mask_src) {
+            const float4 m = *reinterpret_cast<const float4*>(mask_src + 4 * i);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        if (inject) { const float4 j = *reinterpret_cast<const float4*>(inject + 4 * i); v.x += j.x; v.y += j.y; v.z += j.z; v.w += j.w; }
+        *reinterpret_cast<float4*>(out + 4 * i) = v;
+    }
+}
+
+// Split-K factor for a launch that would leave most CUs idle (conv5_1 at 1024^2: 128 workgroups on 256 CUs)
+int conv_wino_splits(int K, int M, int H, int W)
+{
+    static const bool off = [] { const char* e = getenv("ST2_WINO_SPLITK"); return e && *e == '0'; }();
+    if (off || !conv_wino_ok(K, M, H, W)) return 1;
+    const int bm = ((M + 63) / 64 * 64 < (M + 127) / 128 * 128) ? 64 : 128, prows = bm == 64 ? 8 : 4;
+    const long long nblk = (long long)((W + 31) / 32) * ((H + prows - 1) / prows) * ((M + bm - 1) / bm);
+    const int nch = K / WN_CH;
+    int sp = 1;
+    while (nblk * sp * 2 <= 256 && nch % (sp * 2) == 0 && nch / (sp * 2) >= 8 && sp < 4) sp *= 2;
+    return sp;
+}
 
 bool conv_wino_ok(int K, int M, int H, int W)
 {
@@ -825,15 +639,16 @@ bool conv_wino_ok(int K, int M, int H, int W)
 hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s)
 {
     if (!conv_wino_ok(p.K, p.M, p.H, p.W) || (reinterpret_cast<uintptr_t>(p.in) & 15) != 0) return hipErrorInvalidValue;
+    const bool forced_auto = variant < 0;           // split-K only on the automatic path (variants 0 / 1)
     if (variant < 0) {
         const char* env = getenv("ST2_WINO_CFG");            // forces a variant (tests of both variants on every shape)
         const int forced = env && *env ? atoi(env) : -1;
         const int pad128 = (p.M + 127) / 128 * 128, pad64 = (p.M + 63) / 64 * 64;
         variant = forced >= 0 ? forced : (pad64 < pad128 ? 1 : 0);
     }
-    // variants: 0 = 128 ch x 4x32 px (one wave/SIMD), 1 = 64 ch x 8x32 px (one wave/SIMD), 2 = 0 with cycle stamps,
-    //           3 = 64 ch x 8x32 px, two waves/SIMD with U staged in LDS, 4 = 3 with cycle stamps
-    const bool small = variant == 1 || variant >= 3;       // 5 = 1 with cycle stamps
+    // variants: 0 = 128 ch x 4x32 px, 1 = 64 ch x 8x32 px, 2 = 0 with cycle stamps, 5 = 1 with cycle stamps
+    if (variant == 3 || variant == 4 || variant > 5) return hipErrorInvalidValue;
+    const bool small = variant == 1 || variant == 5;
     const int bm = small ? 64 : 128, prows = small ? 8 : 4;
     WinoKArgs k{};
     k.in = p.in; k.upack = reinterpret_cast<const float4*>(p.wpack); k.bias = p.bias; k.out = p.out;
@@ -845,9 +660,22 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     k.stamps = p.stamps;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    k.splits = 1; k.scratch = nullptr;
+    if (forced_auto && p.scratch) {
+        const int sp = conv_wino_splits(p.K, p.M, p.H, p.W);
+        if (sp > 1 && p.scratch_floats >= (size_t)sp * p.M * p.H * p.W) { k.splits = sp; k.scratch = p.scratch; }
+    }
+    if (k.splits > 1) {
+        if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)(nblk * k.splits)), dim3(256), 0, s>>>(k);
+        else conv3x3_wino_f32_128x128<<<dim3((unsigned)(nblk * k.splits)), dim3(256), 0, s>>>(k);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        const size_t n4 = (size_t)p.M * p.H * p.W / 4;
+        const unsigned grid = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        wino_combine_k<<<grid, 256, 0, s>>>(k.scratch, k.splits, p.bias, p.relu, p.mask_src, p.inject, p.out, p.M, (unsigned)(p.H * p.W));
+        return hipGetLastError();
+    }
     if (variant == 5) conv3x3_wino_f32_64x256_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
-    else if (variant == 3) conv3x3_wino_f32_64x256_2w<<<dim3((unsigned)nblk), dim3(512), 0, s>>>(k);
-    else if (variant == 4) conv3x3_wino_f32_64x256_2w_stamped<<<dim3((unsigned)nblk), dim3(512), 0, s>>>(k);
     else if (variant == 2) conv3x3_wino_f32_128x128_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     else if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     else conv3x3_wino_f32_128x128<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);

@@ -114,6 +114,7 @@ struct st_ctx {
     float *diffA = nullptr, *diffB = nullptr, *stmp = nullptr;
     size_t max_blob = 0;
     float *gram_slabs = nullptr, *gram_fold = nullptr, *dbuf = nullptr;
+    float* conv_scratch = nullptr; size_t conv_scratch_cap = 0;       // split-K partial sums of Winograd launches
     size_t gram_slab_cap = 0, gram_fold_cap = 0;
     std::vector<float*> layer_part;                // per blob: 5 * kMaxPartials
     std::vector<float*> s2_part;                   // per blob: style-grad partial sums
@@ -176,6 +177,9 @@ static void dfree(float*& p)
     p = nullptr;
 }
 
+// room for the split-K partial sums of a Winograd launch that would otherwise leave most CUs idle
+static int wino_scratch(st_ctx* c, ConvProblem& p);
+
 static int dmalloc16(unsigned short** p, size_t n)
 {
     void* q = nullptr;
@@ -217,6 +221,21 @@ struct ProfScope {
 };
 
 static bool conv16_ok(const st_ctx* c, int K) { (void)c; return K >= 8 && K % 8 == 0; }
+
+static int wino_scratch(st_ctx* c, ConvProblem& p)
+{
+    const int sp = conv_wino_splits(p.K, p.M, p.H, p.W);
+    if (sp <= 1) return ST_OK;
+    const size_t need = (size_t)sp * p.M * p.H * p.W;
+    if (need > c->conv_scratch_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dfree(c->conv_scratch); c->conv_scratch_cap = 0;
+        ST_TRY(dmalloc(&c->conv_scratch, need));
+        c->conv_scratch_cap = need;
+    }
+    p.scratch = c->conv_scratch; p.scratch_floats = c->conv_scratch_cap;
+    return ST_OK;
+}
 
 static void shapes_for(const st_ctx* c, int H, int W, std::vector<int>& C, std::vector<int>& h, std::vector<int>& w)
 {
@@ -276,7 +295,7 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
                 { const bool wino = c->wino && L.u_fwd && conv_wino_ok(p.K, p.M, p.H, p.W);
                   // flops are the ALGORITHMIC (direct-convolution) count in both classes; Winograd executes 4/9 of them
                   ProfScope ps(c, wino ? P_CONV_FWD_WINO : P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
-                  if (wino) { p.wpack = L.u_fwd; HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
+                  if (wino) { p.wpack = L.u_fwd; ST_TRY(wino_scratch(c, p)); HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
                   else HIP_TRY(launch_conv3x3(p, c->stream)); }
                 if (next16) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
             }
@@ -377,7 +396,7 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
                 p.in = cur; p.wpack = L.w_bwd; p.bias = nullptr; p.out = dst;
                 p.mask_src = mask_src; p.inject = inject;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
-                if (wino_bwd) { p.wpack = L.u_bwd; HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
+                if (wino_bwd) { p.wpack = L.u_bwd; ST_TRY(wino_scratch(c, p)); HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
                 else HIP_TRY(launch_conv3x3(p, c->stream));
             }
         } else {
@@ -729,7 +748,7 @@ int st_destroy(st_ctx* c)
     for (auto& p : c->inject) dfree(p);
     for (auto& p : c->layer_part) dfree(p);
     for (auto& p : c->s2_part) dfree(p);
-    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->gram_fold); dfree(c->dbuf);
+    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->gram_fold); dfree(c->dbuf); dfree(c->conv_scratch);
     dfree(c->tile.p1); dfree(c->tile.p2); dfree(c->tile.p3); dfree(c->tile.pd); dfree(c->tile.wgrad);
     dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->scal); dfree(c->dot_part); dfree(c->hwc_dev);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
@@ -1723,9 +1742,15 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     p.K = K; p.M = M; p.MPad = conv_mpad(M); p.H = H; p.W = W; p.relu = dgrad_epilogue ? 0 : 1;
     if (cfg < 0) cfg = conv_pick_config(p);
     if (cfg_used) *cfg_used = cfg;
+    float* dscr = nullptr;
+    if (cfg == 100 && conv_wino_splits(K, M, H, W) > 1) {      // the automatic Winograd path may split K
+        p.scratch_floats = (size_t)conv_wino_splits(K, M, H, W) * n_out;
+        ST_TRY(dmalloc(&dscr, p.scratch_floats));
+        p.scratch = dscr;
+    }
     unsigned long long* dstamps = nullptr;
     const size_t max_blocks = (size_t)((W + 31) / 32) * ((H + 3) / 4) * (p.MPad / 64);
-    if (cfg == 6 || cfg == 103 || cfg == 105 || cfg == 106) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
+    if (cfg == 6 || cfg == 103 || cfg == 106) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
     hipStream_t s;
     HIP_TRY(hipStreamCreate(&s));
     auto launch = [&]() { return wino ? launch_conv3x3_wino_cfg(p, cfg - 101, s) : launch_conv3x3_cfg(p, cfg, s); };
@@ -1754,6 +1779,7 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
         }
     }
     if (dstamps) (void)hipFree(dstamps);
+    dfree(dscr);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
     dfree(din); dfree(dw); dfree(db); dfree(dout); dfree(dmask); dfree(dinj);
     return rc;

@@ -29,6 +29,8 @@ struct ConvProblem {
     int K, M, MPad, H, W;
     int relu;               // forward epilogue
     unsigned long long* stamps = nullptr;   // diagnostic configs only
+    float* scratch = nullptr;               // optional: room for split-K partial sums (Winograd launches with few workgroups)
+    size_t scratch_floats = 0;
 };
 size_t conv_pack_floats(int K, int M);                       // floats in a packed weight buffer
 int conv_mpad(int M);
@@ -47,6 +49,7 @@ size_t wino_pack_floats(int K, int M);
 void pack_wino_weights_fwd(const float* w, int Cout, int Cin, float* dst);
 void pack_wino_weights_dgrad(const float* w, int Cout, int Cin, float* dst);
 bool conv_wino_ok(int K, int M, int H, int W);
+int conv_wino_splits(int K, int M, int H, int W);   // split-K factor the automatic path would use (1 = none); needs splits*M*H*W floats of scratch
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);
 hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s);   // 0: 128 ch x 4x32 px, 1: 64 ch x 8x32 px
 hipError_t launch_wino_lds_probe(int extra_dma, const float* U, unsigned u_bytes, float* out, unsigned long long* cycles,

@@ -16,3 +16,29 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _release_device_contexts(request):
+    """GPU tests build many engine contexts (each owns a HIP stream and device buffers).  StyleTransfer <-> optimizer
+    reference cycles keep them alive until a garbage-collection pass, so collect after every GPU test: hardware queues
+    are a finite per-process resource, and torch (used by the tile-sharded tests) brings up its own HIP runtime late."""
+    yield
+    if request.node.get_closest_marker('gpu') is not None:
+        import gc
+        gc.collect()
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _torch_hip_runtime_first():
+    """torch bundles its own copy of the HIP runtime; the engine library links /opt/rocm's.  Both live in one process in
+    the tile-sharded tests (and in bench.py with N > 1, where torch.distributed comes up first).  Bring torch's runtime up
+    FIRST here too -- the order bench.py uses and tools/coexist_check.py validates -- instead of whenever the first
+    tile-sharded test happens to touch torch.cuda."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:           # no torch / no GPU: CPU-only session
+        pass
+    yield
