@@ -153,6 +153,15 @@ def main():
                 traffic = json.load(open(tpath))['_conv3x3_all']['hbm_bytes_per_launch']
             except (KeyError, ValueError):
                 traffic = None
+        # matrix-pipe busy fraction of the conv kernels from the committed rocprofv3 PMC pass of this same command
+        # (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): tools/pmc_mfma.py); null when absent
+        mfma_busy = None
+        mpath = os.path.join(HERE, 'profiles', 'pmc_mfma.json')
+        if args.size == 1024 and args.precision == 'fp32' and os.path.exists(mpath):
+            try:
+                mfma_busy = {k: round(v['mfma_busy_frac'], 3) for k, v in json.load(open(mpath)).items() if k.startswith('conv3x3')}
+            except (KeyError, ValueError):
+                mfma_busy = None
         out = {
             'metric': 'style-transfer iters/sec @%dpx VGG19' % args.size,
             'value': its, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -167,7 +176,7 @@ def main():
                                    % ('f32' if args.precision == 'fp32' else 'bf16', sum(c['launches'] for c in wino), launches),
                          'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic,
-                         'executed': executed, 'executed_frac': executed / peak,
+                         'executed': executed, 'executed_frac': executed / peak, 'mfma_busy_pmc': mfma_busy,
                          'note': 'achieved = algorithmic direct-conv flops / kernel time, so frac can exceed 1 where Winograd '
                                  'runs; executed = flops the MFMA pipe actually performs (Winograd: 4/9 of algorithmic)',
                          'flops_per_launch': flops / launches if launches else 0.0,
