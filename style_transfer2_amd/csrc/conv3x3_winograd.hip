@@ -292,6 +292,7 @@ struct WinoKArgs {
     const float* mask_src; const float* inject;
     int K, M, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
     unsigned in_bytes, u_bytes;
+    float* pool_out; int pool_h, pool_w;   // optional fused 2x2/2 max-pool of the (post-ReLU) output: [M][pool_h][pool_w]
     int splits; float* scratch;   // split-K (few workgroups, deep K): split s accumulates chunks [s, s+1) * nch / splits into scratch[s]
     unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
 };
@@ -557,6 +558,18 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
             }
             const float y00 = tt[0][0] + tt[0][1] + tt[0][2], y01 = tt[0][1] - tt[0][2] - tt[0][3];
             const float y10 = tt[1][0] + tt[1][1] + tt[1][2], y11 = tt[1][1] - tt[1][2] - tt[1][3];
+            if (a.pool_out) {
+                // fused max-pool (Caffe MAX 2x2/2, ceil mode): the lane's 2x2 tile IS one pooling window (tile origins are
+                // even); bias and ReLU commute with max.  A window clipped by the bottom edge keeps its first row only.
+                const int ty2 = y0 + 4 * wave_g + 2 * (t31 >> 4), tx2 = x0 + 2 * (t31 & 15);
+                if (tx2 < a.W && ty2 < a.H && mb + ee < a.M) {
+                    float pm = y00 > y01 ? y00 : y01;
+                    if (ty2 + 1 < a.H) { const float p1 = y10 > y11 ? y10 : y11; pm = pm > p1 ? pm : p1; }
+                    pm += bs[ee];
+                    if (relu) pm = pm > 0.f ? pm : 0.f;
+                    a.pool_out[((size_t)(mb + ee) * a.pool_h + (ty2 >> 1)) * a.pool_w + (tx2 >> 1)] = pm;
+                }
+            }
             // give away the row this lane does not keep, receive the partner's part of the row it keeps (quad_perm 1,0,3,2)
             const float s0 = odd ? y00 : y10, s1 = odd ? y01 : y11;
             const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xf, 0xf, true));
@@ -629,6 +642,13 @@ int conv_wino_splits(int K, int M, int H, int W)
     return sp;
 }
 
+// may this launch also write the max-pooled blob?  (forward epilogue only; not when K is split across workgroups)
+bool conv_wino_can_pool(int K, int M, int H, int W)
+{
+    static const bool off = [] { const char* e = getenv("ST2_WINO_POOL"); return e && *e == '0'; }();
+    return !off && conv_wino_ok(K, M, H, W) && conv_wino_splits(K, M, H, W) == 1;
+}
+
 bool conv_wino_ok(int K, int M, int H, int W)
 {
     return K >= 8 && K % 8 == 0 && W % 4 == 0 && M >= 48 && H >= 1 && 4ull * K * H * W < 0xfffffff0ull && 4ull * M * H * W < 0xfffffff0ull;
@@ -661,11 +681,13 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     k.splits = 1; k.scratch = nullptr;
+    k.pool_out = p.pool_out; k.pool_h = (p.H + 1) / 2; k.pool_w = (p.W + 1) / 2;
     if (forced_auto && p.scratch) {
         const int sp = conv_wino_splits(p.K, p.M, p.H, p.W);
         if (sp > 1 && p.scratch_floats >= (size_t)sp * p.M * p.H * p.W) { k.splits = sp; k.scratch = p.scratch; }
     }
     if (k.splits > 1) {
+        if (p.pool_out) return hipErrorInvalidValue;          // the caller asks conv_wino_can_pool() first
         if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)(nblk * k.splits)), dim3(256), 0, s>>>(k);
         else conv3x3_wino_f32_128x128<<<dim3((unsigned)(nblk * k.splits)), dim3(256), 0, s>>>(k);
         hipError_t e = hipGetLastError();

@@ -273,6 +273,7 @@ static int act_ensure(st_ctx* c, ActSet& a, int H, int W)
 static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
 {
     a.data[0] = const_cast<float*>(x);
+    int pooled_by_conv = -1;
     for (int i = 1; i <= last; ++i) {
         const Layer& L = c->topo[i - 1];
         if (L.is_conv) {
@@ -295,10 +296,17 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
                 { const bool wino = c->wino && L.u_fwd && conv_wino_ok(p.K, p.M, p.H, p.W);
                   // flops are the ALGORITHMIC (direct-convolution) count in both classes; Winograd executes 4/9 of them
                   ProfScope ps(c, wino ? P_CONV_FWD_WINO : P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
-                  if (wino) { p.wpack = L.u_fwd; ST_TRY(wino_scratch(c, p)); HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
+                  if (wino) {
+                      p.wpack = L.u_fwd; ST_TRY(wino_scratch(c, p));
+                      // the max-pool that follows rides on this launch's epilogue (the pooled blob is written beside the conv blob)
+                      if (i < last && !c->topo[i].is_conv && !c->bf16 && conv_wino_can_pool(p.K, p.M, p.H, p.W)) { p.pool_out = a.data[i + 1]; pooled_by_conv = i + 1; }
+                      HIP_TRY(launch_conv3x3_wino(p, c->stream));
+                  }
                   else HIP_TRY(launch_conv3x3(p, c->stream)); }
                 if (next16) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
             }
+        } else if (i == pooled_by_conv) {
+            // written by the producing conv's epilogue
         } else {
             const double n_in = (double)a.C[i - 1] * a.h[i - 1] * a.w[i - 1];
             { ProfScope ps(c, P_POOL_FWD, 0, 4.0 * n_in * 1.25);

@@ -29,6 +29,7 @@ struct ConvProblem {
     int K, M, MPad, H, W;
     int relu;               // forward epilogue
     unsigned long long* stamps = nullptr;   // diagnostic configs only
+    float* pool_out = nullptr;              // optional (Winograd forward, see conv_wino_can_pool): also write maxpool2x2/2 of `out`
     float* scratch = nullptr;               // optional: room for split-K partial sums (Winograd launches with few workgroups)
     size_t scratch_floats = 0;
 };
@@ -49,6 +50,7 @@ size_t wino_pack_floats(int K, int M);
 void pack_wino_weights_fwd(const float* w, int Cout, int Cin, float* dst);
 void pack_wino_weights_dgrad(const float* w, int Cout, int Cin, float* dst);
 bool conv_wino_ok(int K, int M, int H, int W);
+bool conv_wino_can_pool(int K, int M, int H, int W);   // launch_conv3x3_wino may fuse the following max-pool (ConvProblem::pool_out)
 int conv_wino_splits(int K, int M, int H, int W);   // split-K factor the automatic path would use (1 = none); needs splits*M*H*W floats of scratch
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);
 hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s);   // 0: 128 ch x 4x32 px, 1: 64 ch x 8x32 px
