@@ -128,10 +128,7 @@ __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = i0 + wm * (T * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                if (row < C && col < C) {
-                    dst[(size_t)row * C + col] = acc[i][j][e];
-                    if (!diag) dst[(size_t)col * C + row] = acc[i][j][e];       // the mirrored tile (same products, same order)
-                }
+                if (row < C && col < C) dst[(size_t)row * C + col] = acc[i][j][e];     // upper-triangular tiles only: the reduction mirrors
             }
         }
 }
@@ -248,10 +245,7 @@ __device__ __forceinline__ void gram_partial_dma_body(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = i0 + wm * (T * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
-                if (row < C && col < C) {
-                    dst[(size_t)row * C + col] = acc[i][j][e];
-                    if (!diag) dst[(size_t)col * C + row] = acc[i][j][e];
-                }
+                if (row < C && col < C) dst[(size_t)row * C + col] = acc[i][j][e];
             }
         }
 }
@@ -283,19 +277,25 @@ hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, cons
 }
 
 // `out` is written with leading dimension out_ld (>= C): the style-gradient GEMM wants D as [C][MPad].
+// The slabs hold the upper-triangular bt x bt tiles only (G is symmetric); an element of such a tile is written to
+// (r, c) and, for an off-diagonal tile, to (c, r) as well -- same value, so the result is exactly symmetric.
 __global__ __launch_bounds__(256) void gram_reduce_k(const float* __restrict__ slabs, const float* __restrict__ target,
                                                      float* __restrict__ out, float* __restrict__ partial,
-                                                     int cc, int splits, float n, int C, int out_ld)
+                                                     int cc, int splits, float n, int C, int out_ld, int bt)
 {
     __shared__ float scratch[4];
     float acc[1] = {0.f};
     for (int i = blockIdx.x * 256 + threadIdx.x; i < cc; i += gridDim.x * 256) {
+        const int r = i / C, c = i - r * C;
+        const int tr = r / bt, tc = c / bt;
+        if (tr > tc) continue;                       // produced by the mirror of (c, r)
         float sum = 0.f;
         for (int s = 0; s < splits; ++s) sum += slabs[(size_t)s * cc + i];
         float v = sum / n;                           // np.dot(x, x.T) / np.float32(x.size)
-        if (target) v -= target[i];                  // gram_matrix(F) - grams[layer]
-        out[(i / C) * out_ld + (i % C)] = v;
+        if (target) v -= target[i];                  // gram_matrix(F) - grams[layer]  (the target is symmetric too)
+        out[r * out_ld + c] = v;
         acc[0] += v * v;
+        if (tr < tc) { out[c * out_ld + r] = v; acc[0] += v * v; }
     }
     block_sum(acc, scratch);
     if (threadIdx.x == 0 && partial) partial[blockIdx.x] = acc[0];
@@ -304,11 +304,12 @@ __global__ __launch_bounds__(256) void gram_reduce_k(const float* __restrict__ s
 // First stage for many splits: fold `splits` slabs into `groups` slabs (each block: 256 elements x
 // one group of consecutive splits, summed in order) so the final pass is short and still deterministic.
 __global__ __launch_bounds__(256) void gram_fold_k(const float* __restrict__ slabs, float* __restrict__ folded,
-                                                   int cc, int splits, int per_group)
+                                                   int cc, int splits, int per_group, int C, int bt)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int g = blockIdx.y;
     if (i >= cc) return;
+    if ((i / C) / bt > (i % C) / bt) return;         // lower-triangular tiles are never written nor read
     const int s0 = g * per_group, s1 = min(splits, s0 + per_group);
     float sum = 0.f;
     for (int s = s0; s < s1; ++s) sum += slabs[(size_t)s * cc + i];
@@ -325,13 +326,13 @@ hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* ta
     const int groups = gram_fold_groups(pl);
     if (groups) {
         const int per = (pl.splits + groups - 1) / groups;
-        gram_fold_k<<<dim3((cc + 255) / 256, groups), 256, 0, s>>>(slabs, folded, cc, pl.splits, per);
+        gram_fold_k<<<dim3((cc + 255) / 256, groups), 256, 0, s>>>(slabs, folded, cc, pl.splits, per, C, pl.bt);
         slabs = folded;
         splits = (pl.splits + per - 1) / per;
     }
     const int grid = reduce_grid((size_t)cc, 256, kMaxPartials);
     if (n_partial) *n_partial = grid;
-    gram_reduce_k<<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)divisor, C, out_ld);
+    gram_reduce_k<<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)divisor, C, out_ld, pl.bt);
     return hipGetLastError();
 }
 
