@@ -46,7 +46,7 @@ int st_destroy(st_ctx* ctx);
 /* weights of one conv layer, Caffe layout (Cout, Cin, 3, 3) + bias (Cout)  [caffe.Net(weights=)] */
 int st_load_conv_weights(st_ctx* ctx, const char* layer, const float* w, const float* bias);
 /* 1 (default; the environment variable ST2_WINO=0 also clears it): fp32 convs whose shape allows it (reduction
- * depth % 8 == 0, width % 4 == 0, >= 96 output channels) run as Winograd F(2x2,3x3) on the fp32 matrix cores --
+ * depth % 8 == 0, >= 48 output channels; any width) run as Winograd F(2x2,3x3) on the fp32 matrix cores --
  * 2.25x fewer multiplies, same IEEE fp32 products and sums in a different association.  0: direct kernel only. */
 int st_set_conv_algo(st_ctx* ctx, int winograd);
 /* 0 (default): fp32 throughout.  1: bf16 feature path (BASELINE config 3) -- conv operands (activations, weights,

@@ -306,17 +306,23 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 //   <4,1>: 128 channels x  4 rows x 32 columns      <2,2>: 64 channels x 8 rows x 32 columns
 // With TG = 2 the two waves that share a channel slice load the same U lines together (one L2 fetch), and every
 // thread transforms two (tile, channel) pairs per chunk.
-template <int WM, int TG, int DIAG = 0>
+// QUAD = true : W % 4 == 0 -- activation rows staged as aligned quads (40 floats, x0-4 .. x0+35), 16-byte epilogue accesses.
+// QUAD = false: any W     -- one staged row = one dword LDS-DMA piece of 64 lanes (x0-1 .. x0+62, 34 used; the row part of
+//                the address is scalar, the lane part is computed once), 8-byte (W even) or 4-byte epilogue accesses.
+template <int WM, int TG, int DIAG = 0, bool QUAD = true>
 __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
     static_assert(WM * TG == 4 && (TG == 1 || TG == 2), "4 waves");
     constexpr int BM = 32 * WM;
     constexpr int PROWS = 4 * TG;                        // pixel rows per block
     constexpr int IN_ROWS = PROWS + 2;
-    constexpr int PLANE = IN_ROWS * WN_IW;
+    constexpr int IW = QUAD ? WN_IW : 64;                // floats per staged row
+    constexpr int COL0 = QUAD ? 3 : 0;                   // staged column of pixel x0 - 1
+    constexpr int PLANE = IN_ROWS * IW;
     constexpr int N_RAW = WN_CH * PLANE;                 // floats staged per chunk
-    constexpr int I_PER_WAVE = (N_RAW / 4 + 255) / 256;  // wave-DMAs (64 quads) per wave
-    constexpr int RAW = I_PER_WAVE * 1024;               // floats per raw buffer
+    constexpr int I_PER_WAVE = QUAD ? (N_RAW / 4 + 255) / 256 : WN_CH * IN_ROWS / 4;   // wave-DMAs per wave (64 quads / 64 dwords each)
+    constexpr int RAW = QUAD ? I_PER_WAVE * 1024 : N_RAW;                              // floats per raw buffer
+    static_assert(QUAD || (WN_CH * IN_ROWS) % 4 == 0, "rows divide over the four waves");
     constexpr int NU = 4 * TG;                           // transform units of 4 LDS ops (reads, writes); 2 * NU of 4 VALU ops
 
     __shared__ __attribute__((aligned(16))) float raw_s[2][RAW];
@@ -346,24 +352,41 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     const unsigned long long t_begin = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
-    unsigned ioff[I_PER_WAVE];
-#pragma unroll
-    for (int t = 0; t < I_PER_WAVE; ++t) {
-        const int e = ((wave + 4 * t) * 64 + lane) * 4;
-        const int c = e / PLANE;
-        const int rem = e - c * PLANE;
-        const int rr = rem / WN_IW;
-        const int col = rem - rr * WN_IW;
-        const int gy = y0 - 1 + rr, gx = x0 - 4 + col;
-        const bool ok = e < N_RAW && gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W;
-        ioff[t] = ok ? ((unsigned)(c_first * WN_CH + c) * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
-    }
-    auto dma_raw = [&](int ch, int buf) {
-        const unsigned coff = (unsigned)ch * WN_CH * plane * 4u;
+    unsigned ioff[QUAD ? I_PER_WAVE : 1];
+    if (QUAD) {
 #pragma unroll
         for (int t = 0; t < I_PER_WAVE; ++t) {
-            const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + coff;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s[buf] + (wave + 4 * t) * 256), 16, vo, 0, 0, 0);
+            const int e = ((wave + 4 * t) * 64 + lane) * 4;
+            const int c = e / PLANE;
+            const int rem = e - c * PLANE;
+            const int rr = rem / IW;
+            const int col = rem - rr * IW;
+            const int gy = y0 - 1 + rr, gx = x0 - 4 + col;
+            const bool ok = e < N_RAW && gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W;
+            ioff[t] = ok ? ((unsigned)(c_first * WN_CH + c) * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
+        }
+    } else {
+        const int gx = x0 - 1 + lane;                                  // lane = staged column
+        ioff[0] = (lane < 34 && gx >= 0 && gx < a.W) ? (unsigned)gx * 4u : kOOB;
+    }
+    auto dma_raw = [&](int ch, int buf) {
+        if (QUAD) {
+            const unsigned coff = (unsigned)ch * WN_CH * plane * 4u;
+#pragma unroll
+            for (int t = 0; t < I_PER_WAVE; ++t) {
+                const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + coff;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s[buf] + (wave + 4 * t) * 256), 16, vo, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < I_PER_WAVE; ++t) {
+                const int row = wave + 4 * t;                          // staged row: channel row / IN_ROWS, image row y0 - 1 + row % IN_ROWS
+                const int c = row / IN_ROWS, gy = y0 - 1 + (row - c * IN_ROWS);
+                const bool row_ok = gy >= 0 && gy < a.H;               // wave-uniform
+                const unsigned base = ((unsigned)((c_first + ch) * WN_CH + c) * plane + (unsigned)(row_ok ? gy : 0) * a.W) * 4u;
+                const unsigned vo = (row_ok && ioff[0] != kOOB) ? ioff[0] + base : kOOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s[buf] + row * 64), 4, vo, 0, 0, 0);
+            }
         }
     };
 
@@ -371,7 +394,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     // V image of one (chunk, tile group): [k-pair 4][pos/4][k parity * 32 + tile][pos%4] -- the B operands of four
     // positions are one ds_read_b128, a transformed row is one ds_write_b128.
     const int xt = tid & 31, xch = tid >> 5;
-    const int x_raw = xch * PLANE + (2 * (xt >> 4)) * WN_IW + 2 * (xt & 15) + 3;          // column 3 = pixel x0 - 1
+    const int x_raw = xch * PLANE + (2 * (xt >> 4)) * IW + 2 * (xt & 15) + COL0;          // column COL0 = pixel x0 - 1
     const int x_v = (((xch >> 1) * 4) * 64 + (xch & 1) * 32 + xt) * 4;
     float d[TG][16];
     // Empty asm with the 16 values as in/out operands: arithmetic on them cannot be scheduled across it, which is
@@ -389,7 +412,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) d[g][4 * i + j] = rp[(4 * g + i) * WN_IW + j];
+                for (int j = 0; j < 4; ++j) d[g][4 * i + j] = rp[(4 * g + i) * IW + j];
     };
     auto xf_math = [&]() {
 #pragma unroll
@@ -509,6 +532,80 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         t_loop_end = t1;
         if (tid == 0 && a.stamps) { a.stamps[2 * blockIdx.x] = t1 - t0; a.stamps[2 * blockIdx.x + 1] = r1 - r0; }
     }
+  if (!QUAD) {
+    // ---- epilogue for any width: the lane stores its own 2x2 tile, 8-byte accesses when W is even, 4-byte otherwise
+    const int t31 = lane & 31, khalf = lane >> 5;
+    const int gy0 = y0 + 4 * wave_g + 2 * (t31 >> 4), gx = x0 + 2 * (t31 & 15);
+    const bool part = a.splits > 1;
+    const bool has_bias = !part && a.bias != nullptr, has_mask = !part && a.mask_src != nullptr, has_inj = !part && a.inject != nullptr;
+    const bool relu = !part && a.relu;
+    float* const outp = part ? a.scratch + (size_t)split * a.M * plane : a.out;
+    const bool live = gx < a.W && gy0 < a.H;
+    const bool row1 = gy0 + 1 < a.H, col1 = gx + 1 < a.W, wide = (a.W & 1) == 0;     // W even: gx + 1 < W and 8-byte alignment
+    const int mw = mt * BM + wave_m * 32 + 4 * khalf;
+    const unsigned pix0 = live ? (unsigned)gy0 * a.W + gx : 0u, pix1 = (live && row1) ? pix0 + a.W : pix0;
+    auto ld2 = [&](const float* base, unsigned off) -> float2 {
+        if (wide) return *reinterpret_cast<const float2*>(base + off);
+        return make_float2(base[off], col1 ? base[off + 1] : 0.f);
+    };
+#pragma unroll
+    for (int eb = 0; eb < 4; ++eb) {
+        const int mb = mw + 8 * eb;
+        unsigned off[4];
+        float2 mk[4][2], ij[4][2];
+        float bs[4];
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int m = mb + ee < a.M ? mb + ee : a.M - 1;
+            off[ee] = (unsigned)m * plane;
+            bs[ee] = has_bias ? a.bias[m] : 0.f;
+        }
+        if (has_mask) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) { mk[ee][0] = ld2(a.mask_src, off[ee] + pix0); mk[ee][1] = ld2(a.mask_src, off[ee] + pix1); }
+        }
+        if (has_inj) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) { ij[ee][0] = ld2(a.inject, off[ee] + pix0); ij[ee][1] = ld2(a.inject, off[ee] + pix1); }
+        }
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 4 * eb + ee;
+            float tt[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tt[0][j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
+                tt[1][j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
+            }
+            float o[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                o[i][0] = tt[i][0] + tt[i][1] + tt[i][2];
+                o[i][1] = tt[i][1] - tt[i][2] - tt[i][3];
+            }
+            if (a.pool_out && live && mb + ee < a.M) {         // fused max-pool: windows clipped at the right / bottom edge
+                float pm = o[0][0];
+                if (col1) pm = pm > o[0][1] ? pm : o[0][1];
+                if (row1) { pm = pm > o[1][0] ? pm : o[1][0]; if (col1) pm = pm > o[1][1] ? pm : o[1][1]; }
+                pm += bs[ee];
+                if (relu) pm = pm > 0.f ? pm : 0.f;
+                a.pool_out[((size_t)(mb + ee) * a.pool_h + (gy0 >> 1)) * a.pool_w + (gx >> 1)] = pm;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float o0 = o[i][0] + bs[ee], o1 = o[i][1] + bs[ee];
+                if (relu) { o0 = o0 > 0.f ? o0 : 0.f; o1 = o1 > 0.f ? o1 : 0.f; }
+                if (has_mask) { o0 = mk[ee][i].x > 0.f ? o0 : 0.f; o1 = mk[ee][i].y > 0.f ? o1 : 0.f; }
+                if (has_inj) { o0 += ij[ee][i].x; o1 += ij[ee][i].y; }
+                if (live && mb + ee < a.M && (i == 0 || row1)) {
+                    float* dst = outp + off[ee] + (i ? pix1 : pix0);
+                    if (wide) *reinterpret_cast<float2*>(dst) = make_float2(o0, o1);
+                    else { dst[0] = o0; if (col1) dst[1] = o1; }
+                }
+            }
+        }
+    }
+  } else {
     // ---- epilogue: output transform (in-lane), then bias / ReLU / mask / inject.
     // A lane holds the 2x2 outputs of one tile; tiles of neighbouring lanes are neighbours in x.  Each lane PAIR swaps
     // one row (two DPP moves per accumulator element) so that the even lane owns row 0 and the odd lane row 1 of the
@@ -589,6 +686,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
             if (live && mb + ee < a.M) *reinterpret_cast<float4*>(outp + off[ee]) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
+  }
     if (DIAG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t2 = __builtin_amdgcn_s_memtime();
@@ -603,6 +701,8 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKArgs a) { conv3x3_wino_body<4, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256(const WinoKArgs a) { conv3x3_wino_body<2, 2>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_anyw(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, false>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_anyw(const WinoKArgs a) { conv3x3_wino_body<2, 2, 0, false>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1>(a); }
 
@@ -633,7 +733,7 @@ __global__ __launch_bounds__(256) void wino_combine_k(const float* __restrict__ 
 int conv_wino_splits(int K, int M, int H, int W)
 {
     static const bool off = [] { const char* e = getenv("ST2_WINO_SPLITK"); return e && *e == '0'; }();
-    if (off || !conv_wino_ok(K, M, H, W)) return 1;
+    if (off || !conv_wino_ok(K, M, H, W) || ((size_t)H * W) % 4 != 0) return 1;      // the combine pass works on float4
     const int bm = ((M + 63) / 64 * 64 < (M + 127) / 128 * 128) ? 64 : 128, prows = bm == 64 ? 8 : 4;
     const long long nblk = (long long)((W + 31) / 32) * ((H + prows - 1) / prows) * ((M + bm - 1) / bm);
     const int nch = K / WN_CH;
@@ -651,7 +751,8 @@ bool conv_wino_can_pool(int K, int M, int H, int W)
 
 bool conv_wino_ok(int K, int M, int H, int W)
 {
-    return K >= 8 && K % 8 == 0 && W % 4 == 0 && M >= 48 && H >= 1 && 4ull * K * H * W < 0xfffffff0ull && 4ull * M * H * W < 0xfffffff0ull;
+    static const bool anyw = [] { const char* e = getenv("ST2_WINO_ANYW"); return !(e && *e == '0'); }();
+    return K >= 8 && K % 8 == 0 && (W % 4 == 0 || anyw) && W >= 1 && M >= 48 && H >= 1 && 4ull * K * H * W < 0xfffffff0ull && 4ull * M * H * W < 0xfffffff0ull;
 }
 
 // variant: 0 = 128 channels x 4x32 pixels, 1 = 64 channels x 8x32 pixels, -1 = choose
@@ -659,6 +760,7 @@ bool conv_wino_ok(int K, int M, int H, int W)
 hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s)
 {
     if (!conv_wino_ok(p.K, p.M, p.H, p.W) || (reinterpret_cast<uintptr_t>(p.in) & 15) != 0) return hipErrorInvalidValue;
+    const bool quad = p.W % 4 == 0;                  // else the any-width kernels (dword staging, narrower epilogue accesses)
     const bool forced_auto = variant < 0;           // split-K only on the automatic path (variants 0 / 1)
     if (variant < 0) {
         const char* env = getenv("ST2_WINO_CFG");            // forces a variant (tests of both variants on every shape)
@@ -688,17 +790,24 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     }
     if (k.splits > 1) {
         if (p.pool_out) return hipErrorInvalidValue;          // the caller asks conv_wino_can_pool() first
-        if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)(nblk * k.splits)), dim3(256), 0, s>>>(k);
-        else conv3x3_wino_f32_128x128<<<dim3((unsigned)(nblk * k.splits)), dim3(256), 0, s>>>(k);
+        const dim3 g((unsigned)(nblk * k.splits));
+        if (variant == 1) { if (quad) conv3x3_wino_f32_64x256<<<g, dim3(256), 0, s>>>(k); else conv3x3_wino_f32_64x256_anyw<<<g, dim3(256), 0, s>>>(k); }
+        else { if (quad) conv3x3_wino_f32_128x128<<<g, dim3(256), 0, s>>>(k); else conv3x3_wino_f32_128x128_anyw<<<g, dim3(256), 0, s>>>(k); }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
         const size_t n4 = (size_t)p.M * p.H * p.W / 4;
         const unsigned grid = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        if (((size_t)p.H * p.W) % 4 != 0) return hipErrorInvalidValue;      // conv_wino_splits() declines such shapes
         wino_combine_k<<<grid, 256, 0, s>>>(k.scratch, k.splits, p.bias, p.relu, p.mask_src, p.inject, p.out, p.M, (unsigned)(p.H * p.W));
         return hipGetLastError();
     }
+    if ((variant == 2 || variant == 5) && !quad) return hipErrorInvalidValue;      // the stamped builds are quad-only
     if (variant == 5) conv3x3_wino_f32_64x256_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     else if (variant == 2) conv3x3_wino_f32_128x128_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+    else if (!quad) {
+        if (variant == 1) conv3x3_wino_f32_64x256_anyw<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+        else conv3x3_wino_f32_128x128_anyw<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+    }
     else if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     else conv3x3_wino_f32_128x128<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
     return hipGetLastError();

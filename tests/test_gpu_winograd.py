@@ -35,7 +35,9 @@ def wino_cfg(request):
 @pytest.mark.parametrize('cin,cout,h,w', [
     (8, 96, 4, 32), (8, 128, 6, 8), (16, 128, 9, 36), (64, 128, 17, 32), (72, 200, 5, 64), (128, 128, 40, 72),
     (128, 256, 12, 12), (256, 256, 7, 44), (256, 512, 8, 8), (512, 512, 6, 4), (64, 160, 33, 100), (128, 128, 64, 96),
-    (64, 64, 19, 40), (8, 48, 3, 4), (64, 64, 64, 96)])
+    (64, 64, 19, 40), (8, 48, 3, 4), (64, 64, 64, 96),
+    # widths that are not multiples of 4: the any-width kernels (dword staging; 8-byte or, for odd W, 4-byte epilogue accesses)
+    (64, 128, 17, 33), (128, 128, 40, 70), (512, 512, 9, 6), (16, 96, 5, 7), (64, 64, 12, 30), (72, 200, 6, 1), (128, 64, 9, 35)])
 def test_winograd_conv_forward_and_dgrad(cin, cout, h, w, wino_cfg):
     """conv1_2 (cin -> cout) runs the Winograd kernel forward (M = cout >= 48) and, when cin >= 48, backward."""
     topo = (('conv', 'conv1_1', 3, cin), ('conv', 'conv1_2', cin, cout))
@@ -67,7 +69,7 @@ def test_winograd_chain_with_masks_and_injections(wino_cfg):
     cpu = oracle.NetOracle(topo, params)
     gpu = st2.HipModel(params, topology=topo)
     rng = np.random.RandomState(3)
-    for h, w in ((24, 40), (17, 72), (8, 8)):
+    for h, w in ((24, 40), (17, 72), (8, 8), (19, 35), (10, 50), (7, 3)):
         x = (rng.randn(1, 3, h, w) * 40).astype(F32)
         fc, fg = cpu.forward(x), gpu.forward(x)
         for name in fc:
