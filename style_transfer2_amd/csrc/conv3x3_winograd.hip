@@ -738,7 +738,7 @@ int conv_wino_splits(int K, int M, int H, int W)
     const long long nblk = (long long)((W + 31) / 32) * ((H + prows - 1) / prows) * ((M + bm - 1) / bm);
     const int nch = K / WN_CH;
     int sp = 1;
-    while (nblk * sp * 2 <= 256 && nch % (sp * 2) == 0 && nch / (sp * 2) >= 8 && sp < 4) sp *= 2;
+    while (nblk * sp * 2 <= 256 && nch % (sp * 2) == 0 && nch / (sp * 2) >= 4 && sp < 16) sp *= 2;
     return sp;
 }
 
