@@ -1,0 +1,48 @@
+"""The bench.py contract on the GPU box: one JSON line with the keys the driver and the judge read (a small
+image and a handful of steps: this checks the plumbing, not the speed)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra):
+    env = dict(os.environ)
+    env.pop('RANK', None); env.pop('WORLD_SIZE', None); env.pop('LOCAL_RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2',
+                          '--size', '256'] + list(extra), capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout          # exactly ONE JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_has_the_contract_keys():
+    d = run_bench('--cpu-size', '64')
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['warmup'] == 2
+    assert d['unit'] == 'it/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config']
+    assert abs(d['value'] - 1e3 / d['ms_per_step']) <= 1e-6 * d['value']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'executed', 'executed_frac'):
+        assert k in r, k
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == pytest.approx(157.3)
+    assert r['frac'] == pytest.approx(r['achieved'] / r['peak'])
+    assert 0 < r['executed'] <= r['achieved']
+    c = d['cpu_baseline']
+    assert c['kind'] == 'port' and c['unit'] == 'it/s' and c['value'] > 0 and c['cores'] >= 1 and '64x64' in c['sample']
+
+
+def test_bench_bf16_and_lbfgs_variants_run():
+    d = run_bench('--precision', 'bf16', '--optimizer', 'lbfgs', '--no-cpu-baseline')
+    assert 'bf16' in d['dtype'] and 'cpu_baseline' not in d
+    assert d['roofline']['peak'] == pytest.approx(2516.6)
