@@ -101,6 +101,10 @@ int st_adam_set_state(st_ctx* ctx, const float* m, const float* v, int items1, i
  * out_hwc (H,W,3 float32) and trace may be NULL: then nothing is copied back and the call does not
  * synchronise (device-resident loop). */
 int st_step(st_ctx* ctx, float* out_hwc, double* trace, float* out_loss);
+/* Steps so far that ran as a hipGraph replay.  Opt-in (environment ST2_GRAPH=1; ST2_GRAPH_MAX_PX=<edge>, default 768):
+ * steady-state Adam steps are captured once per ping-pong parity and replayed, bit-identical to plain launches.  Measured
+ * on MI355X it is no faster (the step is bound by the dependent kernels' execution latency), hence off by default. */
+int st_graph_replays(st_ctx* ctx, long long* n);
 int st_sync(st_ctx* ctx);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */

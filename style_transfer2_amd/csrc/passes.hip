@@ -272,6 +272,8 @@ __global__ __launch_bounds__(256) void image_pass_k(const ImagePassArgs a)
     const int beta_is_2 = a.tv_beta == 2.0f;
     const int do_tv = a.tv_w != 0.0f || true;   // value is traced even when the weight is zero
     (void)do_tv;
+    // per-step Adam scalars: by value, or (graph replay: the launch arguments are frozen) from device memory
+    const float corr1 = a.dyn ? a.dyn[0] : a.corr1, corr2 = a.dyn ? a.dyn[1] : a.corr2, step = a.dyn ? a.dyn[2] : a.step;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int x = (int)(idx % W);
@@ -326,9 +328,9 @@ __global__ __launch_bounds__(256) void image_pass_k(const ImagePassArgs a)
             const float v_new = a.d2 * v_old + a.c2 * (g * g);
             a.m[idx] = m_new;
             a.v[idx] = v_new;
-            const float m_hat = m_new / a.corr1;
-            const float v_hat = v_new / a.corr2;
-            a.x_out[idx] = xv - (a.step * m_hat) / (sqrtf(v_hat) + 1e-8f);
+            const float m_hat = m_new / corr1;
+            const float v_hat = v_new / corr2;
+            a.x_out[idx] = xv - (step * m_hat) / (sqrtf(v_hat) + 1e-8f);
         }
     }
     block_sum(acc, scratch);
@@ -336,6 +338,13 @@ __global__ __launch_bounds__(256) void image_pass_k(const ImagePassArgs a)
 #pragma unroll
         for (int i = 0; i < 6; ++i) a.partial[i * kMaxPartials + blockIdx.x] = acc[i];
     }
+}
+
+__global__ void set_scalars3_k(float* dst, float a, float b, float c) { dst[0] = a; dst[1] = b; dst[2] = c; }
+hipError_t launch_set_scalars3(float* dst, float a, float b, float c, hipStream_t s)
+{
+    set_scalars3_k<<<1, 1, 0, s>>>(dst, a, b, c);
+    return hipGetLastError();
 }
 
 hipError_t launch_image_pass(const ImagePassArgs& a, int* n_partial, hipStream_t s)

@@ -162,7 +162,9 @@ struct ImagePassArgs {
     int m_is_zero;          // m treated as 0 (after clear) without a memset
     int v_is_zero;
     float* partial;         // 6 rows of kMaxPartials: tv, p, scd^2, (tv_w g_tv)^2, (p_w g_p)^2, grad^2
+    const float* dyn = nullptr;   // optional device {corr1, corr2, step} overriding the by-value ones (hipGraph replays)
 };
+hipError_t launch_set_scalars3(float* dst, float a, float b, float c, hipStream_t s);
 hipError_t launch_image_pass(const ImagePassArgs& a, int* n_partial, hipStream_t s);
 // Tile-sharded variant: the tile [ty, ty+th) x [tx, tx+tw) of a window image of pitch ww; neighbours outside
 // the tile come from `ring` ([3][th+2][tw+2], the periodic-wrap neighbourhood gathered from the owners).

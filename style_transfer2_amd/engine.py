@@ -64,6 +64,12 @@ class Engine:
         self.blob_names = [self.lib.st_blob_name(self._ctx, i).decode() for i in range(n)]
         self._index = {name: i for i, name in enumerate(self.blob_names)}
 
+    def graph_replays(self):
+        """Number of steps that ran as a hipGraph replay (steady-state Adam steps at small image sizes)."""
+        n = c_longlong()
+        check(self.lib.st_graph_replays(self._ctx, byref(n)))
+        return n.value
+
     def set_conv_algo(self, winograd):
         """True (default): eligible fp32 convs run as Winograd F(2x2,3x3); False: direct kernel only."""
         check(self.lib.st_set_conv_algo(self._ctx, 1 if winograd else 0))
