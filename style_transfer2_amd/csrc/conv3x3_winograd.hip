@@ -240,22 +240,28 @@ hipError_t launch_wino_probe(const float* U, float* out, int blocks, int nkp, in
 // 4 multiplies per output instead of 9, so the matrix pipe executes 2.25x fewer flops than the direct kernel
 // (conv3x3_mfma.hip) for the same result up to fp32 reassociation (every product and sum is still IEEE fp32).
 //
-// One workgroup = 4 waves = 128 output channels x (4 rows x 32 columns) pixels = 32 tiles (2 tile rows x 16).
-// Wave w owns channels [32w, 32w+32) and all 32 tiles: 16 positions x one 32x32 accumulator = 256 AGPRs,
-// which is why the kernel runs one wave per SIMD and everything below is software-pipelined by hand.
+// One workgroup = 4 waves = 128 output channels x (4 rows x 32 columns) pixels = 32 tiles (2 tile rows x 16), or
+// 64 channels x (8 rows x 32 columns) for layers with <= 64 output channels.
+// A wave owns 32 channels x 32 tiles: 16 positions x one 32x32 accumulator = 256 AGPRs, which is why the kernel
+// runs one wave per SIMD and everything below is software-pipelined by hand.
 //   U (host-transformed weights) never touches LDS: it is packed in MFMA A-operand order
 //       [m/32][k/2][pos/4][lane][pos%4]   (lane&31 -> m, lane>>5 -> k parity)
-//     and streamed L2 -> VGPR with global_load_dwordx4, four k-pairs (one chunk) ahead (16 B/clk/CU; the blocks that share
-//     an XCD walk the same 128-channel slice in step, so the stream is served by that XCD's L2);
-//   raw activations: LDS-DMA, 8 channels x 6 rows x 40 floats per chunk (zero fill outside the image = padding),
-//     double-buffered, issued two chunks ahead;
-//   V: each thread transforms one (tile, channel) pair per chunk (32 adds) and writes the 16 positions to the
-//     B-operand image [k-pair][pos][k parity * 32 + tile], double-buffered, one chunk ahead;
-//   per k-pair: 16 MFMAs, each followed by a pinned slice of the auxiliary work (operand fetch for the next
-//     k-pair, U loads, a quarter of the input transform, DMA issue), one s_barrier per 64 MFMAs.
-// Epilogue: the output transform is in-lane (a lane holds all 16 positions of its (m, tile) pairs), then the same
-// bias / ReLU / ReLU-mask / injected-diff epilogue as the direct kernel, float2 stores.
-// Requirements (else the caller uses the direct kernel): K % 8 == 0, W % 4 == 0, tensors < 4 GiB.
+//     and streamed L2 -> VGPR with global_load_dwordx4 three k-pairs ahead through a 4-set register ring (16 KiB per
+//     k-pair per CU: the CU's vector-memory ingest rate, ~13.8 B/clk, is what bounds the main loop; the workgroups
+//     that share an XCD walk the same channel slice in step, so the stream is served by that XCD's L2);
+//   raw activations: LDS-DMA, 8 channels x 6 rows x 40 floats per chunk as aligned quads (any-width build: one
+//     64-lane dword piece per row), zero fill outside the image = the padding, double-buffered, two chunks ahead;
+//   V: each thread transforms one (tile, channel) pair per chunk (32 adds) one chunk ahead and writes the four rows
+//     of B^T d B as ds_write_b128 into the B-operand image [k-pair][pos/4][k parity * 32 + tile][pos%4];
+//   per k-pair: 16 MFMAs; the auxiliary work (B operands of the next k-pair = 4 ds_read_b128, U of k-pair +3,
+//     a third of the input transform, DMA issue) sits in ONE clump after the first MFMA, the other 15 MFMAs run
+//     back to back (one wave per SIMD: nothing a wave issues overlaps its own MFMAs); one s_barrier per 64 MFMAs
+//     with `s_waitcnt vmcnt(8)` so that the U ring stays in flight across it.
+// Epilogue: the output transform is in-lane (a lane holds all 16 positions of its (m, tile) pairs); lane pairs swap
+// one row (DPP) so that every lane loads / stores 16 bytes; bias / ReLU / ReLU-mask / injected diff as in the direct
+// kernel; optionally the 2x2 max-pool of the output (a tile is one pooling window).  Launches with few workgroups
+// split K (wino_combine_k finishes them).
+// Requirements (else the caller uses the direct kernel): K % 8 == 0, >= 48 output channels, tensors < 4 GiB.
 // ===========================================================================================================
 
 constexpr int WN_CH = 8;                         // input channels per chunk (4 k-pairs)
