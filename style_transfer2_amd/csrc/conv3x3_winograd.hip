@@ -1,9 +1,11 @@
-// Winograd F(2x2,3x3) conv3x3 on the fp32 matrix cores (gfx950) -- feasibility probe of the operand feed.
+// Winograd F(2x2,3x3) conv3x3 on the fp32 matrix cores (gfx950): forward and data-gradient of the VGG convs
+// (reference: pycaffe Convolution forward / backward behind worker.py:84-86 and :100-106), plus the probes that sized
+// the design.  File layout: (1) probes -- operand-feed probe (can the transformed weights stream L2 -> MFMA operand
+// registers fast enough?), issue-rate probe (what does a wave's own auxiliary instruction cost between MFMAs at one wave
+// per SIMD?), LDS-staged-feed probe; (2) the kernel (conv3x3_wino_body) and its host side (packing, launch, split-K).
 //
 // The 16 transform-domain GEMMs of one block keep 16 x (32 m x 32 tiles) fp32 accumulators per wave (256 VGPRs),
 // so the block tile is small (128 m x 32 tiles) and the transformed weights U have to stream at ~16 B/clk/CU.
-// The probe measures whether that stream can come straight from L2 into MFMA A-operand registers
-// (global_load_dwordx4, packed in operand order, no LDS) while the matrix pipe stays busy.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
