@@ -331,7 +331,6 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     constexpr int I_PER_WAVE = QUAD ? (N_RAW / 4 + 255) / 256 : WN_CH * IN_ROWS / 4;   // wave-DMAs per wave (64 quads / 64 dwords each)
     constexpr int RAW = QUAD ? I_PER_WAVE * 1024 : N_RAW;                              // floats per raw buffer
     static_assert(QUAD || (WN_CH * IN_ROWS) % 4 == 0, "rows divide over the four waves");
-    constexpr int NU = 4 * TG;                           // transform units of 4 LDS ops (reads, writes); 2 * NU of 4 VALU ops
 
     __shared__ __attribute__((aligned(16))) float raw_s[2][RAW];
     __shared__ __attribute__((aligned(16))) float v_s[2][TG][WN_V];

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <string>
+#include <memory>
 #include <vector>
 
 using namespace st2;
@@ -644,7 +645,7 @@ static int lbfgs_step(st_ctx* c)
         ST_TRY(eval_objective(c, x, true, c->g_cur, false, nullptr));
         c->have_cur = true;
     }
-    ProfScope* ps = new ProfScope(c, P_VECTOR, 0, 0);
+    std::unique_ptr<ProfScope> ps(new ProfScope(c, P_VECTOR, 0, 0));      // released on every exit path
     // p = inv_hv(grad): optimizers.py:89-108
     HIP_TRY(hipMemcpyAsync(c->pvec, c->g_cur, n * sizeof(float), hipMemcpyDeviceToDevice, s));
     for (int k = (int)c->order.size() - 1; k >= 0; --k) {
@@ -676,14 +677,14 @@ static int lbfgs_step(st_ctx* c)
     // s = -step * p ; x += s
     HIP_TRY(launch_lincomb((float)(-c->step_size), c->pvec, 0.f, nullptr, c->hs[slot], n, s));
     HIP_TRY(launch_lincomb(1.f, x, 1.f, c->hs[slot], x, n, s));
-    delete ps;
+    ps.reset();
     // new loss / grad
     ST_TRY(eval_objective(c, x, true, c->grad, false, nullptr));
-    ps = new ProfScope(c, P_VECTOR, 0, 0);
+    ps.reset(new ProfScope(c, P_VECTOR, 0, 0));
     HIP_TRY(launch_lincomb(1.f, c->grad, -1.f, c->g_cur, c->hy[slot], n, s));       // y = grad - self.grad
     HIP_TRY(launch_dot(c->hs[slot], c->hy[slot], n, c->dot_part, sy + slot, s));
     std::swap(c->g_cur, c->grad);
-    delete ps;
+    ps.reset();
     float sy_host = 0.f;            // the only host decision of the step (optimizers.py:82)
     HIP_TRY(hipMemcpyAsync(&sy_host, sy + slot, sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1478,7 +1479,6 @@ int st_tile_losses(st_ctx* c, float** dev_ptr, int* n_floats)
         HIP_TRY(hipMemsetAsync(c->dbuf, 0, cc * sizeof(float), c->stream));
     }
     size_t pos = 0;
-    int k = 0;
     for (const ActiveLayer& al : c->active) {
         const int b = al.blob, C = a.C[b];
         const BlobRoi r = tile_roi(c, b);
@@ -1486,10 +1486,7 @@ int st_tile_losses(st_ctx* c, float** dev_ptr, int* n_floats)
         if (al.c && !c->norm_valid[b * 3 + 0]) { HIP_TRY(launch_finalize_norm(c->tile.p1 + pos + 1, 1, r.n_global, nrm + 0, c->stream)); c->norm_valid[b * 3 + 0] = 1; }
         if (al.d && !c->norm_valid[b * 3 + 2]) { HIP_TRY(launch_finalize_norm(c->tile.p1 + pos + 3, 1, r.n_global, nrm + 2, c->stream)); c->norm_valid[b * 3 + 2] = 1; }
         pos += 4;
-        if (al.s) {
-            pos += (size_t)C * C;
-            ++k;
-        }
+        if (al.s) pos += (size_t)C * C;
     }
     if (dev_ptr) *dev_ptr = missing ? c->tile.p2 : nullptr;
     if (n_floats) *n_floats = missing ? n_style : 0;
