@@ -62,6 +62,7 @@ void pack_conv_weights_dgrad(const float* w, int Cout, int Cin, float* dst)
 struct ConvKArgs {
     const float* in; const float* wpack; const float* bias; float* out;
     const float* mask_src; const float* inject;
+    unsigned short* out16;        // optional bf16 copy of the output, channel-blocked [M/8][H][W][8] (M % 8 == 0)
     int K, M, MPad, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
     unsigned in_bytes, w_bytes;   // extents of `in` and `wpack` for the buffer descriptors
     unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
@@ -352,6 +353,20 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[e];
+                if (a.out16) {
+                    // rows mbase..+3 and mbase+8..+11: two groups of 4 consecutive channels -> two 8-byte stores
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int mg = mbase + 8 * g;
+                        if (mg < a.M) {             // M is a multiple of 8 on this path (checked at launch)
+                            bf16x4 pk;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[4 * g + e];
+                            *reinterpret_cast<bf16x4*>(a.out16 + ((size_t)(mg >> 3) * plane + pix) * 8 + (mg & 7)) = pk;
+                        }
+                    }
+                }
             }
         }
     }
@@ -384,6 +399,8 @@ static hipError_t run(const ConvProblem& p, int BM, int ROWS, int CCK, conv_kern
     if (style) k = *style;
     k.in = p.in; k.wpack = p.wpack; k.bias = p.bias; k.out = p.out;
     k.mask_src = p.mask_src; k.inject = p.inject;
+    if (p.out16 && p.M % 8 != 0) return hipErrorInvalidValue;
+    k.out16 = style ? nullptr : p.out16;
     k.K = p.K; k.M = p.M; k.MPad = p.MPad; k.H = p.H; k.W = p.W;
     k.nch = (p.K + CCK - 1) / CCK;
     k.tiles_x = (p.W + 31) / 32;

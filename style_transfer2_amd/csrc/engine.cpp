@@ -302,6 +302,7 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
             } else {
                 ConvProblem p{};
+                bool packed = false;
                 p.in = a.data[i - 1]; p.wpack = L.w_fwd; p.bias = L.bias; p.out = a.data[i];
                 p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
                 { const bool wino = c->wino && L.u_fwd && conv_wino_ok(p.K, p.M, p.H, p.W);
@@ -313,8 +314,9 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
                       if (i < last && !c->topo[i].is_conv && !c->bf16 && conv_wino_can_pool(p.K, p.M, p.H, p.W)) { p.pool_out = a.data[i + 1]; pooled_by_conv = i + 1; }
                       HIP_TRY(launch_conv3x3_wino(p, c->stream));
                   }
-                  else HIP_TRY(launch_conv3x3(p, c->stream)); }
-                if (next16) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
+                  else { if (next16 && L.cout % 8 == 0) { p.out16 = a.data16[i]; packed = true; }      // the epilogue writes the bf16 copy too
+                         HIP_TRY(launch_conv3x3(p, c->stream)); } }
+                if (next16 && !packed) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
             }
         } else if (i == pooled_by_conv) {
             // written by the producing conv's epilogue

@@ -29,6 +29,7 @@ struct ConvProblem {
     int K, M, MPad, H, W;
     int relu;               // forward epilogue
     unsigned long long* stamps = nullptr;   // diagnostic configs only
+    unsigned short* out16 = nullptr;        // optional (direct kernel): bf16 channel-blocked copy of `out`, [M/8][H][W][8], M % 8 == 0
     float* pool_out = nullptr;              // optional (Winograd forward, see conv_wino_can_pool): also write maxpool2x2/2 of `out`
     float* scratch = nullptr;               // optional: room for split-K partial sums (Winograd launches with few workgroups)
     size_t scratch_floats = 0;
