@@ -1,23 +1,38 @@
 #!/usr/bin/env python3
-"""Benchmark of the style-transfer inner loop on MI355X (BASELINE.json: iterations/sec @1024px VGG19).
+"""Benchmark of the style-transfer inner loop on MI355X (BASELINE.json: iterations/sec @1024px VGG19; images/hour at
+1/2/4/8 GPUs).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--optimizer adam]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--optimizer adam] [--precision fp32]
+    python bench.py --size 2048 --optimizer lbfgs --precision bf16          # BASELINE configs[2]
+    python bench.py --gpus 8 --tiled 2x4 --size 8192                        # BASELINE configs[4] (tile-sharded image)
 
-One "step" = one ``StyleTransfer.step()`` = forward to conv5_1, 1 content + 5 style loss terms,
-ranged backward, fused TV/p-norm/Adam pass (reference worker.py:303-310).  Inputs are synthetic
-(seeded He-normal VGG19 weights, uniform-noise uint8 images: SURVEY section 8d) and resident in HBM
-before the timed region; nothing is read back inside it.  With N > 1 (launched by torch.distributed.run,
-one rank per GPU) every rank runs an independent job -- jobs are the unit the reference scales by
-(one worker per GPU, no collective) -- so `value` is the aggregate it/s and scaling is weak.
+One "step" = one ``StyleTransfer.step()`` = forward to conv5_1, 1 content + 5 style loss terms, ranged backward,
+TV / p-norm and the optimizer update (reference worker.py:303-310).  Inputs are synthetic (seeded He-normal VGG19
+weights, uniform-noise uint8 images: SURVEY section 8d) and resident in HBM before the timed region; nothing is read
+back inside it.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the conv3x3 MFMA implicit GEMM,
-forward + data-gradient launches) from HIP events on the engine's own stream; `cpu_baseline` is the
-CPU oracle (kind "port") timed on this host on a bounded sample, N = 1 only.
+N > 1: jobs are the unit the reference scales by (one worker per `gpu` key: config.ini:10, worker.py:328,
+router.py:67-84), so every rank runs an independent job on its own GPU with NO data-path collective; `value` is the
+aggregate it/s over all ranks and scaling is weak.  The ranks come either from the launcher (torch.distributed.run
+sets RANK / LOCAL_RANK / WORLD_SIZE) or, when those are absent and --gpus N > 1, from this script itself: it starts N
+fresh child processes (one per GPU) BEFORE anything touches the GPU and relays rank 0's line.
+
+Rank 0 prints ONE JSON line.  `value` comes from the median of R back-to-back timed blocks of exactly K steps (each
+bracketed by barrier + device sync, max over ranks); all blocks are listed under `timing`.  `roofline` is for the
+dominant kernel class (the conv3x3 launches on the matrix cores): `achieved` counts the FLOPs the MFMA pipe executes
+(Winograd launches perform 4/9 of the direct-convolution FLOPs), so `frac` is a true fraction of the MFMA peak; the
+algorithmic (direct-convolution) figure is kept beside it.  `cpu_baseline` (kind "port") and `parity` come
+from the CPU oracle run on this host on the same inputs, N = 1 only.  `worker_level` is the rate including one
+`Iterate` (D2H + pickle) per step, which `value` excludes.
 """
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,10 +40,6 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-
-import style_transfer2_amd as st2                      # noqa: E402
-from style_transfer2_amd import weights as st2_weights  # noqa: E402
-from style_transfer2_amd import distributed as st2_dist  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E
@@ -38,6 +49,7 @@ WEIGHTS = {'content': {'conv4_2': 0.08},
            'deepdream': {}}
 PARAMS = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
 ITERS_PER_IMAGE = 500
+STEP_SIZES = {'adam': 10, 'lbfgs': 1}
 
 
 def images(size):
@@ -48,6 +60,8 @@ def images(size):
 
 
 def make_job(size, optimizer, device, precision='fp32'):
+    import style_transfer2_amd as st2
+    from style_transfer2_amd import weights as st2_weights
     content, style, init = images(size)
     model = st2.HipModel(st2_weights.he_normal(st2.VGG19_TOPOLOGY, seed=0), device=device, precision=precision)
     job = st2.StyleTransfer(model)
@@ -56,21 +70,49 @@ def make_job(size, optimizer, device, precision='fp32'):
     job.set_style(style)
     job.set_weights(WEIGHTS, PARAMS)
     job.optimizer_cls = {'adam': st2.AdamOptimizer, 'lbfgs': st2.LBFGSOptimizer}[optimizer]
-    job.set_step_size({'adam': 10, 'lbfgs': 1}[optimizer])
+    job.set_step_size(STEP_SIZES[optimizer])
     job.reset()
     assert job.start()
     return job
 
 
+class StubJob:
+    """Stands in for a job in the CPU test of the multi-rank plumbing (tests/test_bench_fanout_cpu.py): a step is a
+    1-ms sleep, there is no engine.  Never used on a GPU box."""
+    engine = None
+
+    def step_async(self):
+        time.sleep(0.001)
+
+    def sync(self):
+        pass
+
+
+def workload_label(args):
+    what = '%dx%d single image per GPU, VGG19 to conv5_1, content conv4_2 + 5 style layers, %s %s, %d iterations per image' % (
+        args.size, args.size, args.optimizer, args.precision, ITERS_PER_IMAGE)
+    if (args.size, args.optimizer, args.precision) == (1024, 'adam', 'fp32'):
+        tag = 'configs[1]' if args.gpus == 1 else 'configs[3] (%d independent configs[1] jobs)' % args.gpus
+    elif (args.size, args.optimizer, args.precision) == (2048, 'lbfgs', 'bf16'):
+        tag = 'configs[2]'
+    else:
+        tag = 'custom (not a BASELINE.json config)'
+    return '%s: %s' % (tag, what)
+
+
 def class_roofline(name, rec, conv_peak):
     """One kernel class against its rooflines: TFLOP/s vs the MFMA peak of its operand type when the engine recorded
-    algorithmic flops for it, GB/s vs HBM when it recorded algorithmic bytes (both for classes that have both)."""
+    algorithmic flops for it (Winograd classes: the 4/9 of them that the pipe executes), GB/s vs HBM when it recorded
+    algorithmic bytes (both for classes that have both)."""
     sec = rec['ms'] * 1e-3
     out = {}
     if rec['flops'] > 0:
-        tf = rec['flops'] / sec / 1e12
+        executed = rec['flops'] * (4.0 / 9.0 if 'wino' in name else 1.0)
+        tf = executed / sec / 1e12
         out['TFLOP/s'] = round(tf, 1)
         out['frac_mfma'] = round(tf / (conv_peak if name.startswith('conv3x3') else PEAK_F32_MFMA_TFLOPS), 3)
+        if 'wino' in name:
+            out['algorithmic_TFLOP/s'] = round(rec['flops'] / sec / 1e12, 1)
     if rec['bytes'] > 0:
         gbs = rec['bytes'] / sec / 1e9
         out['GB/s'] = round(gbs, 1)
@@ -78,120 +120,291 @@ def class_roofline(name, rec, conv_peak):
     return out
 
 
-def cpu_baseline(size, optimizer):
-    """The CPU oracle ("port") on this host: setup, one untimed step (norm capture), one timed step."""
+def source_hash():
+    """sha256[:16] over the kernel / engine sources: the committed PMC summaries carry the hash they were measured on."""
+    h = hashlib.sha256()
+    csrc = os.path.join(HERE, 'style_transfer2_amd', 'csrc')
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(('.hip', '.cpp', '.h', '.cuh')):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def committed_pmc(name, args):
+    """A committed rocprofv3 --pmc summary of this same command (tools/profile_round.sh), or (None, why).  The counters
+    need rocprofv3 around the process, so they cannot be taken inside this run: the line names the file and says
+    whether it was measured on the kernel sources that are running now."""
+    path = os.path.join(HERE, 'profiles', name)
+    if (args.size, args.optimizer, args.precision) != (1024, 'adam', 'fp32'):
+        return None, 'no committed PMC pass for this configuration'
+    if not os.path.exists(path):
+        return None, 'profiles/%s absent' % name
+    try:
+        data = json.load(open(path))
+    except ValueError:
+        return None, 'profiles/%s unreadable' % name
+    meta = data.get('_meta', {})
+    if meta.get('source_sha16') != source_hash():
+        return None, 'profiles/%s was measured on other kernel sources (%s, now %s): stale, not reported' % (
+            name, meta.get('source_sha16'), source_hash())
+    return data, 'profiles/%s (rocprofv3 --pmc pass of this command, %s, same kernel sources)' % (name, meta.get('profile', '?'))
+
+
+# ------------------------------------------------------------------------------------------------ CPU oracle legs
+def cpu_baseline_and_parity(size, optimizer, precision, dev_eval):
+    """The CPU oracle ("port") on this host: setup, one objective evaluation at the initial image (untimed; it captures
+    the norms and is what `parity` compares with the HIP path's evaluation of the same state), one timed step."""
     import oracle
     from threadpoolctl import threadpool_info
     content, style, init = images(size)
     topo = oracle.VGG19_TOPOLOGY
-    job = oracle.TransferOracle(oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False))
+    net = oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False,
+                           operands='bf16' if precision == 'bf16' else 'fp32')
+    job = oracle.TransferOracle(net)
     job.set_input(init)
     job.set_content(content)
     job.set_style(style)
     job.reset()
     job.set_weights(WEIGHTS, PARAMS)
-    job.set_optimizer(optimizer, {'adam': 10, 'lbfgs': 1}[optimizer])
+    job.set_optimizer(optimizer, STEP_SIZES[optimizer])
     job.start()
-    job.step()
+    loss0, grad0 = job.opfunc(job.input)
+    parity = None
+    if dev_eval is not None:
+        ld, gd, signs = dev_eval
+        g64, d64 = grad0.astype(np.float64), gd.astype(np.float64)
+        flips = total = 0
+        for name, packed in signs.items():
+            ref = np.packbits(net._blobs[name] > 0)
+            flips += int(np.unpackbits(ref ^ packed).sum())
+            total += net._blobs[name].size
+        pix = np.abs(gd - grad0)[0].max(0)
+        parity = {'against': 'CPU oracle (%s conv operands), objective at the initial image, same inputs' % precision,
+                  'loss_rel': float(abs(float(ld) - float(loss0)) / abs(float(loss0))),
+                  'grad_rel_l2': float(np.linalg.norm(d64 - g64) / np.linalg.norm(g64)),
+                  'grad_cosine': float(np.vdot(d64, g64) / (np.linalg.norm(d64) * np.linalg.norm(g64))),
+                  'relu_sign_flips': flips, 'activations': total,
+                  'affected_pixel_frac': float(np.mean(pix > 1e-3 * np.abs(grad0).max())),
+                  'note': 'ReLU / max-pool are discontinuous: each sign flip between two correct forwards changes the '
+                          'gradient by O(1) inside one receptive field (DESIGN.md section 5)'}
+    if optimizer == 'lbfgs':
+        job.step()                  # the first L-BFGS step costs two evaluations; time a steady-state one
     t0 = time.perf_counter()
     job.step()
     dt = time.perf_counter() - t0
     threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
-    return {'value': 1.0 / dt, 'unit': 'it/s', 'cores': threads, 'host_cpus': os.cpu_count(), 'kind': 'port',
-            'sample': '1 %s iteration at %dx%d (after 1 untimed), numpy+OpenBLAS oracle, forward stops at conv5_1'
+    base = {'value': 1.0 / dt, 'unit': 'it/s', 'cores': threads, 'host_cpus': os.cpu_count(), 'kind': 'port',
+            'sample': '1 %s iteration at %dx%d (after 1 untimed objective evaluation), numpy+OpenBLAS oracle, forward stops at conv5_1'
                       % (optimizer, size, size)}
+    return base, parity
 
 
-def main():
+def device_eval_for_parity(job):
+    """Objective at the initial image on the HIP path, plus the ReLU sign pattern (bit-packed) of every conv blob."""
+    loss, grad = job.opfunc()
+    eng = job.engine
+    signs = {}
+    for layer in eng.topology[:17]:
+        if layer[0] == 'conv':
+            signs[layer[1]] = np.packbits(eng.get_blob(layer[1])[0] > 0)
+    return loss, grad, signs
+
+
+def worker_level(job, steps):
+    """Rate with one Iterate per step as worker.py sends it (image D2H over PCIe + pickle of the HxWx3 float32 image,
+    the sending side of pyzmq's send_pyobj), synchronous and with worker.AsyncSender (SURVEY 8d "report both")."""
+    import pickle
+    import messages
+    import worker as worker_mod
+
+    class PickleSink:
+        def __init__(self):
+            self.bytes = 0
+
+        def send_pyobj(self, obj):
+            self.bytes += len(pickle.dumps(obj, protocol=pickle.DEFAULT_PROTOCOL))
+
+    out = {}
+    for mode in ('sync', 'async'):
+        for _ in range(2):
+            job.step_async()
+        job.engine.sync()
+        sink = PickleSink()
+        send = worker_mod.AsyncSender(sink) if mode == 'async' else sink
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            image, trace = job.step()
+            send.send_pyobj(messages.Iterate(image, job.t, trace))
+        job.engine.sync()
+        if mode == 'async':
+            send.close()
+        dt = time.perf_counter() - t0
+        out[mode + '_iterate_it_s'] = steps / dt
+        out['iterate_MB'] = sink.bytes / steps / 1e6
+    out['steps'] = steps
+    out['note'] = 'one Iterate (D2H + pickle) per step on one host thread / with the sender thread; never `value`'
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ multi-rank plumbing
+def fan_out(args, argv):
+    """--gpus N > 1 without a launcher: start N fresh processes, one per GPU, before anything here touches the GPU.
+    Rank 0's stdout (the one JSON line) is relayed; the exit code is the worst child's."""
+    n = args.gpus
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print('bench.py: ranks failed (rank, exit code): %s' % bad, file=sys.stderr)
+        return max(abs(c) for _, c in bad) or 1
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--repeats', type=int, default=5, help='timed blocks of --steps steps (value = the median block)')
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--optimizer', default='adam', choices=['adam', 'lbfgs'])
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
-                    help="bf16 = BASELINE configs[3] 'bf16 features / fp32 Gram'; the headline metric is fp32")
+                    help="bf16 = BASELINE configs[2] 'bf16 features / fp32 Gram'; the headline metric is fp32")
+    ap.add_argument('--tiled', default='', help='RxC: ONE image of --size tile-sharded over R*C GPUs (BASELINE configs[4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-worker-level', action='store_true')
     ap.add_argument('--cpu-size', type=int, default=0, help='image size of the CPU sample (default: --size)')
-    args = ap.parse_args()
+    ap.add_argument('--engine', default='hip', choices=['hip', 'stub'], help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+    if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
+        ap.error('--gpus, --steps and --repeats must be positive')
 
-    group = st2_dist.Group()
+    # ---- ranks: from the launcher, or started here (nothing above this line has touched the GPU)
+    if 'WORLD_SIZE' not in os.environ:
+        if args.gpus > 1:
+            return fan_out(args, argv)
+    elif int(os.environ['WORLD_SIZE']) != args.gpus:
+        print('bench.py: --gpus %d but the launcher started %s ranks' % (args.gpus, os.environ['WORLD_SIZE']), file=sys.stderr)
+        return 2
+    if args.tiled:
+        import runpy
+        sys.argv = [os.path.join(HERE, 'tools', 'bench_tiled.py'), '--size', str(args.size), '--grid', args.tiled,
+                    '--steps', str(args.steps), '--warmup', str(args.warmup)]
+        runpy.run_path(sys.argv[0], run_name='__main__')
+        return 0
+
+    # native libraries (gloo, RCCL, the HIP runtime) print to fd 1 at will: keep the real stdout for the ONE JSON line
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+
+    from style_transfer2_amd import distributed as st2_dist
+    group = st2_dist.Group(backend='gloo' if args.engine == 'stub' else None)
     rank, local_rank, world = group.rank, group.local_rank, group.world
 
-    job = make_job(args.size, args.optimizer, local_rank, args.precision)
-    elapsed = st2_dist.timed_region(group, job.step_async, args.steps, args.warmup, job.engine.sync)
+    if args.engine == 'stub':
+        job, sync = StubJob(), StubJob().sync
+    else:
+        job = make_job(args.size, args.optimizer, local_rank, args.precision)
+        sync = job.engine.sync
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.engine == 'hip'
+    cpu_size = args.cpu_size or args.size
+    dev_eval = device_eval_for_parity(job) if want_cpu and cpu_size == args.size else None
 
-    # per-kernel-class HIP-event timing of the same steps (separate leg so `value` carries no event overhead)
-    prof_steps = max(3, min(10, args.steps))
-    job.engine.profile_enable(True)
-    for _ in range(prof_steps):
-        job.step_async()
-    prof = job.engine.profile_read()
-    job.engine.profile_enable(False)
+    blocks = []
+    for r in range(args.repeats):
+        blocks.append(st2_dist.timed_region(group, job.step_async, args.steps, args.warmup if r == 0 else 0, sync))
+    elapsed = statistics.median(blocks)
+
+    prof, prof_steps = {}, 0
+    if args.engine == 'hip':
+        # per-kernel-class HIP-event timing of the same steps (separate leg so `value` carries no event overhead)
+        prof_steps = max(3, min(10, args.steps))
+        job.engine.profile_enable(True)
+        for _ in range(prof_steps):
+            job.step_async()
+        prof = job.engine.profile_read()
+        job.engine.profile_enable(False)
 
     if rank == 0:
         its = world * args.steps / elapsed
-        # the dominant kernel = every conv3x3 launch on the matrix cores (direct implicit GEMM and Winograd F(2x2,3x3));
-        # `flops` are ALGORITHMIC (direct-convolution: 2*9*Cin*Cout*H*W per launch, SURVEY 8d) for both; the Winograd
-        # launches execute 4/9 of them on the MFMA pipe, which `executed` accounts for.
-        direct = [prof[k] for k in ('conv3x3_fwd_mfma_f32', 'conv3x3_dgrad_mfma_f32') if k in prof]
-        wino = [prof[k] for k in ('conv3x3_fwd_wino_f32', 'conv3x3_dgrad_wino_f32') if k in prof]
-        conv = direct + wino
-        flops = sum(c['flops'] for c in conv)
-        ms = sum(c['ms'] for c in conv)
-        launches = sum(c['launches'] for c in conv)
-        achieved = flops / (ms * 1e-3) / 1e12 if ms else 0.0
-        executed = (sum(c['flops'] for c in direct) + sum(c['flops'] for c in wino) * 4.0 / 9.0) / (ms * 1e-3) / 1e12 if ms else 0.0
-        total_ms = sum(v['ms'] for v in prof.values())
-        # HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command
-        # (FETCH_SIZE doubled for wide loads, WRITE_SIZE exact: tools/pmc_traffic.py); null when absent.
-        traffic = None
-        tpath = os.path.join(HERE, 'profiles', 'pmc_traffic.json')
-        peak = PEAK_F32_MFMA_TFLOPS if args.precision == 'fp32' else PEAK_BF16_MFMA_TFLOPS
-        if args.size == 1024 and args.precision == 'fp32' and os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath))['_conv3x3_all']['hbm_bytes_per_launch']
-            except (KeyError, ValueError):
-                traffic = None
-        # matrix-pipe busy fraction of the conv kernels from the committed rocprofv3 PMC pass of this same command
-        # (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs): tools/pmc_mfma.py); null when absent
-        mfma_busy = None
-        mpath = os.path.join(HERE, 'profiles', 'pmc_mfma.json')
-        if args.size == 1024 and args.precision == 'fp32' and os.path.exists(mpath):
-            try:
-                mfma_busy = {k: round(v['mfma_busy_frac'], 3) for k, v in json.load(open(mpath)).items() if k.startswith('conv3x3')}
-            except (KeyError, ValueError):
-                mfma_busy = None
+        f32 = args.precision == 'fp32'
         out = {
             'metric': 'style-transfer iters/sec @%dpx VGG19' % args.size,
             'value': its, 'unit': 'it/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if args.precision == 'fp32' else 'bf16 conv operands, f32 accumulate/Gram/optimizer', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32' if f32 else 'bf16 conv operands, f32 accumulate/Gram/optimizer', 'data': 'synthetic',
             'images_per_hour': its * 3600.0 / ITERS_PER_IMAGE,
-            'config': {'workload': 'configs[1]: %dx%d single image per GPU, VGG19 to conv5_1, content conv4_2 + 5 style '
-                                   'layers, %s %s, %d iterations per image' % (args.size, args.size, args.optimizer,
-                                                                                args.precision, ITERS_PER_IMAGE),
-                       'jobs': world, 'parallelism': 'independent jobs, 1 per GPU, no collective'},
-            'roofline': {'bound': 'mfma', 'kernel': 'conv3x3 on the %s matrix cores (forward + dgrad launches; %d of %d launches Winograd F(2x2,3x3))'
-                                   % ('f32' if args.precision == 'fp32' else 'bf16', sum(c['launches'] for c in wino), launches),
-                         'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic,
-                         'executed': executed, 'executed_frac': executed / peak, 'mfma_busy_pmc': mfma_busy,
-                         'note': 'achieved = algorithmic direct-conv flops / kernel time, so frac can exceed 1 where Winograd '
-                                 'runs; executed = flops the MFMA pipe actually performs (Winograd: 4/9 of algorithmic)',
-                         'flops_per_launch': flops / launches if launches else 0.0,
-                         'avg_launch_ms': ms / launches if launches else 0.0,
-                         'share_of_step': ms / total_ms if total_ms else 0.0},
-            'kernel_ms_per_step': {k: round(v['ms'] / prof_steps, 4) for k, v in sorted(prof.items())},
-            # every kernel class against its own roofline (algorithmic flops / bytes recorded by the engine per launch):
-            # matrix-core classes in TFLOP/s vs the MFMA peak of the operand type, streaming passes in GB/s vs HBM 8 TB/s
-            'kernel_rooflines': {k: class_roofline(k, v, peak) for k, v in sorted(prof.items()) if v['ms'] > 0},
+            'timing': {'blocks': args.repeats, 'steps_per_block': args.steps, 'value_from': 'median block',
+                       'ms_per_step': {'median': 1e3 * elapsed / args.steps, 'min': 1e3 * min(blocks) / args.steps,
+                                       'max': 1e3 * max(blocks) / args.steps},
+                       'block_ms': [round(1e3 * b, 3) for b in blocks]},
+            'config': {'workload': workload_label(args), 'jobs': world,
+                       'parallelism': 'independent jobs, 1 per GPU, no collective (replicas)',
+                       'scaling_curve': 'measured only by the driver (N = 1, 2, 4, 8); none has been measured by the builder'},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.cpu_size or args.size, args.optimizer)
-        print(json.dumps(out))
+        if prof:
+            # the dominant kernel class = every conv3x3 launch on the matrix cores (direct implicit GEMM + Winograd F(2x2,3x3)).
+            # The engine records ALGORITHMIC flops per launch (direct convolution: 2*9*Cin*Cout*H*W, SURVEY 8d); a Winograd
+            # launch executes 4/9 of them on the MFMA pipe.
+            peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
+            direct = [prof[k] for k in ('conv3x3_fwd_mfma_f32', 'conv3x3_dgrad_mfma_f32') if k in prof]
+            wino = [prof[k] for k in ('conv3x3_fwd_wino_f32', 'conv3x3_dgrad_wino_f32') if k in prof]
+            conv = direct + wino
+            flops = sum(c['flops'] for c in conv)
+            ms = sum(c['ms'] for c in conv)
+            launches = sum(c['launches'] for c in conv)
+            sec = ms * 1e-3
+            algorithmic = flops / sec / 1e12 if ms else 0.0
+            executed = (sum(c['flops'] for c in direct) + sum(c['flops'] for c in wino) * 4.0 / 9.0) / sec / 1e12 if ms else 0.0
+            total_ms = sum(v['ms'] for v in prof.values())
+            traffic, traffic_src = committed_pmc('pmc_traffic.json', args)
+            mfma, mfma_src = committed_pmc('pmc_mfma.json', args)
+            out['roofline'] = {
+                'bound': 'mfma',
+                'kernel': 'conv3x3 on the %s matrix cores (forward + dgrad launches; %d of %d launches Winograd F(2x2,3x3))'
+                          % ('f32' if f32 else 'bf16', sum(c['launches'] for c in wino), launches),
+                'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s', 'frac': executed / peak,
+                'achieved_is': 'FLOPs the MFMA pipe executes / kernel time (HIP events on the engine stream): direct launches '
+                               '2*9*K*M*H*W, Winograd launches 4/9 of that',
+                'algorithmic': algorithmic, 'algorithmic_over_peak': algorithmic / peak,
+                'algorithmic_is': 'direct-convolution FLOPs (SURVEY 8d) / kernel time; exceeds the peak where Winograd runs '
+                                  'because it needs 2.25x fewer multiplies -- not a fraction of any ceiling',
+                'traffic': traffic['_conv3x3_all']['hbm_bytes_per_launch'] if traffic else None, 'traffic_source': traffic_src,
+                'mfma_busy_pmc': ({k: round(v['mfma_busy_frac'], 3) for k, v in mfma.items() if k.startswith('conv3x3')} if mfma else None),
+                'mfma_busy_source': mfma_src,
+                'executed_flops_per_launch': executed * 1e12 * sec / launches if launches else 0.0,
+                'algorithmic_flops_per_launch': flops / launches if launches else 0.0,
+                'avg_launch_ms': ms / launches if launches else 0.0,
+                'share_of_step': ms / total_ms if total_ms else 0.0}
+            out['kernel_ms_per_step'] = {k: round(v['ms'] / prof_steps, 4) for k, v in sorted(prof.items())}
+            # every kernel class against its own roofline (flops / bytes recorded by the engine per launch): matrix-core
+            # classes in executed TFLOP/s vs the MFMA peak of the operand type, streaming passes in GB/s vs HBM 8 TB/s
+            out['kernel_rooflines'] = {k: class_roofline(k, v, peak) for k, v in sorted(prof.items()) if v['ms'] > 0}
+        if world == 1 and args.engine == 'hip' and not args.no_worker_level:
+            out['worker_level'] = worker_level(job, max(3, min(20, args.steps)))
+        if want_cpu:
+            out['cpu_baseline'], parity = cpu_baseline_and_parity(cpu_size, args.optimizer, args.precision, dev_eval)
+            out['parity'] = parity
+        json_out.write(json.dumps(out) + '\n')
+        json_out.flush()
     group.close()
+    return 0
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

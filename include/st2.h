@@ -149,23 +149,6 @@ int st_tile_update(st_ctx* ctx, const float* ring_dev, float** dev_ptr, int* n_f
 int st_tile_buffer(st_ctx* ctx, int which, float** dev_ptr);
 int st_tile_swap(st_ctx* ctx);
 
-/* isolated timing of the conv3x3 MFMA kernel on one layer shape (K input channels, M output
- * channels, HxW, random data).  cfg < 0: the engine's own tile choice (returned in *cfg_used).
- * dgrad_epilogue != 0 adds the ReLU-mask + injected-diff epilogue of the backward pass. */
-int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_epilogue, int iters,
-                  double* avg_ms, int* cfg_used);
-/* matrix-pipe ceiling probe: variant 0 = register operands, 1 = + LDS operand reads; blocks_per_cu
- * 256-thread workgroups per CU; returns sustained TFLOP/s of v_mfma_f32_32x32x2_f32 */
-int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops);
-/* Winograd operand-feed probe: executed MFMA TFLOP/s with the A operands streamed from L2 (depth = k-pairs in flight) */
-/* issue-rate probe: shader cycles per v_mfma_f32_32x32x2_f32 at one wave per SIMD with naux VALU + nlds ds_read between MFMAs */
-int st_bench_issue_probe(int device_id, int naux, int nlds, double* cycles_per_mfma);
-/* feed probe of the LDS-staged-U Winograd design: shader cycles per k-pair (16 MFMAs = 1024 cycles ideal) */
-int st_bench_lds_feed_probe(int device_id, int extra_dma, int K, int blocks, double* cycles_per_kpair);
-int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int depth, double* tflops);
-int st_conv_num_configs(void);
-const char* st_conv_config_name(int cfg);
-
 #ifdef __cplusplus
 }
 #endif

@@ -5,7 +5,7 @@ hot path of crowsonkb/style_transfer2 (``worker.py:32-315``, ``optimizers.py:7-1
 ``utils.py:29-69,232-304``, ``models/vgg19.prototxt``).  It exists so that the HIP
 path can be checked against something that runs anywhere.
 
-Rules (enforced by tests/test_layout.py):
+Rules (enforced by tests/test_boundary.py::test_product_code_never_imports_the_oracle):
   * only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
     ``bench.py`` may import it -- and only as the checker, never as the product;
   * nothing under ``style_transfer2_amd/``, ``worker.py`` or ``messages.py`` imports it;

@@ -80,13 +80,6 @@ PROTOTYPES = {
     'st_tile_update': (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_int)]),
     'st_tile_buffer': (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
     'st_tile_swap': (c_int, [c_void_p]),
-    'st_bench_conv': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_double), POINTER(c_int)]),
-    'st_bench_mfma': (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
-    'st_bench_issue_probe': (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
-    'st_bench_lds_feed_probe': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_double)]),
-    'st_bench_wino_probe': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_double)]),
-    'st_conv_num_configs': (c_int, []),
-    'st_conv_config_name': (c_char_p, [c_int]),
 }
 
 _lib = None

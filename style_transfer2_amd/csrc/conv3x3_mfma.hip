@@ -627,83 +627,4 @@ hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* d
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------------------
-// Ceiling probes (measurement only): what the matrix pipe sustains on this chip for the same
-// instruction with (variant 0) register operands only, (variant 1) + the conv kernel's LDS operand
-// reads, (variant 2) variant 1 at 1 wave per SIMD.
-// ------------------------------------------------------------------------------------------
-// variant: 0 registers only (smooth data) | 1 LDS reads, smooth data | 2 LDS reads, random data |
-//          3 = 2 with the conv kernel's pinned issue order | 4 = random register operands, no LDS
-template <int VARIANT>
-__global__ __launch_bounds__(256) void mfma_probe_k(float* out, int iters, float seed)
-{
-    __shared__ float lds[8192];
-    for (int i = threadIdx.x; i < 8192; i += 256) {
-        unsigned h = (i + 1) * 2654435761u + blockIdx.x * 40503u;
-        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        lds[i] = (VARIANT >= 2) ? ((h & 0xffffff) / 8388608.0f - 1.0f) : seed + i * 1e-4f;
-    }
-    __syncthreads();
-    f32x16 acc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-    float a0 = seed + threadIdx.x * 1e-3f, a1 = a0 * 0.5f, b0 = 1.f - a0, b1 = b0 * 0.25f;
-    if (VARIANT == 4) { a0 = lds[threadIdx.x]; a1 = lds[threadIdx.x + 256]; b0 = lds[threadIdx.x + 512]; b1 = lds[threadIdx.x + 768]; }
-    const float* base = lds + (threadIdx.x & 63);
-    for (int it = 0; it < iters; ++it) {
-        if (VARIANT == 3) {
-            float av[2][2], bv[2][2];
-            av[0][0] = base[0]; av[0][1] = base[32]; bv[0][0] = base[4096]; bv[0][1] = base[4096 + 34];
-#pragma unroll
-            for (int s2 = 0; s2 < 18; ++s2) {
-#pragma unroll
-                for (int ij = 0; ij < 4; ++ij) {
-                    acc[ij] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s2 & 1][ij >> 1], bv[s2 & 1][ij & 1], acc[ij], 0, 0, 0);
-                    if (ij == 0) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (s2 + 1 < 18) {
-                            av[(s2 + 1) & 1][0] = base[(s2 + 1) * 128]; av[(s2 + 1) & 1][1] = base[(s2 + 1) * 128 + 32];
-                            bv[(s2 + 1) & 1][0] = base[4096 + (s2 + 1) * 70]; bv[(s2 + 1) & 1][1] = base[4096 + (s2 + 1) * 70 + 34];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else {
-#pragma unroll
-            for (int s2 = 0; s2 < 18; ++s2) {
-                if (VARIANT >= 1 && VARIANT <= 2) {
-                    a0 = base[s2 * 128]; a1 = base[s2 * 128 + 32];
-                    b0 = base[4096 + s2 * 70]; b1 = base[4096 + s2 * 70 + 34];
-                }
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
-            }
-        }
-    }
-    float r = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) r += acc[i][e];
-    out[(size_t)blockIdx.x * 256 + threadIdx.x] = r;
-}
-
-hipError_t launch_mfma_probe(int variant, float* out, int blocks, int iters, hipStream_t s)
-{
-    switch (variant) {
-    case 0: mfma_probe_k<0><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
-    case 1: mfma_probe_k<1><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
-    case 2: mfma_probe_k<2><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
-    case 3: mfma_probe_k<3><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
-    default: mfma_probe_k<4><<<blocks, 256, 0, s>>>(out, iters, 0.37f); break;
-    }
-    return hipGetLastError();
-}
-
 }  // namespace st2

@@ -1,8 +1,7 @@
 // Winograd F(2x2,3x3) conv3x3 on the fp32 matrix cores (gfx950): forward and data-gradient of the VGG convs
-// (reference: pycaffe Convolution forward / backward behind worker.py:84-86 and :100-106), plus the probes that sized
-// the design.  File layout: (1) probes -- operand-feed probe (can the transformed weights stream L2 -> MFMA operand
-// registers fast enough?), issue-rate probe (what does a wave's own auxiliary instruction cost between MFMAs at one wave
-// per SIMD?), LDS-staged-feed probe; (2) the kernel (conv3x3_wino_body) and its host side (packing, launch, split-K).
+// (reference: pycaffe Convolution forward / backward behind worker.py:84-86 and :100-106): the kernel
+// (conv3x3_wino_body) and its host side (packing, launch, split-K).  The probes that sized the design (operand feed,
+// issue rate, LDS-staged feed) live in tools/probes/, outside the product library.
 //
 // The 16 transform-domain GEMMs of one block keep 16 x (32 m x 32 tiles) fp32 accumulators per wave (256 VGPRs),
 // so the block tile is small (128 m x 32 tiles) and the transformed weights U have to stream at ~16 B/clk/CU.
@@ -17,221 +16,6 @@ namespace st2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// U layout: [m32][kpair][posgroup 4][lane 64][4 floats]; one wave-load (dwordx4) = 1 KB contiguous
-template <int DEPTH, int ROT>
-__global__ __launch_bounds__(256, 1) void wino_probe_k(const float4* __restrict__ U, float* out, int nkp, int n_mt)
-{
-    __shared__ float vs[2][16 * 64];
-    for (int i = threadIdx.x; i < 2 * 16 * 64; i += 256) {
-        unsigned h = (i + 1) * 2654435761u + blockIdx.x * 40503u;
-        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-        (&vs[0][0])[i] = (h & 0xffffff) / 8388608.0f - 1.0f;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int xcd = blockIdx.x & 7;
-    const int mt = (xcd * 2 + ((blockIdx.x >> 3) & 1)) % n_mt;          // the blocks of one XCD share two 128-m slices
-    const float4* up = U + (size_t)(mt * 4 + wave) * nkp * 256 + lane;
-    const int rot = ROT ? (int)((blockIdx.x >> 4) & 7) * (nkp / 8) : 0;      // staggered start of the k walk
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-    // register prefetch ring: slot d holds k-pair (kp + d); the loads of k-pair kp + DEPTH are issued before the
-    // MFMAs of k-pair kp.  The empty asm keeps InstCombine from folding the loop-carried loads into "load at use".
-    float4 ua[DEPTH][4];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) ua[d][g] = up[(size_t)(((d + rot) % nkp) * 4 + g) * 64];
-    asm volatile("" ::: "memory");
-    for (int kp = 0; kp < nkp; kp += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            float4 cur[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) cur[g] = ua[d][g];
-            const int nxt = ((kp + d + DEPTH < nkp ? kp + d + DEPTH : kp + d) + rot) % nkp;     // tail: reload (harmless)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) ua[d][g] = up[((size_t)nxt * 4 + g) * 64];
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            const float* vb = &vs[(kp + d) & 1][lane];
-            float b[16];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) b[p] = vb[p * 64];
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const float a = (p & 3) == 0 ? cur[p >> 2].x : (p & 3) == 1 ? cur[p >> 2].y : (p & 3) == 2 ? cur[p >> 2].z : cur[p >> 2].w;
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[p], acc[p], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    float r = 0.f;
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) r += acc[p][e];
-    out[(size_t)blockIdx.x * 256 + threadIdx.x] = r;
-}
-
-// Issue-rate probe: one wave per SIMD (256 accumulators), 16 independent MFMAs per iteration with register operands,
-// NAUX independent VALU / NLDS ds_read instructions pinned after each; reports shader cycles per MFMA.
-template <int NAUX, int NLDS>
-__global__ __launch_bounds__(256, 1) void wino_issue_probe_k(float* out, unsigned long long* cycles, int iters, float seed)
-{
-    __shared__ float lds[4096];
-    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = seed + i;
-    __syncthreads();
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-    float a0 = seed + threadIdx.x * 1e-3f, b0 = 1.f - a0;
-    float x[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = seed * (j + 1);
-    float ld[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* lp = lds + (threadIdx.x & 63);
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < iters; ++it) {
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[p], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < NAUX; ++j) x[j & 7] = x[j & 7] * 1.0001f + seed;
-#pragma unroll
-            for (int j = 0; j < NLDS; ++j) ld[j & 3] += lp[(p * 4 + j) * 64];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    float r = 0.f;
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) r += acc[p][e];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) r += x[j];
-    r += ld[0] + ld[1] + ld[2] + ld[3];
-    out[(size_t)blockIdx.x * 256 + threadIdx.x] = r;
-    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
-}
-
-// Feed probe for the LDS-staged U design: 64 channels x 64 tiles per workgroup; per k-pair every wave issues 2 LDS-DMA
-// pieces (its share of the 8-KiB U slab) + EXTRA_DMA more (standing in for the raw activation tile), one barrier,
-// 8 ds_read_b128 (A and B operands of the next k-pair), 16 MFMAs.  Reports shader cycles per k-pair.
-typedef __attribute__((address_space(3))) void* lptr_probe_t;
-template <int EXTRA_DMA>
-__global__ __launch_bounds__(256, 1) void wino_lds_probe_k(const float* __restrict__ U, unsigned u_bytes, float* out,
-                                                           unsigned long long* cycles, int nkp)
-{
-    __shared__ __attribute__((aligned(16))) float u_s[4][2048];
-    __shared__ __attribute__((aligned(16))) float v_s[2][1024];
-    __shared__ __attribute__((aligned(16))) float junk[4][256];
-    for (int i = threadIdx.x; i < 2048; i += 256) (&v_s[0][0])[i] = 0.001f * i;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wave_m = wave >> 1;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, u_bytes, 0x00020000);
-    const unsigned mt = (blockIdx.x & 7);                      // one 64-channel slab per XCD
-    const unsigned lane_off = (unsigned)lane * 16u;
-    auto dma_u = [&](int kp) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int piece = wave + 4 * t;                    // 8 pieces of 1 KiB: slice = piece / 4, quarter = piece % 4
-            const unsigned src = ((mt * 2 + piece / 4) * (unsigned)nkp + (unsigned)kp) * 4096u + (piece % 4) * 1024u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_probe_t)(u_s[kp & 3] + piece * 256), 16, lane_off, src, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < EXTRA_DMA; ++t)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_probe_t)(junk[wave]), 16, lane_off, (unsigned)(kp * 4 + t) * 1024u, 0, 0);
-    };
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
-    f32x4 aq[2][4], bq[2][4];
-    dma_u(0); dma_u(1);
-    __syncthreads();
-#pragma unroll
-    for (int pg = 0; pg < 4; ++pg) {
-        aq[0][pg] = *reinterpret_cast<const f32x4*>(&u_s[0][wave_m * 1024 + (pg * 64 + lane) * 4]);
-        bq[0][pg] = *reinterpret_cast<const f32x4*>(&v_s[0][(pg * 64 + lane) * 4]);
-    }
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    for (int kp0 = 0; kp0 < nkp; kp0 += 4) {
-#pragma unroll
-        for (int kpl = 0; kpl < 4; ++kpl) {
-            const int kp = kp0 + kpl, set = kpl & 1;
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[set][p >> 2][p & 3], bq[set][p >> 2][p & 3], acc[p], 0, 0, 0);
-                if (p == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-                    for (int pg = 0; pg < 4; ++pg) {
-                        aq[set ^ 1][pg] = *reinterpret_cast<const f32x4*>(&u_s[(kpl + 1) & 3][wave_m * 1024 + (pg * 64 + lane) * 4]);
-                        bq[set ^ 1][pg] = *reinterpret_cast<const f32x4*>(&v_s[set ^ 1][(pg * 64 + lane) * 4]);
-                    }
-                    dma_u(kp + 2 < nkp ? kp + 2 : kp);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-    float r = 0.f;
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) r += acc[p][e];
-    out[(size_t)blockIdx.x * 256 + threadIdx.x] = r + junk[0][threadIdx.x & 255];
-    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
-}
-
-hipError_t launch_wino_lds_probe(int extra_dma, const float* U, unsigned u_bytes, float* out, unsigned long long* cycles,
-                                 int blocks, int nkp, hipStream_t s)
-{
-    if (nkp < 4 || nkp % 4) return hipErrorInvalidValue;
-    switch (extra_dma) {
-    case 0: wino_lds_probe_k<0><<<blocks, 256, 0, s>>>(U, u_bytes, out, cycles, nkp); break;
-    case 1: wino_lds_probe_k<1><<<blocks, 256, 0, s>>>(U, u_bytes, out, cycles, nkp); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_wino_issue_probe(int naux, int nlds, float* out, unsigned long long* cycles, int blocks, int iters, hipStream_t s)
-{
-#define ST2_IP(A, L) if (naux == A && nlds == L) { wino_issue_probe_k<A, L><<<blocks, 256, 0, s>>>(out, cycles, iters, 0.37f); return hipGetLastError(); }
-    ST2_IP(0, 0) ST2_IP(2, 0) ST2_IP(4, 0) ST2_IP(8, 0) ST2_IP(12, 0) ST2_IP(0, 2) ST2_IP(0, 4) ST2_IP(4, 2) ST2_IP(4, 4)
-#undef ST2_IP
-    return hipErrorInvalidValue;
-}
-
-hipError_t launch_wino_probe(const float* U, float* out, int blocks, int nkp, int n_mt, int depth, hipStream_t s)
-{
-    if (nkp <= 0 || nkp % 4 != 0) return hipErrorInvalidValue;
-    const float4* u4 = reinterpret_cast<const float4*>(U);
-    switch (depth) {
-    case 1: wino_probe_k<1, 0><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;
-    case 2: wino_probe_k<2, 0><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;
-    case 4: wino_probe_k<4, 0><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;
-    case 12: wino_probe_k<2, 1><<<blocks, 256, 0, s>>>(u4, out, nkp, n_mt); break;     // depth 2, staggered k walk
-    default: return hipErrorInvalidValue;      // nkp must be a multiple of depth (the ring is unrolled by it)
-    }
-    return hipGetLastError();
-}
-
 
 // ===========================================================================================================
 // Winograd F(2x2,3x3) conv3x3 (pad 1, stride 1), NCHW fp32, on v_mfma_f32_32x32x2_f32.

@@ -97,6 +97,7 @@ struct st_ctx {
     int H = 0, W = 0;                              // input geometry (0 = no input)
     float* x[2] = {nullptr, nullptr};
     int cur = 0;
+    float* fwd_x = nullptr; size_t fwd_x_cap = 0;   // image of the st_forward test hook (never the job's iterate)
     float* grad = nullptr;                         // combined gradient (opfunc / L-BFGS)
     // content / style
     int cH = 0, cW = 0;
@@ -477,6 +478,19 @@ static int preprocess_into(st_ctx* c, const void* hwc, int H, int W, int is_u8, 
     return ST_OK;
 }
 
+// an input of a new geometry: every size-dependent optimizer tensor starts from zero
+static int set_input_common(st_ctx* c, int H, int W)
+{
+    const bool reshaped = !(c->H == H && c->W == W && c->x[0]);
+    ST_TRY(ensure_input_buffers(c, H, W));
+    if (reshaped) {            // every size-dependent optimizer tensor starts from zero
+        c->m_zero = c->v_zero = true;
+        c->order.clear();
+        c->have_cur = false;
+    }
+    return ST_OK;
+}
+
 // ------------------------------------------------------------------------------------ the objective
 static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad_out, bool adam, float* x_next)
 {
@@ -810,6 +824,7 @@ int st_destroy(st_ctx* c)
     dfree16(c->diff16A); dfree16(c->diff16B);
     act_free(c->act);
     for (int i = 0; i < 2; ++i) dfree(c->x[i]);
+    dfree(c->fwd_x);
     dfree(c->grad); dfree(c->m); dfree(c->v); dfree(c->g_cur); dfree(c->pvec);
     for (int i = 0; i <= st_ctx::kCorr; ++i) { dfree(c->hs[i]); dfree(c->hy[i]); }
     for (auto& p : c->content_feat) dfree(p);
@@ -909,11 +924,16 @@ int st_forward(st_ctx* c, const float* x_nchw, int H, int W, int last_blob)
     if (c) c->epoch++;       // anything but st_step may change what a step launches: captured step graphs are stale
     if (!c || !x_nchw || H <= 0 || W <= 0) return fail(ST_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
-    ST_TRY(ensure_input_buffers(c, H, W));
+    // The probe image lives in a buffer of its own: the job's iterate (x) is never touched.  A forward at ANOTHER
+    // geometry re-creates the size-dependent buffers exactly like st_set_input at a new size does (optimizer state
+    // starts from zero again); st_backward works on this geometry.
+    ST_TRY(set_input_common(c, H, W));
     ST_TRY(act_ensure(c, c->act, H, W));
-    HIP_TRY(hipMemcpyAsync(c->x[c->cur], x_nchw, (size_t)3 * H * W * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    const size_t n3 = (size_t)3 * H * W;
+    if (n3 > c->fwd_x_cap) { dfree(c->fwd_x); c->fwd_x_cap = 0; ST_TRY(dmalloc(&c->fwd_x, n3)); c->fwd_x_cap = n3; }
+    HIP_TRY(hipMemcpyAsync(c->fwd_x, x_nchw, n3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
     if (last_blob < 0 || last_blob >= c->nb) last_blob = c->nb - 1;
-    ST_TRY(forward_range(c, c->act, c->x[c->cur], last_blob));
+    ST_TRY(forward_range(c, c->act, c->fwd_x, last_blob));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ST_OK;
 }
@@ -974,18 +994,6 @@ int st_gram(st_ctx* c, int index, float* out)
 }
 
 // ---- image slots
-static int set_input_common(st_ctx* c, int H, int W)
-{
-    const bool reshaped = !(c->H == H && c->W == W && c->x[0]);
-    ST_TRY(ensure_input_buffers(c, H, W));
-    if (reshaped) {            // every size-dependent optimizer tensor starts from zero
-        c->m_zero = c->v_zero = true;
-        c->order.clear();
-        c->have_cur = false;
-    }
-    return ST_OK;
-}
-
 int st_set_input(st_ctx* c, const void* hwc, int H, int W, int is_u8)
 {
     if (c) c->epoch++;       // anything but st_step may change what a step launches: captured step graphs are stale
@@ -1713,196 +1721,6 @@ int st_profile_read(st_ctx* c, long long* launches, double* ms, double* flops, d
     c->prof.clear();
     c->ev_used = 0;
     return ST_OK;
-}
-
-int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops)
-{
-    if (!tflops || blocks_per_cu <= 0) return fail(ST_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(device_id));
-    const int blocks = 256 * blocks_per_cu, iters = 2000;
-    float* out = nullptr;
-    ST_TRY(dmalloc(&out, (size_t)blocks * 256));
-    hipStream_t s;
-    HIP_TRY(hipStreamCreate(&s));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    (void)launch_mfma_probe(variant, out, blocks, iters, s);
-    (void)hipEventRecord(e0, s);
-    const int reps = 5;
-    for (int i = 0; i < reps; ++i) (void)launch_mfma_probe(variant, out, blocks, iters, s);
-    (void)hipEventRecord(e1, s);
-    HIP_TRY(hipStreamSynchronize(s));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    const double flops = (double)reps * blocks * 4 /*waves*/ * iters * 72.0 * 4096.0;
-    *tflops = flops / (ms * 1e-3) / 1e12;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
-    dfree(out);
-    return ST_OK;
-}
-
-int st_bench_lds_feed_probe(int device_id, int extra_dma, int K, int blocks, double* cycles_per_kpair)
-{
-    if (!cycles_per_kpair || K < 8 || K % 8 || blocks <= 0) return fail(ST_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(device_id));
-    const int nkp = K / 2;
-    const size_t n_u = (size_t)16 * nkp * 1024;             // 8 slabs of 2 x 32 channels
-    float *out = nullptr, *U = nullptr;
-    unsigned long long* cyc = nullptr;
-    ST_TRY(dmalloc(&out, (size_t)blocks * 256)); ST_TRY(dmalloc(&U, n_u));
-    HIP_TRY(hipMemset(U, 0x3c, n_u * 4));
-    HIP_TRY(hipMalloc((void**)&cyc, blocks * sizeof(unsigned long long)));
-    hipStream_t s;
-    HIP_TRY(hipStreamCreate(&s));
-    int rc = ST_OK;
-    for (int i = 0; i < 20 && rc == ST_OK; ++i)
-        if (launch_wino_lds_probe(extra_dma, U, (unsigned)(n_u * 4), out, cyc, blocks, nkp, s) != hipSuccess) rc = fail(ST_ERR_ARG, "no such probe variant");
-    if (rc == ST_OK) {
-        HIP_TRY(hipStreamSynchronize(s));
-        std::vector<unsigned long long> h(blocks);
-        HIP_TRY(hipMemcpy(h.data(), cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        std::sort(h.begin(), h.end());
-        *cycles_per_kpair = (double)h[blocks / 2] / nkp;
-    }
-    (void)hipStreamDestroy(s);
-    dfree(out); dfree(U); (void)hipFree(cyc);
-    return rc;
-}
-
-int st_bench_issue_probe(int device_id, int naux, int nlds, double* cycles_per_mfma)
-{
-    if (!cycles_per_mfma) return fail(ST_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(device_id));
-    const int blocks = 256, iters = 20000;
-    float* out = nullptr;
-    unsigned long long* cyc = nullptr;
-    ST_TRY(dmalloc(&out, (size_t)blocks * 256));
-    HIP_TRY(hipMalloc((void**)&cyc, blocks * sizeof(unsigned long long)));
-    hipStream_t s;
-    HIP_TRY(hipStreamCreate(&s));
-    int rc = ST_OK;
-    for (int i = 0; i < 2 && rc == ST_OK; ++i)
-        if (launch_wino_issue_probe(naux, nlds, out, cyc, blocks, iters, s) != hipSuccess) rc = fail(ST_ERR_ARG, "no such probe variant");
-    if (rc == ST_OK) {
-        HIP_TRY(hipStreamSynchronize(s));
-        std::vector<unsigned long long> h(blocks);
-        HIP_TRY(hipMemcpy(h.data(), cyc, blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        std::sort(h.begin(), h.end());
-        *cycles_per_mfma = (double)h[blocks / 2] / ((double)iters * 16.0);
-    }
-    (void)hipStreamDestroy(s);
-    dfree(out); (void)hipFree(cyc);
-    return rc;
-}
-
-int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int depth, double* tflops)
-{
-    if (!tflops || blocks_per_cu == 0 || K < 8 || K % 8 || M < 128 || M % 128 || (depth != 1 && depth != 2 && depth != 4 && depth != 12))
-        return fail(ST_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(device_id));
-    const int blocks = blocks_per_cu > 0 ? 256 * blocks_per_cu : -blocks_per_cu, nkp = K / 2, n_mt = M / 128;   // < 0: absolute block count
-    const size_t n_u = (size_t)(M / 32) * nkp * 256 * 4;
-    float *out = nullptr, *U = nullptr;
-    ST_TRY(dmalloc(&out, (size_t)blocks * 256)); ST_TRY(dmalloc(&U, n_u));
-    HIP_TRY(hipMemset(U, 0x3c, n_u * 4));
-    hipStream_t s;
-    HIP_TRY(hipStreamCreate(&s));
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) (void)launch_wino_probe(U, out, blocks, nkp, n_mt, depth, s);
-    (void)hipEventRecord(e0, s);
-    const int reps = 10;
-    for (int i = 0; i < reps; ++i) (void)launch_wino_probe(U, out, blocks, nkp, n_mt, depth, s);
-    (void)hipEventRecord(e1, s);
-    HIP_TRY(hipStreamSynchronize(s));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    *tflops = (double)reps * blocks * 4 * nkp * 16.0 * 4096.0 / (ms * 1e-3) / 1e12;
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
-    dfree(out); dfree(U);
-    return ST_OK;
-}
-
-int st_conv_num_configs(void) { return conv_num_configs(); }
-const char* st_conv_config_name(int cfg) { return conv_config_name(cfg); }
-
-int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_epilogue, int iters,
-                  double* avg_ms, int* cfg_used)
-{
-    if (K <= 0 || M <= 0 || H <= 0 || W <= 0 || iters <= 0 || !avg_ms) return fail(ST_ERR_ARG, "bad argument");
-    HIP_TRY(hipSetDevice(device_id));
-    const size_t n_in = (size_t)K * H * W, n_out = (size_t)M * H * W;
-    std::vector<float> w((size_t)M * K * 9), pk(conv_pack_floats(K, M)), hin(n_in), hb(conv_mpad(M), 0.1f);
-    uint32_t st = 12345u;
-    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
-    for (auto& x : w) x = rnd() * 0.05f;
-    for (auto& x : hin) x = rnd();
-    const bool wino = cfg >= 100;      // 100: choose, 101: 128 ch x 4x32 px, 102: 64 ch x 8x32 px
-    if (wino) {
-        if (!conv_wino_ok(K, M, H, W)) return fail(ST_ERR_ARG, "shape not eligible for the Winograd kernel");
-        pk.assign(wino_pack_floats(K, M), 0.f);
-        pack_wino_weights_fwd(w.data(), M, K, pk.data());
-    } else
-    pack_conv_weights_fwd(w.data(), M, K, pk.data());
-    float *din = nullptr, *dw = nullptr, *db = nullptr, *dout = nullptr, *dmask = nullptr, *dinj = nullptr;
-    ST_TRY(dmalloc(&din, n_in)); ST_TRY(dmalloc(&dw, pk.size())); ST_TRY(dmalloc(&db, hb.size())); ST_TRY(dmalloc(&dout, n_out));
-    HIP_TRY(hipMemcpy(din, hin.data(), n_in * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
-    if (dgrad_epilogue) {
-        ST_TRY(dmalloc(&dmask, n_out)); ST_TRY(dmalloc(&dinj, n_out));
-        for (size_t off = 0; off < n_out; off += n_in) {      // reuse the random input as mask / inject data
-            const size_t n = std::min(n_in, n_out - off);
-            HIP_TRY(hipMemcpy(dmask + off, din, n * 4, hipMemcpyDeviceToDevice));
-            HIP_TRY(hipMemcpy(dinj + off, din, n * 4, hipMemcpyDeviceToDevice));
-        }
-    }
-    ConvProblem p{};
-    p.in = din; p.wpack = dw; p.bias = dgrad_epilogue ? nullptr : db; p.out = dout; p.mask_src = dmask; p.inject = dinj;
-    p.K = K; p.M = M; p.MPad = conv_mpad(M); p.H = H; p.W = W; p.relu = dgrad_epilogue ? 0 : 1;
-    if (cfg < 0) cfg = conv_pick_config(p);
-    if (cfg_used) *cfg_used = cfg;
-    float* dscr = nullptr;
-    if (cfg == 100 && conv_wino_splits(K, M, H, W) > 1) {      // the automatic Winograd path may split K
-        p.scratch_floats = (size_t)conv_wino_splits(K, M, H, W) * n_out;
-        ST_TRY(dmalloc(&dscr, p.scratch_floats));
-        p.scratch = dscr;
-    }
-    unsigned long long* dstamps = nullptr;
-    const size_t max_blocks = (size_t)((W + 31) / 32) * ((H + 3) / 4) * (p.MPad / 64);
-    if (cfg == 6 || cfg == 103 || cfg == 106) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
-    hipStream_t s;
-    HIP_TRY(hipStreamCreate(&s));
-    auto launch = [&]() { return wino ? launch_conv3x3_wino_cfg(p, cfg - 101, s) : launch_conv3x3_cfg(p, cfg, s); };
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    int rc = ST_OK;
-    for (int i = 0; i < 2 && rc == ST_OK; ++i) if (launch() != hipSuccess) rc = fail(ST_ERR_HIP, "conv launch failed (cfg %d)", cfg);
-    if (rc == ST_OK) {
-        (void)hipEventRecord(e0, s);
-        for (int i = 0; i < iters; ++i) (void)launch();
-        (void)hipEventRecord(e1, s);
-        if (hipStreamSynchronize(s) != hipSuccess) rc = fail(ST_ERR_HIP, "conv bench sync failed");
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        *avg_ms = ms / iters;
-        if (dstamps) {     // in-kernel clock and cycles of the main loop, median block
-            std::vector<unsigned long long> h(max_blocks * 2);
-            (void)hipMemcpy(h.data(), dstamps, max_blocks * 16, hipMemcpyDeviceToHost);
-            std::vector<double> cyc, clk;
-            for (size_t b = 0; b < max_blocks; ++b) if (h[2 * b + 1]) { cyc.push_back((double)h[2 * b]); clk.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1); }
-            if (!cyc.empty()) {
-                std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
-                fprintf(stderr, "[stamps] blocks=%zu loop cycles median=%.0f (min %.0f max %.0f) in-kernel clock median=%.3f GHz; chunks=%d -> %.0f cycles/chunk\n",
-                        cyc.size(), cyc[cyc.size() / 2], cyc.front(), cyc.back(), clk[clk.size() / 2], wino ? K / 8 : (K + 3) / 4, cyc[cyc.size() / 2] / (wino ? K / 8 : (K + 3) / 4));
-            }
-        }
-    }
-    if (dstamps) (void)hipFree(dstamps);
-    dfree(dscr);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
-    dfree(din); dfree(dw); dfree(db); dfree(dout); dfree(dmask); dfree(dinj);
-    return rc;
 }
 
 }  // extern "C"

@@ -45,7 +45,6 @@ int conv_num_configs();
 const char* conv_config_name(int cfg);
 int conv_pick_config(const ConvProblem& p);
 hipError_t launch_conv3x3_cfg(const ConvProblem& p, int cfg, hipStream_t s);
-hipError_t launch_mfma_probe(int variant, float* out, int blocks, int iters, hipStream_t s);
 // Winograd F(2x2,3x3) variant of launch_conv3x3 (same ConvProblem, p.wpack = the Winograd pack, MPad unused)
 size_t wino_pack_floats(int K, int M);
 void pack_wino_weights_fwd(const float* w, int Cout, int Cin, float* dst);
@@ -55,10 +54,6 @@ bool conv_wino_can_pool(int K, int M, int H, int W);   // launch_conv3x3_wino ma
 int conv_wino_splits(int K, int M, int H, int W);   // split-K factor the automatic path would use (1 = none); needs splits*M*H*W floats of scratch
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);
 hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s);   // 0: 128 ch x 4x32 px, 1: 64 ch x 8x32 px
-hipError_t launch_wino_lds_probe(int extra_dma, const float* U, unsigned u_bytes, float* out, unsigned long long* cycles,
-                                 int blocks, int nkp, hipStream_t s);
-hipError_t launch_wino_issue_probe(int naux, int nlds, float* out, unsigned long long* cycles, int blocks, int iters, hipStream_t s);
-hipError_t launch_wino_probe(const float* U, float* out, int blocks, int nkp, int n_mt, int depth, hipStream_t s);
 // conv1_1-style dgrad (tiny M): direct VALU kernel, w is the ORIGINAL (Cout,Cin,3,3) layout
 bool conv_dgrad_smallM_ok(int Cout, int Cin);
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,

@@ -115,7 +115,8 @@ class Engine:
         check(self.lib.st_forward(self._ctx, _ptr(x), x.shape[2], x.shape[3], last_i))
 
     def get_blob(self, name):
-        h, w = self._fwd_hw
+        """Host copy of a blob of the last forward (st_forward, or the forward inside the last opfunc / step)."""
+        h, w = getattr(self, '_fwd_hw', None) or self.input_shape()
         out = np.empty((1,) + self.blob_shape(name, h, w), F32)
         check(self.lib.st_get_blob(self._ctx, self._index[name], _ptr(out)))
         return out
@@ -193,6 +194,7 @@ class Engine:
         trace = np.zeros(self.trace_len(), np.float64)
         grad = np.empty((1, 3, h, w), F32) if return_grad else None
         check(self.lib.st_opfunc(self._ctx, byref(loss), _ptr(grad), _ptr(trace)))
+        self._fwd_hw = (h, w)           # the blobs up to the deepest weighted layer are those of this evaluation
         return F32(loss.value), grad, trace
 
     # -- optimizer -----------------------------------------------------------------------------------

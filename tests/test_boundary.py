@@ -221,7 +221,48 @@ def test_product_code_never_imports_the_oracle():
     assert not offenders, offenders
     bench = open(os.path.join(REPO, 'bench.py')).read()
     assert bench.count('import oracle') == 1
-    assert bench.split('import oracle')[0].rsplit('\ndef ', 1)[1].startswith('cpu_baseline(')   # only inside that leg
+    assert bench.split('import oracle')[0].rsplit('\ndef ', 1)[1].startswith('cpu_baseline_and_parity(')   # only inside that leg
+    assert 'oracle' not in open(os.path.join(REPO, 'tools', 'probes', 'probes.hip')).read()
+
+
+def _code_object_kernels(lib):
+    """{kernel name: metadata dict} of every gfx950 code object bundled in a shared library (llvm-objdump --offloading
+    + llvm-readelf --notes on a scratch copy)."""
+    import shutil
+    import tempfile
+    llvm = '/opt/rocm/lib/llvm/bin'
+    kernels = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = shutil.copy(lib, tmp)
+        subprocess.run([os.path.join(llvm, 'llvm-objdump'), '--offloading', copy], check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if 'amdgcn' not in f:
+                continue
+            notes = subprocess.run([os.path.join(llvm, 'llvm-readelf'), '--notes', os.path.join(tmp, f)], check=True,
+                                   capture_output=True, text=True).stdout
+            cur = None
+            for line in notes.splitlines():
+                m = re.match(r'\s*-?\s*\.(\w+):\s+(\S+)', line)
+                if not m:
+                    continue
+                key, val = m.groups()
+                if key == 'name' and val.startswith('_Z'):
+                    cur = kernels.setdefault(val, {})
+                elif cur is not None and key in ('private_segment_fixed_size', 'vgpr_spill_count', 'vgpr_count', 'sgpr_spill_count'):
+                    cur[key] = int(val)
+    return kernels
+
+
+def test_no_product_kernel_uses_scratch():
+    """Every kernel of libst2_hip.so keeps its state in registers / LDS: no private segment, no VGPR spills (a
+    512-register kernel that spills is what faulted in round 1's operand-feed probe, now in tools/probes/)."""
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-readelf'):
+        pytest.skip('ROCm llvm tools absent')
+    kernels = _code_object_kernels(capi.lib_path())
+    assert len(kernels) >= 40, len(kernels)
+    bad = {k: v for k, v in kernels.items() if v.get('private_segment_fixed_size', 0) or v.get('vgpr_spill_count', 0)}
+    assert not bad, bad
+    assert not [k for k in kernels if 'probe' in k], 'development probes belong to tools/probes/, not the product library'
 
 
 # --------------------------------------------------------------------------- host-side mirrors

@@ -32,17 +32,31 @@ def test_bench_line_has_the_contract_keys():
     assert d['unit'] == 'it/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['vs_baseline'] is None
     assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config']
     assert abs(d['value'] - 1e3 / d['ms_per_step']) <= 1e-6 * d['value']
+    assert 'custom' in d['config']['workload']                  # 256 px is not a BASELINE.json config and says so
+    assert d['timing']['blocks'] == 5 and len(d['timing']['block_ms']) == 5
     r = d['roofline']
-    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'executed', 'executed_frac'):
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'algorithmic', 'algorithmic_over_peak'):
         assert k in r, k
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == pytest.approx(157.3)
     assert r['frac'] == pytest.approx(r['achieved'] / r['peak'])
-    assert 0 < r['executed'] <= r['achieved']
+    assert 0 < r['frac'] < 1                                    # a fraction of the MFMA peak: executed flops
+    assert 0 < r['achieved'] <= r['algorithmic']
+    assert r['traffic'] is None and r['traffic_source']         # no PMC pass for this configuration: null, and says why
     c = d['cpu_baseline']
     assert c['kind'] == 'port' and c['unit'] == 'it/s' and c['value'] > 0 and c['cores'] >= 1 and '64x64' in c['sample']
+    assert d['parity'] is None                                  # the CPU sample was taken at another size
+    w = d['worker_level']
+    assert w['sync_iterate_it_s'] > 0 and w['async_iterate_it_s'] > 0 and w['iterate_MB'] == pytest.approx(256 * 256 * 3 * 4 / 1e6, rel=0.05)
+
+
+def test_bench_parity_leg_at_the_benched_size():
+    d = run_bench('--size', '128', '--no-worker-level')
+    p = d['parity']
+    assert p['loss_rel'] <= 1e-4 and p['grad_rel_l2'] <= 5e-3 and p['grad_cosine'] >= 0.9999
+    assert p['relu_sign_flips'] <= 50 and p['activations'] > 1e6
 
 
 def test_bench_bf16_and_lbfgs_variants_run():
-    d = run_bench('--precision', 'bf16', '--optimizer', 'lbfgs', '--no-cpu-baseline')
-    assert 'bf16' in d['dtype'] and 'cpu_baseline' not in d
+    d = run_bench('--precision', 'bf16', '--optimizer', 'lbfgs', '--no-cpu-baseline', '--repeats', '2')
+    assert 'bf16' in d['dtype'] and 'cpu_baseline' not in d and d['timing']['blocks'] == 2
     assert d['roofline']['peak'] == pytest.approx(2516.6)

@@ -85,7 +85,10 @@ if dist is not None:
 dt = time.perf_counter() - t0
 if rank == 0:
     print(json.dumps({'metric': 'tile-sharded style-transfer iters/sec @%sx%s VGG19' % (gH, gW), 'value': args.steps / dt,
-                      'unit': 'it/s', 'n_gpus': world, 'grid': args.grid, 'steps': args.steps, 'ms_per_step': 1e3 * dt / args.steps,
+                      'unit': 'it/s', 'n_gpus': world, 'grid': args.grid, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
+                      'higher_is_better': True, 'vs_baseline': None,
+                      'config': {'workload': 'configs[4]: ONE %dx%d image tile-sharded %s (apron design, RCCL all-reduces + strip exchange), adam fp32' % (gH, gW, args.grid),
+                                 'measured_on_hardware': 'by the driver only; the builder has one GPU'},
                       'apron_px': grid.apron, 'window': [win.y1 - win.y0, win.x1 - win.x0], 'loss': float(vals[-2]),
                       'dtype': 'f32', 'scaling': 'strong', 'data': 'synthetic'}))
 if dist is not None:

@@ -2,8 +2,8 @@
 """Time one conv shape/config with a chosen iteration count: conv_one.py K M H W cfg dgrad iters [repeat]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from style_transfer2_amd import capi
-lib = capi.load_library()
+from tools import probes
+lib = probes.load_library()
 K, M, H, W, cfg, dgrad, iters = [int(v) for v in sys.argv[1:8]]
 rep = int(sys.argv[8]) if len(sys.argv) > 8 else 1
 for _ in range(rep):

@@ -4,9 +4,9 @@ import ctypes
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from style_transfer2_amd import capi
+from tools import probes
 
-lib = capi.load_library()
+lib = probes.load_library()
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 only = sys.argv[2].split(',') if len(sys.argv) > 2 else None
 LAYERS = [('conv1_1', 3, 64, 1), ('conv1_2', 64, 64, 1), ('conv2_1', 64, 128, 2), ('conv2_2', 128, 128, 2),

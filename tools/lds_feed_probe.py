@@ -2,8 +2,8 @@
 """Cycles per k-pair of the LDS-staged-U Winograd feed pattern (GPU box); 1024 = MFMA-bound."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from style_transfer2_amd import capi
-lib = capi.load_library()
+from tools import probes
+lib = probes.load_library()
 for K in (512, 128):
     for extra in (0, 1):
         for blocks in (8, 256, 1024):

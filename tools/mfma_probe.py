@@ -2,8 +2,8 @@
 """Matrix-pipe ceiling on this chip for v_mfma_f32_32x32x2_f32 (GPU box)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from style_transfer2_amd import capi
-lib = capi.load_library()
+from tools import probes
+lib = probes.load_library()
 for variant, name in ((0, 'registers, smooth data'), (4, 'registers, random data'), (1, 'LDS reads, smooth data'), (2, 'LDS reads, random data'), (3, 'LDS reads, random, pinned order')):
     for bpc in (1, 2, 3):
         tf = ctypes.c_double()

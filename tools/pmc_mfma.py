@@ -26,4 +26,8 @@ for name in sorted(acc, key=lambda n: -acc[n].get('GRBM_GUI_ACTIVE', 0)):
     out[name] = dict(launches=calls[name], mfma_busy_frac=frac, gui_active_cycles_per_launch=gui / 8.0 / max(1, calls[name]))
     print('%-46s n=%-4d MFMA busy %5.1f %%   %9.0f active cycles per launch' % (name[:46], calls[name], 100 * frac, gui / 8.0 / max(1, calls[name])))
 if len(sys.argv) > 2:
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out['_meta'] = dict(source_sha16=bench.source_hash(), profile=os.environ.get('ST2_PROFILE_TAG', '?'))
     json.dump(out, open(sys.argv[2], 'w'), indent=1)

@@ -42,4 +42,9 @@ out['_conv3x3_all'] = dict(launches=conv_n, hbm_bytes_per_launch=(conv_rd + conv
 print('conv3x3 matrix-core launches (direct + Winograd): %.1f MB read + %.1f MB written per launch (avg over %d launches)' % (
     conv_rd / max(1, conv_n) / 1e6, conv_wr / max(1, conv_n) / 1e6, conv_n))
 if len(sys.argv) > 3:
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out['_meta'] = dict(source_sha16=bench.source_hash(), profile=os.environ.get('ST2_PROFILE_TAG', '?'),
+                        note='HBM bytes per launch from separate --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled for wide loads')
     json.dump(out, open(sys.argv[3], 'w'), indent=1)

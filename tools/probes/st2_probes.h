@@ -1,0 +1,33 @@
+/* st2_probes.h -- C entry points of tools/probes/libst2_probes.so: micro-benchmarks that sized the kernels of
+ * libst2_hip.so (matrix-pipe ceiling, operand-feed and issue-rate probes) and an isolated timing hook for the conv
+ * kernels.  Development tools: NOT part of the product library or of its C ABI (include/st2.h), never loaded by
+ * worker.py / bench.py / the tests of the product path.  Every function returns 0 on success; st_probe_last_error()
+ * has the message otherwise. */
+#ifndef ST2_PROBES_H
+#define ST2_PROBES_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+const char* st_probe_last_error(void);
+/* isolated timing of the conv3x3 MFMA kernel on one layer shape (K input channels, M output channels, HxW, random
+ * data).  cfg < 0: the engine's own tile choice (returned in *cfg_used); cfg >= 100: the Winograd kernel (100: its own
+ * choice incl. split-K, 101: 128 ch x 4x32 px, 102: 64 ch x 8x32 px, 103 / 106: those with cycle stamps).
+ * dgrad_epilogue != 0 adds the ReLU-mask + injected-diff epilogue of the backward pass. */
+int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_epilogue, int iters,
+                  double* avg_ms, int* cfg_used);
+int st_conv_num_configs(void);
+const char* st_conv_config_name(int cfg);
+/* matrix-pipe ceiling probe: variant 0 = register operands, 1 = + LDS operand reads; blocks_per_cu 256-thread
+ * workgroups per CU; returns sustained TFLOP/s of v_mfma_f32_32x32x2_f32 */
+int st_bench_mfma(int device_id, int variant, int blocks_per_cu, double* tflops);
+/* issue-rate probe: shader cycles per v_mfma_f32_32x32x2_f32 at one wave per SIMD with naux VALU + nlds ds_read between MFMAs */
+int st_bench_issue_probe(int device_id, int naux, int nlds, double* cycles_per_mfma);
+/* feed probe of the LDS-staged-U Winograd design: shader cycles per k-pair (16 MFMAs = 1024 cycles ideal) */
+int st_bench_lds_feed_probe(int device_id, int extra_dma, int K, int blocks, double* cycles_per_kpair);
+/* Winograd operand-feed probe: executed MFMA TFLOP/s with the A operands streamed L2 -> VGPR; depth = k-pairs in
+ * flight: 1, 2, or 12 (= 2 with a staggered k walk).  Depth 4 is rejected: see probes.hip. */
+int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int depth, double* tflops);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -2,8 +2,8 @@
 """Can transformed Winograd weights stream from L2 straight into MFMA operand registers fast enough? (GPU box)"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from style_transfer2_amd import capi
-lib = capi.load_library()
+from tools import probes
+lib = probes.load_library()
 for K, M in ((512, 512), (256, 256), (128, 128)):
     for depth in (1, 2, 12):
         for bpc in (2, 4):

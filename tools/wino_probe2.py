@@ -2,8 +2,8 @@
 """Is the U stream bound per CU or by contention in the XCD's L2?  Same probe with 8, 32, 64, 128, 256 workgroups."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from style_transfer2_amd import capi
-lib = capi.load_library()
+from tools import probes
+lib = probes.load_library()
 for K, M in ((512, 512), (128, 128)):
     for blocks in (8, 32, 64, 128, 256, 512):
         tf = ctypes.c_double()

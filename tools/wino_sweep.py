@@ -2,8 +2,8 @@
 """Winograd vs direct conv3x3 kernel per VGG19 layer shape (GPU box).  TF/s are ALGORITHMIC (direct-conv flops)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from style_transfer2_amd import capi
-lib = capi.load_library()
+from tools import probes
+lib = probes.load_library()
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 ITERS = int(os.environ.get('ITERS', '40'))
 LAYERS = [('conv1_2', 64, 64, 1), ('conv2_1', 64, 128, 2), ('conv2_2', 128, 128, 2), ('conv3_1', 128, 256, 4),

@@ -151,12 +151,18 @@ class Worker:
             self._again = getattr(sock_in, 'Again', BlockingIOError)
             self._noblock = 1
         self.sock_in = sock_in
-        self._raw_out = sock_out
-        async_send = str(config.get('async_iterate', '1')).lower() not in ('0', 'false', 'no')
-        self.sock_out = AsyncSender(sock_out) if async_send else sock_out
+        self._raw_out = self.sock_out = sock_out
         self.run_should_stop = False
-        self.transfer = transfer if transfer is not None else build_transfer(config)
-        self.sock_out.send_pyobj(WorkerReady(layers=self.transfer.model.layers()))
+        try:
+            # the model first (it may sys.exit(2): reference worker.py:51-53), the sender thread only once it exists
+            self.transfer = transfer if transfer is not None else build_transfer(config)
+            async_send = str(config.get('async_iterate', '1')).lower() not in ('0', 'false', 'no')
+            if async_send:
+                self.sock_out = AsyncSender(sock_out)
+            self.sock_out.send_pyobj(WorkerReady(layers=self.transfer.model.layers()))
+        except BaseException:
+            self.close()            # the reference always reaches ctx.destroy(0) (worker.py:429-431)
+            raise
 
     def close(self):
         if isinstance(self.sock_out, AsyncSender):
