@@ -105,6 +105,10 @@ int st_step(st_ctx* ctx, float* out_hwc, double* trace, float* out_loss);
  * steady-state Adam steps are captured once per ping-pong parity and replayed, bit-identical to plain launches.  Measured
  * on MI355X it is no faster (the step is bound by the dependent kernels' execution latency), hence off by default. */
 int st_graph_replays(st_ctx* ctx, long long* n);
+/* Test hook for LBFGSOptimizer.inv_hv (optimizers.py:89-108): p = H g by the device two-loop recursion for a given
+ * history of n_pairs <= 10 (s, y) pairs, oldest first, each a (3,H,W) array of the current input geometry with
+ * s.y > 1e-10; nothing is applied to the iterate.  Replaces the optimizer's history (the next step starts empty). */
+int st_lbfgs_inv_hv(st_ctx* ctx, int n_pairs, const float* const* s, const float* const* y, const float* g, float* out_p);
 int st_sync(st_ctx* ctx);
 
 /* ---- measurement ----------------------------------------------------------------------------------- */

@@ -23,6 +23,7 @@ SOURCES = (
     ('conv3x3_winograd.hip', ()),
     ('gram.hip', ()),
     ('passes.hip', ('-ffp-contract=off',)),      # NumPy-like one-rounding-per-operation arithmetic
+    ('lbfgs.hip', ('-ffp-contract=off',)),
     ('engine.cpp', ('-x', 'hip')),
 )
 HEADERS = ('st2_kernels.h', 'reduce.cuh', os.path.join('..', '..', 'include', 'st2.h'))

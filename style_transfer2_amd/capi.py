@@ -62,6 +62,7 @@ PROTOTYPES = {
     'st_adam_set_state': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
     'st_step': (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float)]),
     'st_graph_replays': (c_int, [c_void_p, POINTER(c_longlong)]),
+    'st_lbfgs_inv_hv': (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p]),
     'st_sync': (c_int, [c_void_p]),
     'st_profile_enable': (c_int, [c_void_p, c_int]),
     'st_profile_num_classes': (c_int, []),

@@ -147,14 +147,14 @@ struct st_ctx {
     int items1 = 0, items2 = 0;
     bool m_zero = true, v_zero = true;
     // L-BFGS
-    static const int kCorr = 10;
-    float* hs[kCorr + 1] = {nullptr};              // ring of s vectors (+1 scratch slot)
-    float* hy[kCorr + 1] = {nullptr};
-    std::vector<int> order;                        // slot ids, oldest first
+    static const int kCorr = kLbfgsCorr;
+    float* hs[kLbfgsSlots] = {nullptr};            // ring of s vectors (10 pairs + the one being formed)
+    float* hy[kLbfgsSlots] = {nullptr};
+    LbfgsDev* lb_dev = nullptr;                    // history bookkeeping (pair count, ring order, s.y, y.y): device-resident
+    bool lb_clear = true;                          // history to be emptied before the next step (reset / objective_changed)
+    float* lb_part = nullptr;                      // [4][kMaxPartials] partial sums of the chained dot products
     float* g_cur = nullptr; float* pvec = nullptr;
     bool have_cur = false;
-    float* scal = nullptr;                         // device scalars: sy[11], alpha[11], tmp[8]
-    float* dot_part = nullptr;
     float last_loss = 0.f;
     // tile-sharded mode (BASELINE config 5): this context holds ONE window of a larger image
     struct Tile {
@@ -485,7 +485,7 @@ static int set_input_common(st_ctx* c, int H, int W)
     ST_TRY(ensure_input_buffers(c, H, W));
     if (reshaped) {            // every size-dependent optimizer tensor starts from zero
         c->m_zero = c->v_zero = true;
-        c->order.clear();
+        c->lb_clear = true;
         c->have_cur = false;
     }
     return ST_OK;
@@ -648,64 +648,42 @@ static int lbfgs_alloc(st_ctx* c)
     return ST_OK;
 }
 
+static LbfgsArgs lbfgs_args(st_ctx* c, int apply)
+{
+    LbfgsArgs a{};
+    for (int i = 0; i < kLbfgsSlots; ++i) { a.v.s[i] = c->hs[i]; a.v.y[i] = c->hy[i]; }
+    a.st = c->lb_dev; a.part = c->lb_part; a.part2 = c->lb_part + 2 * kMaxPartials;
+    a.g = c->g_cur; a.p = c->pvec; a.x = c->x[c->cur];
+    a.n = (size_t)3 * c->H * c->W; a.step = (float)c->step_size; a.apply = apply;
+    return a;
+}
+
+// One LBFGSOptimizer.step (optimizers.py:62-77).  Nothing is read back: the pair count, the ring order and the
+// s.y > 1e-10 decision live on the device (lbfgs.hip), so consecutive steps queue up like Adam steps do.
 static int lbfgs_step(st_ctx* c)
 {
     ST_TRY(lbfgs_alloc(c));
     const size_t n = (size_t)3 * c->H * c->W;
     float* x = c->x[c->cur];
-    float* sy = c->scal;            // [11] by slot
-    float* alpha = c->scal + 16;    // [11] by slot
-    float* tmp = c->scal + 32;      // scratch scalars
     hipStream_t s = c->stream;
+    if (c->lb_clear) {              // objective_changed / a new optimizer: sy = [], ss = [], ys = [] (optimizers.py:121-125)
+        HIP_TRY(hipMemsetAsync(c->lb_dev, 0, sizeof(LbfgsDev), s));
+        c->lb_clear = false;
+    }
     if (!c->have_cur) {             // optimizers.py:64-65
         ST_TRY(eval_objective(c, x, true, c->g_cur, false, nullptr));
         c->have_cur = true;
     }
-    std::unique_ptr<ProfScope> ps(new ProfScope(c, P_VECTOR, 0, 0));      // released on every exit path
-    // p = inv_hv(grad): optimizers.py:89-108
-    HIP_TRY(hipMemcpyAsync(c->pvec, c->g_cur, n * sizeof(float), hipMemcpyDeviceToDevice, s));
-    for (int k = (int)c->order.size() - 1; k >= 0; --k) {
-        const int slot = c->order[k];
-        HIP_TRY(launch_dot(c->hs[slot], c->pvec, n, c->dot_part, tmp, s));
-        HIP_TRY(launch_scalar_op(kOpDiv, tmp, sy + slot, nullptr, 0.f, alpha + slot, s));
-        HIP_TRY(launch_axpy_dev(alpha + slot, -1.f, c->hy[slot], c->pvec, n, s));
+    {   // s = -step * inv_hv(grad) ; x += s          (optimizers.py:68-69, 89-108)
+        ProfScope ps(c, P_VECTOR, 0, 4.0 * n * (8.0 * kLbfgsCorr + 3.0));
+        HIP_TRY(launch_lbfgs_two_loop(lbfgs_args(c, 1), s));
     }
-    if (!c->order.empty()) {
-        const int slot = c->order.back();
-        HIP_TRY(launch_dot(c->hy[slot], c->hy[slot], n, c->dot_part, tmp, s));
-        HIP_TRY(launch_scalar_op(kOpDivInv, sy + slot, tmp, nullptr, 0.f, tmp + 1, s));
-        HIP_TRY(launch_scale_dev(tmp + 1, 1.f, c->pvec, c->pvec, n, s));
-    } else {
-        HIP_TRY(launch_dot(c->pvec, c->pvec, n, c->dot_part, tmp, s));
-        HIP_TRY(launch_scalar_op(kOpRsqrtMean, tmp, nullptr, nullptr, (float)n, tmp + 1, s));
-        HIP_TRY(launch_scale_dev(tmp + 1, -1.f, c->pvec, c->pvec, n, s));
+    ST_TRY(eval_objective(c, x, true, c->grad, false, nullptr));       // new loss / grad (optimizers.py:72)
+    {   // y = grad - self.grad ; store_curvature_pair(s, y)            (optimizers.py:73-87)
+        ProfScope ps(c, P_VECTOR, 0, 4.0 * n * 4.0);
+        HIP_TRY(launch_lbfgs_pair(lbfgs_args(c, 1), c->grad, 0, s));
     }
-    for (size_t k = 0; k < c->order.size(); ++k) {
-        const int slot = c->order[k];
-        HIP_TRY(launch_dot(c->hy[slot], c->pvec, n, c->dot_part, tmp, s));
-        HIP_TRY(launch_scalar_op(kOpSubDiv, tmp, sy + slot, alpha + slot, 0.f, tmp + 1, s));
-        HIP_TRY(launch_axpy_dev(tmp + 1, 1.f, c->hs[slot], c->pvec, n, s));
-    }
-    // free slot for the new pair
-    int slot = -1;
-    for (int i = 0; i <= st_ctx::kCorr && slot < 0; ++i)
-        if (std::find(c->order.begin(), c->order.end(), i) == c->order.end()) slot = i;
-    // s = -step * p ; x += s
-    HIP_TRY(launch_lincomb((float)(-c->step_size), c->pvec, 0.f, nullptr, c->hs[slot], n, s));
-    HIP_TRY(launch_lincomb(1.f, x, 1.f, c->hs[slot], x, n, s));
-    ps.reset();
-    // new loss / grad
-    ST_TRY(eval_objective(c, x, true, c->grad, false, nullptr));
-    ps.reset(new ProfScope(c, P_VECTOR, 0, 0));
-    HIP_TRY(launch_lincomb(1.f, c->grad, -1.f, c->g_cur, c->hy[slot], n, s));       // y = grad - self.grad
-    HIP_TRY(launch_dot(c->hs[slot], c->hy[slot], n, c->dot_part, sy + slot, s));
     std::swap(c->g_cur, c->grad);
-    ps.reset();
-    float sy_host = 0.f;            // the only host decision of the step (optimizers.py:82)
-    HIP_TRY(hipMemcpyAsync(&sy_host, sy + slot, sizeof(float), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (sy_host > 1e-10f) c->order.push_back(slot);
-    if ((int)c->order.size() > st_ctx::kCorr) c->order.erase(c->order.begin());
     return ST_OK;
 }
 
@@ -803,8 +781,9 @@ int st_create(st_ctx** out, int device_id, const st_layer_desc* layers, int n_la
     ST_TRY(dmalloc(&c->image_part, 6 * kMaxPartials));
     ST_TRY(dmalloc(&c->trace_dev, kMaxTraceLayers * 6 + 8));
     HIP_TRY(hipMalloc((void**)&c->trace_sums, (kMaxTraceLayers * kLayerSlots + kImageSlots) * sizeof(double)));
-    ST_TRY(dmalloc(&c->scal, 64));
-    ST_TRY(dmalloc(&c->dot_part, kMaxPartials));
+    HIP_TRY(hipMalloc((void**)&c->lb_dev, sizeof(LbfgsDev)));
+    HIP_TRY(hipMemset(c->lb_dev, 0, sizeof(LbfgsDev)));
+    ST_TRY(dmalloc(&c->lb_part, 4 * kMaxPartials));
     HIP_TRY(hipHostMalloc((void**)&c->trace_host, (kMaxTraceLayers * 6 + 8) * sizeof(float), 0));
     // worker.py:129-133: all-ones weights over every blob until SetWeights arrives
     for (int b = 0; b < c->nb; ++b) c->rows.push_back(ActiveLayer{b, 1.f, 1.f, 1.f, true, true, true});
@@ -835,7 +814,8 @@ int st_destroy(st_ctx* c)
     for (auto& p : c->s2_part) dfree(p);
     dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->gram_fold); dfree(c->dbuf); dfree(c->conv_scratch);
     dfree(c->tile.p1); dfree(c->tile.p2); dfree(c->tile.p3); dfree(c->tile.pd); dfree(c->tile.wgrad);
-    dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->scal); dfree(c->dot_part); dfree(c->hwc_dev);
+    dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->lb_part); dfree(c->hwc_dev);
+    if (c->lb_dev) (void)hipFree(c->lb_dev);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     if (c->trace_sums) (void)hipFree(c->trace_sums);
     if (c->trace_host) (void)hipHostFree(c->trace_host);
@@ -1155,7 +1135,7 @@ int st_optimizer_reset(st_ctx* c, int kind, double step_size)
     c->step_size = step_size;
     c->items1 = c->items2 = 0;
     c->m_zero = c->v_zero = true;
-    c->order.clear();
+    c->lb_clear = true;
     c->have_cur = false;
     return ST_OK;
 }
@@ -1178,7 +1158,7 @@ int st_objective_changed(st_ctx* c)
         c->items1 = 0;
         c->m_zero = true;
     } else if (c->opt_kind == ST_OPT_LBFGS) {    // optimizers.py:121-125
-        c->order.clear();
+        c->lb_clear = true;
         c->have_cur = false;
     }
     return ST_OK;
@@ -1244,6 +1224,36 @@ int st_step(st_ctx* c, float* out_hwc, double* trace, float* out_loss)
         HIP_TRY(hipMemcpyAsync(out_hwc, c->hwc_dev, (size_t)3 * c->H * c->W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     }
     if (out_hwc || trace || out_loss) return read_trace(c, trace, out_loss);
+    return ST_OK;
+}
+
+// Test hook: p = inv_hv(g) of optimizers.py:89-108 for a GIVEN history, run by the same device two-loop the optimizer
+// uses (lbfgs.hip), without applying the update.  pairs are oldest first; each must pass the s.y > 1e-10 gate.
+// The optimizer's own history is replaced: the next L-BFGS step starts from an empty one.
+int st_lbfgs_inv_hv(st_ctx* c, int n_pairs, const float* const* s_vecs, const float* const* y_vecs, const float* g, float* out_p)
+{
+    if (c) c->epoch++;
+    if (!c || !g || !out_p || n_pairs < 0 || n_pairs > kLbfgsCorr || (n_pairs && (!s_vecs || !y_vecs))) return fail(ST_ERR_ARG, "bad argument");
+    if (!c->x[0]) return fail(ST_ERR_STATE, "no input image (it fixes the vector length)");
+    HIP_TRY(hipSetDevice(c->device));
+    ST_TRY(lbfgs_alloc(c));
+    const size_t bytes = (size_t)3 * c->H * c->W * sizeof(float);
+    hipStream_t st = c->stream;
+    HIP_TRY(hipMemsetAsync(c->lb_dev, 0, sizeof(LbfgsDev), st));
+    c->lb_clear = true; c->have_cur = false;
+    for (int k = 0; k < n_pairs; ++k) {        // an empty ring hands out slots 0, 1, 2, ... while every pair is kept
+        HIP_TRY(hipMemcpyAsync(c->hs[k], s_vecs[k], bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(c->hy[k], y_vecs[k], bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(launch_lbfgs_pair(lbfgs_args(c, 0), nullptr, 1, st));
+    }
+    HIP_TRY(hipMemcpyAsync(c->g_cur, g, bytes, hipMemcpyHostToDevice, st));
+    LbfgsDev host{};
+    HIP_TRY(hipMemcpyAsync(&host, c->lb_dev, sizeof host, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (host.count != n_pairs) return fail(ST_ERR_ARG, "%d of %d pairs failed the s.y > 1e-10 gate", n_pairs - host.count, n_pairs);
+    HIP_TRY(launch_lbfgs_two_loop(lbfgs_args(c, 0), st));
+    HIP_TRY(hipMemcpyAsync(out_p, c->pvec, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return ST_OK;
 }
 
@@ -1328,7 +1338,7 @@ int st_resample_state(st_ctx* c, const st_resample_table* lan_x, const st_resamp
     const int i1 = c->items1, i2 = c->items2;
     if (rc == ST_OK) rc = ensure_input_buffers(c, H2, W2);            // frees and re-creates x, m, v, L-BFGS vectors
     if (rc == ST_OK) {
-        c->order.clear(); c->have_cur = false;
+        c->lb_clear = true; c->have_cur = false;
         hip_ok(hipMemcpyAsync(c->x[c->cur], tx, n2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "x copy");
         if (keep_m) hip_ok(hipMemcpyAsync(c->m, tm, n2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "m copy");
         if (keep_v) hip_ok(hipMemcpyAsync(c->v, tv, n2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream), "v copy");

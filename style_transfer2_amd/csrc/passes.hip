@@ -616,17 +616,7 @@ hipError_t launch_finalize_trace(const TraceArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
-// ------------------------------------------------------------------------------- BLAS-1 (L-BFGS)
-__global__ __launch_bounds__(256) void dot_partial_k(const float* __restrict__ x, const float* __restrict__ y,
-                                                     size_t n, float* __restrict__ part)
-{
-    __shared__ float scratch[4];
-    float acc[1] = {0.f};
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc[0] += x[i] * y[i];
-    block_sum(acc, scratch);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
-}
-
+// ---------------------------------------------------------------------- deterministic final sums
 __global__ __launch_bounds__(256) void dot_final_k(const float* part, int n_part, float* out)
 {
     __shared__ double scratch[256];
@@ -637,59 +627,6 @@ __global__ __launch_bounds__(256) void dot_final_k(const float* part, int n_part
 hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t s)
 {
     dot_final_k<<<1, 256, 0, s>>>(part, n, out);
-    return hipGetLastError();
-}
-
-hipError_t launch_dot(const float* x, const float* y, size_t n, float* partial, float* out, hipStream_t s)
-{
-    const int grid = reduce_grid(n, 256 * 8, kMaxPartials);
-    dot_partial_k<<<grid, 256, 0, s>>>(x, y, n, partial);
-    dot_final_k<<<1, 256, 0, s>>>(partial, grid, out);
-    return hipGetLastError();
-}
-
-__global__ void scalar_op_k(int op, const float* a, const float* b, const float* c, float k, float* out)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    switch (op) {
-    case kOpDiv: *out = *a / *b; break;                       // dot / sy
-    case kOpNegDiv: *out = -(*a / *b); break;
-    case kOpSubDiv: *out = *c - *a / *b; break;               // alpha - beta
-    case kOpRsqrtMean: *out = sqrtf(*a / k); break;           // sqrt(dot(p,p) / p.size)
-    case kOpDivInv: *out = *a / *b; break;                    // sy / dot(y,y)
-    }
-}
-
-hipError_t launch_scalar_op(int op, const float* a, const float* b, const float* c, float k, float* out, hipStream_t s)
-{
-    scalar_op_k<<<1, 64, 0, s>>>(op, a, b, c, k, out);
-    return hipGetLastError();
-}
-
-__global__ __launch_bounds__(256) void axpy_dev_k(const float* coef, float sign, const float* __restrict__ x,
-                                                  float* __restrict__ y, size_t n)
-{
-    const float c = sign * *coef;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = c * x[i] + y[i];
-}
-
-hipError_t launch_axpy_dev(const float* coef, float coef_sign, const float* x, float* y, size_t n, hipStream_t s)
-{
-    axpy_dev_k<<<reduce_grid(n, 256 * 4, 8192), 256, 0, s>>>(coef, coef_sign, x, y, n);
-    return hipGetLastError();
-}
-
-// k > 0: y = x * (*coef) ; k < 0: y = x / (*coef)
-__global__ __launch_bounds__(256) void scale_dev_k(const float* coef, float k, const float* x, float* y, size_t n)
-{
-    const float c = *coef;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        y[i] = k > 0.f ? x[i] * c : x[i] / c;
-}
-
-hipError_t launch_scale_dev(const float* coef, float k, const float* x, float* y, size_t n, hipStream_t s)
-{
-    scale_dev_k<<<reduce_grid(n, 256 * 4, 8192), 256, 0, s>>>(coef, k, x, y, n);
     return hipGetLastError();
 }
 

@@ -211,17 +211,39 @@ struct TraceArgs {
 hipError_t launch_finalize_trace(const TraceArgs& a, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
-// BLAS-1 with device-resident scalars (L-BFGS two-loop), optimizers.py:62-108, utils.py:29-46
+// Fixed-step L-BFGS as a device-resident state machine (lbfgs.hip), optimizers.py:49-125, utils.py:29-46
 // ------------------------------------------------------------------------------------------
-hipError_t launch_dot(const float* a, const float* b, size_t n, float* partial, float* out, hipStream_t s);
-enum ScalarOp { kOpDiv = 0, kOpNegDiv = 1, kOpSubDiv = 2, kOpRsqrtMean = 3, kOpDivInv = 4 };
-// tiny scalar kernel: out = f(op, a, b, c)
-hipError_t launch_scalar_op(int op, const float* a, const float* b, const float* c, float k, float* out, hipStream_t s);
-// y = coef_sign * (*coef) * x + y
-hipError_t launch_axpy_dev(const float* coef, float coef_sign, const float* x, float* y, size_t n, hipStream_t s);
-// y = (*coef) * k * x  (y may alias x)
-hipError_t launch_scale_dev(const float* coef, float k, const float* x, float* y, size_t n, hipStream_t s);
-// z = a*x + b*y  (host scalars)
+constexpr int kLbfgsCorr = 10;                  // n_corr (optimizers.py:52)
+constexpr int kLbfgsSlots = kLbfgsCorr + 1;     // ring slots: n_corr pairs + the one being formed
+struct LbfgsDev {                               // lives in device memory; zero = empty history
+    int count;                                  // pairs kept
+    int free_slot;                              // slot of the pair being formed
+    int order[kLbfgsSlots];                     // slot ids of the kept pairs, oldest first
+    int pad_;
+    double sy[kLbfgsSlots], yy[kLbfgsSlots];    // s.y and y.y per slot
+    double alpha[kLbfgsSlots];                  // first-loop coefficients of the current recursion
+    double last_sy;                             // s.y of the last candidate pair (kept or not)
+};
+struct LbfgsVecs { float* s[kLbfgsSlots]; float* y[kLbfgsSlots]; };
+struct LbfgsArgs {
+    LbfgsVecs v;
+    LbfgsDev* st;
+    float* part;            // [2][kMaxPartials] ping-pong partial sums of the chained dot products
+    float* part2;           // [2][kMaxPartials] partial sums of s.y and y.y of the candidate pair
+    const float* g;         // gradient at the current x (self.grad)
+    float* p;               // work vector of the recursion
+    float* x;               // the iterate, updated in place
+    size_t n;
+    float step;
+    int apply;              // 1: the last link forms s = -step p and x += s; 0 (test hook): p = H g is left in `p`
+};
+// p = inv_hv(g) by the two-loop recursion, every link one launch (axpy_i fused with dot_{i+1}); 24 launches, those
+// beyond the current pair count return at once
+hipError_t launch_lbfgs_two_loop(const LbfgsArgs& a, hipStream_t s);
+// candidate pair in the free slot: mode 0: y = g_new - a.g; mode 1: y already stored.  Then the s.y > 1e-10 gate,
+// the commit into the ring and the eviction of the oldest pair, all on the device.
+hipError_t launch_lbfgs_pair(const LbfgsArgs& a, const float* g_new, int mode, hipStream_t s);
+// z = a*x + b*y  (host scalars; y may be nullptr)
 hipError_t launch_lincomb(float a, const float* x, float b, const float* y, float* z, size_t n, hipStream_t s);
 
 }  // namespace st2

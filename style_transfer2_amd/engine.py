@@ -274,6 +274,17 @@ class Engine:
                                byref(loss) if (want_image or want_trace) else None))
         return img, trace, F32(loss.value)
 
+    def lbfgs_inv_hv(self, pairs, g):
+        """Test hook: H g of optimizers.py:89-108 for the given [(s, y), ...] history (oldest first) on the device."""
+        g = np.ascontiguousarray(g, F32)
+        ss = [np.ascontiguousarray(s, F32) for s, _ in pairs]
+        ys = [np.ascontiguousarray(y, F32) for _, y in pairs]
+        sp = (c_void_p * len(pairs))(*[a.ctypes.data for a in ss])
+        yp = (c_void_p * len(pairs))(*[a.ctypes.data for a in ys])
+        out = np.empty_like(g)
+        check(self.lib.st_lbfgs_inv_hv(self._ctx, len(pairs), sp, yp, _ptr(g), _ptr(out)))
+        return out
+
     def sync(self):
         check(self.lib.st_sync(self._ctx))
 

@@ -91,7 +91,7 @@ def test_production_conv_shapes_fp32_at_1024(name, K, M, edge, pooled):
     names = [l[1] for l in topo]
     fg = gpu.forward(x, names)
     fc = cpu.forward(x, names)
-    tol = 1e-5 if K <= 256 else 3e-5            # fp32 k-chain of 9 K terms vs BLAS blocking: ~sqrt(K) eps
+    tol = 2e-6 if K <= 256 else 4e-6            # fp32 k-chain of 9 K terms vs BLAS blocking: ~sqrt(K) eps (measured 3e-7 .. 9e-7)
     errs = {n: rel_l2(fg[n], fc[n]) for n in names}
     flips = int(np.sum((fg['conv_b'] > 0) != (fc['conv_b'] > 0)))
     for n in names:
@@ -117,7 +117,7 @@ def test_production_conv_shapes_bf16_at_2048(name, K, M, edge, pooled):
     wgt, b = params['conv_b']
     ref = np.maximum(conv3x3_forward(bf16_round(fg['conv_a'][0]), bf16_round(wgt), b), 0)
     ferr = rel_l2(fg['conv_b'][0], ref)
-    assert ferr <= 3e-5, ferr
+    assert ferr <= 2e-6, ferr                   # measured 1.3e-7 .. 3.6e-7 on MI355X
     if pooled:
         assert np.array_equal(fg['pool_b'][0], maxpool_forward(fg['conv_b'][0])[0])      # pooling is exact
     del ref
@@ -127,7 +127,7 @@ def test_production_conv_shapes_bf16_at_2048(name, K, M, edge, pooled):
     diffs = {n: rng.randn(*fg[n].shape).astype(F32) for n in names}
     berr = rel_l2(gpu.backward(diffs), cpu.backward(diffs))
     report('bf16 layer %s K%d M%d %dpx' % (name, K, M, edge), {'forward_rel_l2': ferr, 'backward_rel_l2': berr})
-    assert berr <= 5e-5, berr
+    assert berr <= 5e-6, berr                   # measured 4.7e-7 .. 1.3e-6
 
 
 # ------------------------------------------------------------------------------ 2 + 3. whole objective, configs[1]
@@ -168,7 +168,7 @@ def test_vgg19_objective_fp32_at_1024_bench_inputs():
     # (2a) forward blobs of the six weighted layers
     ferr = {n: rel_l2(eng.get_blob(n)[0], net._blobs[n]) for n in WEIGHTED}
     for n in WEIGHTED:
-        assert ferr[n] <= 1e-5, ferr
+        assert ferr[n] <= 3e-6, ferr               # measured 1.2e-7 (conv1_1) .. 9.5e-7 (conv5_1)
     # (2b) loss and every trace scalar that does not depend on the backward pass
     assert np.isclose(ld, lo, rtol=1e-5), (ld, lo)
     tc, td = cpu.traces[-1].data, dev.traces[-1].data
@@ -184,8 +184,9 @@ def test_vgg19_objective_fp32_at_1024_bench_inputs():
     report('fp32 vgg19 1024 objective', {'forward_rel_l2': ferr, 'loss_rel': float(abs(ld - lo) / abs(lo)), 'grad_rel_l2': gerr,
                                          'relu_flips': relu, 'pool_argmax_flips': pool, 'activations': total,
                                          'affected_pixel_frac': frac, 'trace_grad_rms': [td['grad'], tc['grad']]})
-    assert relu <= 3e-6 * total and pool <= 50, (relu, pool, total)
-    assert gerr <= 5e-3, gerr
+    # measured on MI355X: 46 ReLU + 20 arg-max flips in 3.04e8 activations, gradient rel-L2 6.9e-4, 0.66 % of the pixels
+    assert relu <= 1e-6 * total and pool <= 100, (relu, pool, total)
+    assert gerr <= 3e-3, gerr
     assert frac <= 0.02, frac
     assert np.isclose(td['grad'], tc['grad'], rtol=1e-3) and np.isclose(td['scd_grad'], tc['scd_grad'], rtol=1e-3)
     # second evaluation (frozen norms) after moving the image by 2 levels along sign(grad)
@@ -193,7 +194,7 @@ def test_vgg19_objective_fp32_at_1024_bench_inputs():
     lo2, go2 = cpu.opfunc(x2)
     ld2, gd2 = dev.opfunc(x2)
     assert np.isclose(ld2, lo2, rtol=1e-5)
-    assert rel_l2(gd2, go2) <= 5e-3
+    assert rel_l2(gd2, go2) <= 3e-3
     report('fp32 vgg19 1024 second eval', {'loss_rel': float(abs(ld2 - lo2) / abs(lo2)), 'grad_rel_l2': rel_l2(gd2, go2)})
 
 
@@ -212,7 +213,7 @@ def test_vgg19_ranged_backward_fp32_at_1024_on_shared_forward_state():
     diffs = {n: rs(5 + i).randn(*full[n].shape).astype(F32) for i, n in enumerate(['conv5_1', 'pool4', 'conv4_2', 'conv3_1', 'conv2_1', 'conv1_1', 'data'])}
     err = rel_l2(gpu.backward(diffs), net.backward(diffs))
     report('fp32 vgg19 1024 ranged backward (shared forward state)', {'rel_l2': err})
-    assert err <= 3e-5, err
+    assert err <= 3e-6, err                     # measured 8.8e-7
 
 
 # ------------------------------------------------------------------------------ configs[2]: 2048^2, bf16, L-BFGS
@@ -232,9 +233,10 @@ def test_vgg19_objective_bf16_at_2048_and_one_lbfgs_step():
     cos = float(np.vdot(gd.astype(np.float64), go.astype(np.float64)) / (np.linalg.norm(gd.astype(np.float64)) * np.linalg.norm(go.astype(np.float64))))
     vals = {'forward_rel_l2': ferr, 'loss_rel': float(abs(ld - lo) / abs(lo)), 'grad_rel_l2': rel_l2(gd, go), 'grad_cosine': cos}
     report('bf16 vgg19 2048 objective', vals)
-    assert ferr['conv1_1'] <= 1e-5 and max(ferr.values()) <= 2e-2, ferr
-    assert np.isclose(ld, lo, rtol=1e-2)
-    assert cos >= 0.995 and vals['grad_rel_l2'] <= 1e-1
+    # measured: forward 1.2e-7 (conv1_1, fp32 operands) .. 4.4e-3 (conv5_1), loss 2.4e-4, gradient rel-L2 3.3e-2, cosine 0.99947
+    assert ferr['conv1_1'] <= 1e-6 and max(ferr.values()) <= 2e-2, ferr
+    assert np.isclose(ld, lo, rtol=3e-3)
+    assert cos >= 0.998 and vals['grad_rel_l2'] <= 8e-2
     # one L-BFGS step from the same state (optimizers.py:62-77: first step = unit-RMS direction, two evaluations)
     cpu.reset(); dev.reset()
     ic, tc = cpu.step()
@@ -244,4 +246,4 @@ def test_vgg19_objective_bf16_at_2048_and_one_lbfgs_step():
     report('bf16 vgg19 2048 one L-BFGS step', {'loss_rel': float(abs(td['loss'] - tc['loss']) / abs(tc['loss'])), 'image_mse': mse,
                                                'moved_mse': float(np.mean((ic - images(2048)[2]) ** 2))})
     assert np.isclose(td['loss'], tc['loss'], rtol=1e-2)
-    assert mse <= 0.05                      # the step moves every pixel by ~1 level (unit-RMS direction): MSE of the move ~1
+    assert mse <= 0.02                      # the step moves every pixel by ~1 level (unit-RMS direction): MSE of the move ~1

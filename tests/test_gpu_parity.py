@@ -566,6 +566,71 @@ def test_worker_end_to_end_on_gpu_with_resample_and_optimizer_switch():
     assert isinstance(tr.optimizer, st2.LBFGSOptimizer)
 
 
+def test_worker_async_iterate_on_gpu_keeps_order_one_iterate_per_step_shutdown_last():
+    """SURVEY 8f item 3 on the real engine: with the sender thread (async_iterate = 1, the default) the wire still
+    carries WorkerReady first, exactly one Iterate per step in step order, Shutdown last (reference worker.py:333,
+    351-353, 362-363), and the iterates are the ones a synchronous run of the same job produces, bit for bit."""
+    import sys, os, pickle, time
+    from collections import deque
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import messages, worker as worker_mod
+
+    class Socks:
+        class Again(Exception):
+            pass
+
+        def __init__(self):
+            self.inbound, self.sent = deque(), []
+
+        def recv_pyobj(self, flags=0):
+            if not self.inbound:
+                if flags:
+                    raise self.Again()
+                return messages.Shutdown()
+            return pickle.loads(pickle.dumps(self.inbound.popleft()))
+
+        def send_pyobj(self, obj):                     # runs on the sender thread
+            time.sleep(0.002)                          # a slow wire: the worker runs ahead, the queue fills
+            self.sent.append(pickle.loads(pickle.dumps(obj)))
+            if sum(isinstance(m, messages.Iterate) for m in self.sent) == 6:
+                self.inbound.append(messages.PauseIteration())
+
+    topo = oracle.tiny_topology((8, 16), (2, 2))
+    params = oracle.he_init_weights(topo, 0, 0.1)
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (32, 40, 3)).astype(np.uint8), rs(2).randint(0, 256, (24, 24, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (32, 40, 3)).astype(np.uint8))
+    weights = {'content': {'conv2_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1}, 'deepdream': {}}
+    params4 = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+
+    def script():
+        return [messages.SetImages(None, init, content, style, True), messages.SetWeights(weights, params4),
+                messages.SetOptimizer('adam', 10), messages.StartIteration()]
+
+    socks = Socks()
+    socks.inbound.extend(script())
+    wk = worker_mod.Worker({'async_iterate': '1'}, sock_in=socks, sock_out=socks,
+                           transfer=st2.StyleTransfer(st2.HipModel(params, topology=topo)))
+    assert isinstance(wk.sock_out, worker_mod.AsyncSender)
+    wk.run()
+    kinds = [type(m).__name__ for m in socks.sent]
+    assert kinds[0] == 'WorkerReady' and kinds[-1] == 'Shutdown' and kinds.count('Shutdown') == 1
+    its = [m for m in socks.sent if isinstance(m, messages.Iterate)]
+    n = len(its)
+    assert n >= 6 and kinds == ['WorkerReady'] + ['Iterate'] * n + ['Shutdown']
+    assert [m.i for m in its] == list(range(1, n + 1))                 # one per step, in step order, none lost
+    assert [m.trace['fevals'] for m in its] == list(range(1, n + 1))
+    # the same job driven synchronously: identical iterates (the sender thread only moves bytes)
+    ref = st2.StyleTransfer(st2.HipModel(params, topology=topo))
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(weights, params4)
+    ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
+    assert ref.start()
+    for m in its:
+        img, tr = ref.step()
+        assert np.array_equal(m.image, img) and m.trace['loss'] == tr['loss'], m.i
+
+
 def test_engine_error_paths_are_loud():
     topo = oracle.tiny_topology((8, 16), (2, 2))
     params = oracle.he_init_weights(topo, 0, 0.1)

@@ -61,3 +61,36 @@ def test_app_side_image_helpers_match_reference_fixture():
     from PIL import Image
     im = Image.fromarray(np.random.RandomState(0).randint(0, 256, (40, 60, 3)).astype(np.uint8))
     assert jobs.resize_to_fit(im, 30).size == (30, 20)
+
+
+# ---------------------------------------------------------------- .caffemodel reader vs google.protobuf's own encoder
+CAFFEMODEL_VARIANTS = ('v2_shape_packed', 'v1_legacy_unpacked', 'v2_double', 'v2_extra_fields')
+
+
+@pytest.mark.parametrize('variant', CAFFEMODEL_VARIANTS)
+def test_caffemodel_reader_on_protobuf_encoded_fixtures(variant, golden_dir):
+    """tests/golden/caffemodel_*.bin were serialized by google.protobuf from a hand-written minimal caffe.proto schema
+    (tests/golden/make_caffemodel_fixture.py): an encoder that shares nothing with caffemodel.py's test writer.
+    V1 + V2 layers, BlobShape + legacy dims, packed + unpacked floats, double_data, unknown fields to skip."""
+    import os
+    raw = open(os.path.join(golden_dir, 'caffemodel_%s.bin' % variant), 'rb').read()
+    params = weights.he_normal(TOPO, seed=4, bias_std=0.3)
+    layers = caffemodel.read_caffemodel(raw)
+    assert list(layers) == list(params), list(layers)          # weight-less layers (ReLU) are not reported
+    got = caffemodel.vgg_params(layers, TOPO)
+    for name, (w, b) in params.items():
+        assert got[name][0].shape == w.shape and got[name][0].dtype == np.float32
+        assert np.array_equal(got[name][0], w) and np.array_equal(got[name][1], b), (variant, name)
+
+
+@pytest.mark.parametrize('variant', CAFFEMODEL_VARIANTS)
+def test_caffemodel_fixtures_are_what_protobuf_encodes_today(variant, golden_dir):
+    """The committed bytes are reproducible from the committed generator (skipped where google.protobuf is absent)."""
+    import importlib.util
+    import os
+    pytest.importorskip('google.protobuf')
+    spec = importlib.util.spec_from_file_location('make_caffemodel_fixture', os.path.join(golden_dir, 'make_caffemodel_fixture.py'))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    raw = gen.encode(weights.he_normal(TOPO, seed=4, bias_std=0.3), variant)
+    assert raw == open(os.path.join(golden_dir, 'caffemodel_%s.bin' % variant), 'rb').read()
