@@ -98,13 +98,21 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 //   <4,1>: 128 channels x  4 rows x 32 columns      <2,2>: 64 channels x 8 rows x 32 columns
 // With TG = 2 the two waves that share a channel slice load the same U lines together (one L2 fetch), and every
 // thread transforms two (tile, channel) pairs per chunk.
+// PS = true (position split, WM = TG = 2): the two waves that share a channel slice split the 16 transform-domain
+//                POSITIONS instead of the tile groups: wave (m, ph) accumulates positions 8 ph .. 8 ph + 7 of BOTH tile
+//                groups (still 16 accumulators).  Every U quad is then loaded by exactly one wave and feeds two MFMAs:
+//                8 KiB of U per k-pair per CU instead of 16 -- the vector-memory ingest of the CU (~12.8 B/clk) is what
+//                bounds the main loop of the other two variants.  Price: the output transform needs all 16 positions of a
+//                tile in one lane, so the epilogue exchanges PARTIAL 2x2 outputs (the transform is linear: 4 floats per
+//                (channel, tile) instead of 8 positions) through LDS: wave ph finishes tile group ph.
 // QUAD = true : W % 4 == 0 -- activation rows staged as aligned quads (40 floats, x0-4 .. x0+35), 16-byte epilogue accesses.
 // QUAD = false: any W     -- one staged row = one dword LDS-DMA piece of 64 lanes (x0-1 .. x0+62, 34 used; the row part of
 //                the address is scalar, the lane part is computed once), 8-byte (W even) or 4-byte epilogue accesses.
-template <int WM, int TG, int DIAG = 0, bool QUAD = true>
+template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false>
 __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
     static_assert(WM * TG == 4 && (TG == 1 || TG == 2), "4 waves");
+    static_assert(!PS || (WM == 2 && TG == 2), "position split: 2 channel slices x 2 position halves");
     constexpr int BM = 32 * WM;
     constexpr int PROWS = 4 * TG;                        // pixel rows per block
     constexpr int IN_ROWS = PROWS + 2;
@@ -122,6 +130,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // PS: wave_g is the position half in the main loop and the tile group the wave finishes in the epilogue
     const int wave_m = wave / TG, wave_g = wave % TG;
 
     // XCD-aware bijective block -> tile map, pixel tile fastest: the co-resident blocks of one XCD work on the
@@ -230,20 +239,26 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     };
 
     const f32x4* up = reinterpret_cast<const f32x4*>(a.upack) + ((size_t)(mt * WM + wave_m) * nkp + 4 * c_first) * 256 + lane;
-    f32x4 ua[4][4];                     // U ring: set kp % 4 holds k-pair kp, refilled three k-pairs ahead
+    constexpr int UQ = PS ? 2 : 4;      // U quads (4 positions each) a wave needs per k-pair
+    f32x4 ua[4][UQ];                    // U ring: set kp % 4 holds k-pair kp, refilled three k-pairs ahead
     auto u_fill = [&](int kp) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) ua[kp & 3][g] = up[((size_t)kp * 4 + g) * 64];
+        for (int g = 0; g < UQ; ++g) ua[kp & 3][g] = up[((size_t)kp * 4 + (PS ? 2 * wave_g + g : g)) * 64];
         asm volatile("" ::: "memory");   // keeps the loads here (no folding into "load at use")
     };
     // makes the compiler wait for a whole U set at one place (inside a clump) instead of before each group of four MFMAs
     auto u_pin = [&](int set) {
-        asm volatile("" : "+v"(ua[set][0]), "+v"(ua[set][1]), "+v"(ua[set][2]), "+v"(ua[set][3]));
+        if constexpr (PS) asm volatile("" : "+v"(ua[set][0]), "+v"(ua[set][1]));
+        else asm volatile("" : "+v"(ua[set][0]), "+v"(ua[set][1]), "+v"(ua[set][2]), "+v"(ua[set][3]));
     };
-    f32x4 bq[2][4];                     // B operands of two k-pairs, four positions per quad
-    auto b_fetch = [&](const float* vimg, int kpl, int set) {
+    f32x4 bq[2][4];                     // B operands of two k-pairs, four positions per quad (PS: [tile group][quad of the half])
+    auto b_fetch = [&](int buf, int kpl, int set) {
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg) bq[set][pg] = *reinterpret_cast<const f32x4*>(vimg + ((kpl * 4 + pg) * 64 + lane) * 4);
+        for (int pg = 0; pg < 4; ++pg) {
+            const float* vimg = PS ? v_s[buf][pg >> 1] : v_s[buf][wave_g];
+            const int quad = PS ? 2 * wave_g + (pg & 1) : pg;
+            bq[set][pg] = *reinterpret_cast<const f32x4*>(vimg + ((kpl * 4 + quad) * 64 + lane) * 4);
+        }
     };
     // one wait for the rest of a B set (its first quad is awaited by the k-pair's first MFMA) instead of one per quad
     auto b_pin = [&](int set) { asm volatile("" : "+v"(bq[set][1]), "+v"(bq[set][2]), "+v"(bq[set][3])); };
@@ -263,7 +278,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     xf_math();
     xf_write(&v_s[0][0][0] + x_v);
     __syncthreads();
-    b_fetch(v_s[0][wave_g], 0, 0);
+    b_fetch(0, 0, 0);
 
     unsigned long long t0 = 0, r0 = 0;
     if (DIAG) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -285,15 +300,16 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
             const int set = kpl & 1;
 #pragma unroll
             for (int p = 0; p < 16; ++p) {
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[kpl][p >> 2][p & 3], bq[set][p >> 2][p & 3], acc[p], 0, 0, 0);
+                // PS: accumulator p = tile group p / 8, position 8 * half + p % 8 (U quad (p / 4) % 2 of this wave's two)
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[kpl][PS ? (p >> 2) & 1 : p >> 2][p & 3], bq[set][p >> 2][p & 3], acc[p], 0, 0, 0);
                 if (p == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     b_pin(set);
-                    if (kpl < 3) b_fetch(v_s[cur][wave_g], kpl + 1, set ^ 1);
+                    if (kpl < 3) b_fetch(cur, kpl + 1, set ^ 1);
                     else if (MORE) {
                         // own V writes done (lgkmcnt), own raw DMA landed (the 8 U loads of k-pairs 1 and 2 came after it)
                         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                        b_fetch(v_s[cur ^ 1][wave_g], 0, 0);
+                        b_fetch(cur ^ 1, 0, 0);
                     }
                     if (MORE || kpl == 0) u_fill(kp + 3);
                     if (MORE) {
@@ -323,6 +339,54 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         t_loop_end = t1;
         if (tid == 0 && a.stamps) { a.stamps[2 * blockIdx.x] = t1 - t0; a.stamps[2 * blockIdx.x + 1] = r1 - r0; }
     }
+    // Output transform of accumulator element e: the lane's 2x2 outputs y = A^T M A (M = the 4x4 transform-domain tile).
+    // PS: this wave holds two rows of M (positions 8 ph .. 8 ph + 7) of BOTH tile groups; the transform is linear, so each
+    // wave reduces its rows to a partial 2x2 output, hands the partial of the other tile group to its partner through LDS
+    // (the V images are dead by now) and finishes its own group: y = partial(rows 0,1) + partial(rows 2,3).
+    float* const xbuf = &v_s[0][0][0];                         // PS: [wave][e][lane][4] floats = 4 x 16 KiB
+    // (the tile group is a compile-time constant: a run-time index into the accumulators would put them in scratch)
+    auto partial_out = [&](auto grp_t, int e, float (&y)[4]) {    // PS only: this wave's two rows of tile group grp
+        constexpr int grp = decltype(grp_t)::value;
+        float t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float ra = acc[grp * 8 + j][e], rb = acc[grp * 8 + 4 + j][e];      // rows 2 ph and 2 ph + 1 of M
+            if (wave_g == 0) { t0[j] = ra + rb; t1[j] = rb; }                         // rows 0, 1:  tt0 = M0 + M1, tt1 = M1
+            else { t0[j] = ra; t1[j] = -ra - rb; }                                    // rows 2, 3:  tt0 = M2, tt1 = -M2 - M3
+        }
+        y[0] = t0[0] + t0[1] + t0[2]; y[1] = t0[1] - t0[2] - t0[3];
+        y[2] = t1[0] + t1[1] + t1[2]; y[3] = t1[1] - t1[2] - t1[3];
+    };
+    if constexpr (PS) {
+        __syncthreads();                                       // every wave is done with the V images
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float y[4];
+            if (wave_g == 0) partial_out(std::integral_constant<int, 1>{}, e, y);      // the group the partner finishes
+            else partial_out(std::integral_constant<int, 0>{}, e, y);
+            *reinterpret_cast<float4*>(xbuf + ((wave * 16 + e) * 64 + lane) * 4) = make_float4(y[0], y[1], y[2], y[3]);
+        }
+        __syncthreads();
+    }
+    auto out_xf = [&](int e, float& y00, float& y01, float& y10, float& y11) {
+        if constexpr (PS) {
+            float y[4];
+            if (wave_g == 0) partial_out(std::integral_constant<int, 0>{}, e, y);
+            else partial_out(std::integral_constant<int, 1>{}, e, y);
+            const float4 o = *reinterpret_cast<const float4*>(xbuf + (((wave ^ 1) * 16 + e) * 64 + lane) * 4);
+            // rows 0,1 + rows 2,3, whichever wave adds them
+            y00 = y[0] + o.x; y01 = y[1] + o.y; y10 = y[2] + o.z; y11 = y[3] + o.w;
+        } else {
+            float tt[2][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tt[0][j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
+                tt[1][j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
+            }
+            y00 = tt[0][0] + tt[0][1] + tt[0][2]; y01 = tt[0][1] - tt[0][2] - tt[0][3];
+            y10 = tt[1][0] + tt[1][1] + tt[1][2]; y11 = tt[1][1] - tt[1][2] - tt[1][3];
+        }
+    };
   if (!QUAD) {
     // ---- epilogue for any width: the lane stores its own 2x2 tile, 8-byte accesses when W is even, 4-byte otherwise
     const int t31 = lane & 31, khalf = lane >> 5;
@@ -362,18 +426,8 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) {
             const int e = 4 * eb + ee;
-            float tt[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tt[0][j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
-                tt[1][j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
-            }
             float o[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                o[i][0] = tt[i][0] + tt[i][1] + tt[i][2];
-                o[i][1] = tt[i][1] - tt[i][2] - tt[i][3];
-            }
+            out_xf(e, o[0][0], o[0][1], o[1][0], o[1][1]);
             if (a.pool_out && live && mb + ee < a.M) {         // fused max-pool: windows clipped at the right / bottom edge
                 float pm = o[0][0];
                 if (col1) pm = pm > o[0][1] ? pm : o[0][1];
@@ -438,14 +492,8 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) {
             const int e = 4 * eb + ee;
-            float tt[2][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tt[0][j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
-                tt[1][j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
-            }
-            const float y00 = tt[0][0] + tt[0][1] + tt[0][2], y01 = tt[0][1] - tt[0][2] - tt[0][3];
-            const float y10 = tt[1][0] + tt[1][1] + tt[1][2], y11 = tt[1][1] - tt[1][2] - tt[1][3];
+            float y00, y01, y10, y11;
+            out_xf(e, y00, y01, y10, y11);
             if (a.pool_out) {
                 // fused max-pool (Caffe MAX 2x2/2, ceil mode): the lane's 2x2 tile IS one pooling window (tile origins are
                 // even); bias and ReLU commute with max.  A window clipped by the bottom edge keeps its first row only.
@@ -494,6 +542,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128(const WinoKAr
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256(const WinoKArgs a) { conv3x3_wino_body<2, 2>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_anyw(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, false>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_anyw(const WinoKArgs a) { conv3x3_wino_body<2, 2, 0, false>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_ps64x256(const WinoKArgs a) { conv3x3_wino_body<2, 2, 0, true, true>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_ps64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1, true, true>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1>(a); }
 
@@ -520,12 +570,17 @@ __global__ __launch_bounds__(256) void wino_combine_k(const float* __restrict__ 
     }
 }
 
+static int wino_default_variant(int M, int W);
+static bool wino_variant_small(int variant);
+
 // Split-K factor for a launch that would leave most CUs idle (conv5_1 at 1024^2: 128 workgroups on 256 CUs)
 int conv_wino_splits(int K, int M, int H, int W)
 {
     static const bool off = [] { const char* e = getenv("ST2_WINO_SPLITK"); return e && *e == '0'; }();
     if (off || !conv_wino_ok(K, M, H, W) || ((size_t)H * W) % 4 != 0) return 1;      // the combine pass works on float4
-    const int bm = ((M + 63) / 64 * 64 < (M + 127) / 128 * 128) ? 64 : 128, prows = bm == 64 ? 8 : 4;
+    int v = wino_default_variant(M, W);
+    if (v == 3 && W % 4 != 0) v = 1;
+    const int bm = wino_variant_small(v) ? 64 : 128, prows = bm == 64 ? 8 : 4;
     const long long nblk = (long long)((W + 31) / 32) * ((H + prows - 1) / prows) * ((M + bm - 1) / bm);
     const int nch = K / WN_CH;
     int sp = 1;
@@ -546,22 +601,31 @@ bool conv_wino_ok(int K, int M, int H, int W)
     return K >= 8 && K % 8 == 0 && (W % 4 == 0 || anyw) && W >= 1 && M >= 48 && H >= 1 && 4ull * K * H * W < 0xfffffff0ull && 4ull * M * H * W < 0xfffffff0ull;
 }
 
-// variant: 0 = 128 channels x 4x32 pixels, 1 = 64 channels x 8x32 pixels, -1 = choose
+// variant: 0 = 128 channels x 4x32 pixels, 1 = 64 channels x 8x32 pixels (tile groups split over the waves),
+// 3 = 64 channels x 8x32 pixels with the POSITIONS split over the waves (half the U stream), -1 = choose;
+// 2 / 5 / 4 = 0 / 1 / 3 with cycle stamps (diagnostic builds).
 // p.wpack = the Winograd pack (pack_wino_weights_*); p.bias may be any length >= M
+static int wino_default_variant(int M, int W)
+{
+    const char* fe = getenv("ST2_WINO_CFG");               // read per launch: the tests force every variant on every shape
+    if (fe && *fe) return atoi(fe);
+    const char* pe = getenv("ST2_WINO_PS");
+    const bool ps = !(pe && *pe == '0');
+    const int pad128 = (M + 127) / 128 * 128, pad64 = (M + 63) / 64 * 64;
+    if (ps && W % 4 == 0) return 3;       // the any-width build of the position split would spill (it is not built)
+    return pad64 < pad128 ? 1 : 0;
+}
+static bool wino_variant_small(int variant) { return variant == 1 || variant == 3 || variant == 4 || variant == 5; }
+
 hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s)
 {
     if (!conv_wino_ok(p.K, p.M, p.H, p.W) || (reinterpret_cast<uintptr_t>(p.in) & 15) != 0) return hipErrorInvalidValue;
     const bool quad = p.W % 4 == 0;                  // else the any-width kernels (dword staging, narrower epilogue accesses)
-    const bool forced_auto = variant < 0;           // split-K only on the automatic path (variants 0 / 1)
-    if (variant < 0) {
-        const char* env = getenv("ST2_WINO_CFG");            // forces a variant (tests of both variants on every shape)
-        const int forced = env && *env ? atoi(env) : -1;
-        const int pad128 = (p.M + 127) / 128 * 128, pad64 = (p.M + 63) / 64 * 64;
-        variant = forced >= 0 ? forced : (pad64 < pad128 ? 1 : 0);
-    }
-    // variants: 0 = 128 ch x 4x32 px, 1 = 64 ch x 8x32 px, 2 = 0 with cycle stamps, 5 = 1 with cycle stamps
-    if (variant == 3 || variant == 4 || variant > 5) return hipErrorInvalidValue;
-    const bool small = variant == 1 || variant == 5;
+    const bool forced_auto = variant < 0;           // split-K only on the automatic path
+    if (variant < 0) variant = wino_default_variant(p.M, p.W);
+    if (variant == 3 && !quad) variant = 1;
+    if (variant > 5) return hipErrorInvalidValue;
+    const bool small = wino_variant_small(variant);
     const int bm = small ? 64 : 128, prows = small ? 8 : 4;
     WinoKArgs k{};
     k.in = p.in; k.upack = reinterpret_cast<const float4*>(p.wpack); k.bias = p.bias; k.out = p.out;
@@ -579,28 +643,24 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
         const int sp = conv_wino_splits(p.K, p.M, p.H, p.W);
         if (sp > 1 && p.scratch_floats >= (size_t)sp * p.M * p.H * p.W) { k.splits = sp; k.scratch = p.scratch; }
     }
-    if (k.splits > 1) {
-        if (p.pool_out) return hipErrorInvalidValue;          // the caller asks conv_wino_can_pool() first
-        const dim3 g((unsigned)(nblk * k.splits));
-        if (variant == 1) { if (quad) conv3x3_wino_f32_64x256<<<g, dim3(256), 0, s>>>(k); else conv3x3_wino_f32_64x256_anyw<<<g, dim3(256), 0, s>>>(k); }
-        else { if (quad) conv3x3_wino_f32_128x128<<<g, dim3(256), 0, s>>>(k); else conv3x3_wino_f32_128x128_anyw<<<g, dim3(256), 0, s>>>(k); }
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        const size_t n4 = (size_t)p.M * p.H * p.W / 4;
-        const unsigned grid = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-        if (((size_t)p.H * p.W) % 4 != 0) return hipErrorInvalidValue;      // conv_wino_splits() declines such shapes
-        wino_combine_k<<<grid, 256, 0, s>>>(k.scratch, k.splits, p.bias, p.relu, p.mask_src, p.inject, p.out, p.M, (unsigned)(p.H * p.W));
-        return hipGetLastError();
+    const bool stamped = variant == 2 || variant == 4 || variant == 5;
+    if (stamped && (!quad || k.splits > 1)) return hipErrorInvalidValue;      // the stamped builds are quad-only, one pass
+    if (k.splits > 1 && p.pool_out) return hipErrorInvalidValue;              // the caller asks conv_wino_can_pool() first
+    const dim3 g((unsigned)(nblk * k.splits)), b(256);
+    switch (variant) {
+    case 0: if (quad) conv3x3_wino_f32_128x128<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_128x128_anyw<<<g, b, 0, s>>>(k); break;
+    case 1: if (quad) conv3x3_wino_f32_64x256<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_64x256_anyw<<<g, b, 0, s>>>(k); break;
+    case 3: conv3x3_wino_f32_ps64x256<<<g, b, 0, s>>>(k); break;
+    case 2: conv3x3_wino_f32_128x128_stamped<<<g, b, 0, s>>>(k); break;
+    case 4: conv3x3_wino_f32_ps64x256_stamped<<<g, b, 0, s>>>(k); break;
+    default: conv3x3_wino_f32_64x256_stamped<<<g, b, 0, s>>>(k); break;
     }
-    if ((variant == 2 || variant == 5) && !quad) return hipErrorInvalidValue;      // the stamped builds are quad-only
-    if (variant == 5) conv3x3_wino_f32_64x256_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
-    else if (variant == 2) conv3x3_wino_f32_128x128_stamped<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
-    else if (!quad) {
-        if (variant == 1) conv3x3_wino_f32_64x256_anyw<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
-        else conv3x3_wino_f32_128x128_anyw<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
-    }
-    else if (variant == 1) conv3x3_wino_f32_64x256<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
-    else conv3x3_wino_f32_128x128<<<dim3((unsigned)nblk), dim3(256), 0, s>>>(k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || k.splits == 1) return e;
+    if (((size_t)p.H * p.W) % 4 != 0) return hipErrorInvalidValue;      // conv_wino_splits() declines such shapes
+    const size_t n4 = (size_t)p.M * p.H * p.W / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    wino_combine_k<<<grid, 256, 0, s>>>(k.scratch, k.splits, p.bias, p.relu, p.mask_src, p.inject, p.out, p.M, (unsigned)(p.H * p.W));
     return hipGetLastError();
 }
 
