@@ -105,14 +105,26 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 //                bounds the main loop of the other two variants.  Price: the output transform needs all 16 positions of a
 //                tile in one lane, so the epilogue exchanges PARTIAL 2x2 outputs (the transform is linear: 4 floats per
 //                (channel, tile) instead of 8 positions) through LDS: wave ph finishes tile group ph.
+// W8 = true (<4,1> only): EIGHT waves, two per SIMD.  A pair of SIMD partners (waves w and w + 4) shares one channel
+//                slice and splits the 16 positions: 128 accumulator registers per wave instead of 256, which is what lets
+//                two waves live on one SIMD.  With one wave per SIMD nothing a wave issues overlaps its own fp32 MFMAs
+//                (profiles/r01_f_issue_probe: 64 cycles per MFMA bare, +13 for the first two instructions in between), so
+//                every operand fetch / transform / DMA instruction is paid in full; with two waves the partner's MFMAs
+//                run underneath them.  U bytes per CU are unchanged (each wave loads the two quads of its position half),
+//                the input transform of a chunk is done by ONE of the two halves (alternating by chunk), and the
+//                epilogue exchanges partial 2x2 outputs between the partners through LDS (as PS does): the wave with
+//                position half ph finishes accumulator rows 8 ph .. 8 ph + 7.
 // QUAD = true : W % 4 == 0 -- activation rows staged as aligned quads (40 floats, x0-4 .. x0+35), 16-byte epilogue accesses.
 // QUAD = false: any W     -- one staged row = one dword LDS-DMA piece of 64 lanes (x0-1 .. x0+62, 34 used; the row part of
 //                the address is scalar, the lane part is computed once), 8-byte (W even) or 4-byte epilogue accesses.
-template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false>
+template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false>
 __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
     static_assert(WM * TG == 4 && (TG == 1 || TG == 2), "4 waves");
     static_assert(!PS || (WM == 2 && TG == 2), "position split: 2 channel slices x 2 position halves");
+    static_assert(!W8 || (WM == 4 && TG == 1 && QUAD && !PS), "eight waves: 4 channel slices x 2 position halves, aligned widths");
+    constexpr int NW = W8 ? 8 : 4;                       // waves per workgroup
+    constexpr bool SPLIT = PS || W8;                     // the 16 positions are split over two waves
     constexpr int BM = 32 * WM;
     constexpr int PROWS = 4 * TG;                        // pixel rows per block
     constexpr int IN_ROWS = PROWS + 2;
@@ -120,18 +132,20 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     constexpr int COL0 = QUAD ? 3 : 0;                   // staged column of pixel x0 - 1
     constexpr int PLANE = IN_ROWS * IW;
     constexpr int N_RAW = WN_CH * PLANE;                 // floats staged per chunk
-    constexpr int I_PER_WAVE = QUAD ? (N_RAW / 4 + 255) / 256 : WN_CH * IN_ROWS / 4;   // wave-DMAs per wave (64 quads / 64 dwords each)
-    constexpr int RAW = QUAD ? I_PER_WAVE * 1024 : N_RAW;                              // floats per raw buffer
+    constexpr int I_PER_WAVE = QUAD ? (N_RAW / 4 + 64 * NW - 1) / (64 * NW) : WN_CH * IN_ROWS / 4;   // wave-DMAs per wave (64 quads / 64 dwords each)
+    constexpr int RAW = QUAD ? I_PER_WAVE * NW * 256 : N_RAW;                          // floats per raw buffer
     static_assert(QUAD || (WN_CH * IN_ROWS) % 4 == 0, "rows divide over the four waves");
 
     __shared__ __attribute__((aligned(16))) float raw_s[2][RAW];
     __shared__ __attribute__((aligned(16))) float v_s[2][TG][WN_V];
+    __shared__ __attribute__((aligned(16))) float x8_s[W8 ? 8 * 8 * 64 * 4 : 4];     // W8: partial outputs for the partner, [wave][row][lane][4]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // PS: wave_g is the position half in the main loop and the tile group the wave finishes in the epilogue
-    const int wave_m = wave / TG, wave_g = wave % TG;
+    const int wave_m = W8 ? (wave & 3) : wave / TG, wave_g = W8 ? 0 : wave % TG;
+    const int ph = W8 ? wave >> 2 : wave_g;              // position half (SPLIT builds)
 
     // XCD-aware bijective block -> tile map, pixel tile fastest: the co-resident blocks of one XCD work on the
     // same channel slice of U (the dominant stream) and on neighbouring pixel tiles.
@@ -156,7 +170,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     if (QUAD) {
 #pragma unroll
         for (int t = 0; t < I_PER_WAVE; ++t) {
-            const int e = ((wave + 4 * t) * 64 + lane) * 4;
+            const int e = ((wave + NW * t) * 64 + lane) * 4;
             const int c = e / PLANE;
             const int rem = e - c * PLANE;
             const int rr = rem / IW;
@@ -175,7 +189,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 #pragma unroll
             for (int t = 0; t < I_PER_WAVE; ++t) {
                 const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + coff;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s[buf] + (wave + 4 * t) * 256), 16, vo, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s[buf] + (wave + NW * t) * 256), 16, vo, 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -193,7 +207,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     // input transform: this thread owns tile xt of channel xch, in every tile group, of every chunk.
     // V image of one (chunk, tile group): [k-pair 4][pos/4][k parity * 32 + tile][pos%4] -- the B operands of four
     // positions are one ds_read_b128, a transformed row is one ds_write_b128.
-    const int xt = tid & 31, xch = tid >> 5;
+    const int xt = tid & 31, xch = (tid >> 5) & 7;       // W8: both position halves map onto the same 256 pairs; one of them works per chunk
     const int x_raw = xch * PLANE + (2 * (xt >> 4)) * IW + 2 * (xt & 15) + COL0;          // column COL0 = pixel x0 - 1
     const int x_v = (((xch >> 1) * 4) * 64 + (xch & 1) * 32 + xt) * 4;
     float d[TG][16];
@@ -239,33 +253,38 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     };
 
     const f32x4* up = reinterpret_cast<const f32x4*>(a.upack) + ((size_t)(mt * WM + wave_m) * nkp + 4 * c_first) * 256 + lane;
-    constexpr int UQ = PS ? 2 : 4;      // U quads (4 positions each) a wave needs per k-pair
+    constexpr int UQ = SPLIT ? 2 : 4;      // U quads (4 positions each) a wave needs per k-pair
     f32x4 ua[4][UQ];                    // U ring: set kp % 4 holds k-pair kp, refilled three k-pairs ahead
     auto u_fill = [&](int kp) {
 #pragma unroll
-        for (int g = 0; g < UQ; ++g) ua[kp & 3][g] = up[((size_t)kp * 4 + (PS ? 2 * wave_g + g : g)) * 64];
+        for (int g = 0; g < UQ; ++g) ua[kp & 3][g] = up[((size_t)kp * 4 + (SPLIT ? 2 * ph + g : g)) * 64];
         asm volatile("" ::: "memory");   // keeps the loads here (no folding into "load at use")
     };
     // makes the compiler wait for a whole U set at one place (inside a clump) instead of before each group of four MFMAs
     auto u_pin = [&](int set) {
-        if constexpr (PS) asm volatile("" : "+v"(ua[set][0]), "+v"(ua[set][1]));
+        if constexpr (SPLIT) asm volatile("" : "+v"(ua[set][0]), "+v"(ua[set][1]));
         else asm volatile("" : "+v"(ua[set][0]), "+v"(ua[set][1]), "+v"(ua[set][2]), "+v"(ua[set][3]));
     };
-    f32x4 bq[2][4];                     // B operands of two k-pairs, four positions per quad (PS: [tile group][quad of the half])
+    constexpr int NACC = W8 ? 8 : 16;   // 32x32 accumulators per wave
+    constexpr int NBQ = NACC / 4;
+    f32x4 bq[2][NBQ];                   // B operands of two k-pairs, four positions per quad (PS: [tile group][quad of the half])
     auto b_fetch = [&](int buf, int kpl, int set) {
 #pragma unroll
-        for (int pg = 0; pg < 4; ++pg) {
+        for (int pg = 0; pg < NBQ; ++pg) {
             const float* vimg = PS ? v_s[buf][pg >> 1] : v_s[buf][wave_g];
-            const int quad = PS ? 2 * wave_g + (pg & 1) : pg;
+            const int quad = PS ? 2 * ph + (pg & 1) : (W8 ? 2 * ph + pg : pg);
             bq[set][pg] = *reinterpret_cast<const f32x4*>(vimg + ((kpl * 4 + quad) * 64 + lane) * 4);
         }
     };
     // one wait for the rest of a B set (its first quad is awaited by the k-pair's first MFMA) instead of one per quad
-    auto b_pin = [&](int set) { asm volatile("" : "+v"(bq[set][1]), "+v"(bq[set][2]), "+v"(bq[set][3])); };
+    auto b_pin = [&](int set) {
+        if constexpr (W8) asm volatile("" : "+v"(bq[set][1]));
+        else asm volatile("" : "+v"(bq[set][1]), "+v"(bq[set][2]), "+v"(bq[set][3]));
+    };
 
-    f32x16 acc[16];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < NACC; ++p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
 
@@ -274,9 +293,11 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     if (nch > 1) dma_raw(1, 1);
     u_fill(0); u_fill(1); u_fill(2);
     __syncthreads();
-    xf_read(raw_s[0] + x_raw);
-    xf_math();
-    xf_write(&v_s[0][0][0] + x_v);
+    if (!W8 || ph == 0) {
+        xf_read(raw_s[0] + x_raw);
+        xf_math();
+        xf_write(&v_s[0][0][0] + x_v);
+    }
     __syncthreads();
     b_fetch(0, 0, 0);
 
@@ -294,25 +315,27 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     auto chunk = [&](const int c, auto more_t, auto more2_t) {
         constexpr bool MORE = decltype(more_t)::value, MORE2 = decltype(more2_t)::value;
         const int cur = c & 1;
+        const bool do_xf = !W8 || ph == ((c + 1) & 1);       // W8: the two position halves take turns with the input transform
 #pragma unroll
         for (int kpl = 0; kpl < 4; ++kpl) {
             const int kp = 4 * c + kpl;
             const int set = kpl & 1;
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
+            for (int p = 0; p < NACC; ++p) {
                 // PS: accumulator p = tile group p / 8, position 8 * half + p % 8 (U quad (p / 4) % 2 of this wave's two)
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[kpl][PS ? (p >> 2) & 1 : p >> 2][p & 3], bq[set][p >> 2][p & 3], acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[kpl][SPLIT ? (p >> 2) & 1 : p >> 2][p & 3], bq[set][p >> 2][p & 3], acc[p], 0, 0, 0);
                 if (p == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     b_pin(set);
                     if (kpl < 3) b_fetch(cur, kpl + 1, set ^ 1);
                     else if (MORE) {
-                        // own V writes done (lgkmcnt), own raw DMA landed (the 8 U loads of k-pairs 1 and 2 came after it)
-                        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        // own V writes done (lgkmcnt), own raw DMA landed (only the U loads of k-pairs 1 and 2 came after it)
+                        if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                         b_fetch(cur ^ 1, 0, 0);
                     }
                     if (MORE || kpl == 0) u_fill(kp + 3);
-                    if (MORE) {
+                    if (MORE && do_xf) {
                         if (kpl == 0) xf_read(raw_s[cur ^ 1] + x_raw);
                         if (kpl == 1) { pin(); xf_math(); pin(); }
                         if (kpl == 2) xf_write(&v_s[cur ^ 1][0][0] + x_v);
@@ -345,13 +368,15 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     // (the V images are dead by now) and finishes its own group: y = partial(rows 0,1) + partial(rows 2,3).
     float* const xbuf = &v_s[0][0][0];                         // PS: [wave][e][lane][4] floats = 4 x 16 KiB
     // (the tile group is a compile-time constant: a run-time index into the accumulators would put them in scratch)
-    auto partial_out = [&](auto grp_t, int e, float (&y)[4]) {    // PS only: this wave's two rows of tile group grp
-        constexpr int grp = decltype(grp_t)::value;
+    // W8: same exchange between SIMD partners (waves w, w + 4), split by accumulator ROW instead of tile group: the wave
+    // with position half ph finishes rows e = 8 ph .. 8 ph + 7; `e0_t` makes the row index a compile-time constant too.
+    auto partial_out = [&](auto grp_t, auto e0_t, int el, float (&y)[4]) {    // SPLIT builds: this wave's two rows of M
+        constexpr int grp = decltype(grp_t)::value, e0 = decltype(e0_t)::value;
         float t0[4], t1[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float ra = acc[grp * 8 + j][e], rb = acc[grp * 8 + 4 + j][e];      // rows 2 ph and 2 ph + 1 of M
-            if (wave_g == 0) { t0[j] = ra + rb; t1[j] = rb; }                         // rows 0, 1:  tt0 = M0 + M1, tt1 = M1
+            const float ra = acc[(grp * 8 + j) % NACC][e0 + el], rb = acc[(grp * 8 + 4 + j) % NACC][e0 + el];      // rows 2 ph and 2 ph + 1 of M
+            if (ph == 0) { t0[j] = ra + rb; t1[j] = rb; }                             // rows 0, 1:  tt0 = M0 + M1, tt1 = M1
             else { t0[j] = ra; t1[j] = -ra - rb; }                                    // rows 2, 3:  tt0 = M2, tt1 = -M2 - M3
         }
         y[0] = t0[0] + t0[1] + t0[2]; y[1] = t0[1] - t0[2] - t0[3];
@@ -362,17 +387,33 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             float y[4];
-            if (wave_g == 0) partial_out(std::integral_constant<int, 1>{}, e, y);      // the group the partner finishes
-            else partial_out(std::integral_constant<int, 0>{}, e, y);
+            if (wave_g == 0) partial_out(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, e, y);      // the group the partner finishes
+            else partial_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, e, y);
             *reinterpret_cast<float4*>(xbuf + ((wave * 16 + e) * 64 + lane) * 4) = make_float4(y[0], y[1], y[2], y[3]);
         }
         __syncthreads();
     }
-    auto out_xf = [&](int e, float& y00, float& y01, float& y10, float& y11) {
-        if constexpr (PS) {
+    if constexpr (W8) {
+#pragma unroll
+        for (int el = 0; el < 8; ++el) {                       // the rows the partner finishes
             float y[4];
-            if (wave_g == 0) partial_out(std::integral_constant<int, 0>{}, e, y);
-            else partial_out(std::integral_constant<int, 1>{}, e, y);
+            if (ph == 0) partial_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, el, y);
+            else partial_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, el, y);
+            *reinterpret_cast<float4*>(x8_s + ((wave * 8 + el) * 64 + lane) * 4) = make_float4(y[0], y[1], y[2], y[3]);
+        }
+        __syncthreads();
+    }
+    auto out_xf = [&](int e, float& y00, float& y01, float& y10, float& y11) {
+        if constexpr (W8) {                                    // e = row index WITHIN this wave's half (0..7)
+            float y[4];
+            if (ph == 0) partial_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, e, y);
+            else partial_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, e, y);
+            const float4 o = *reinterpret_cast<const float4*>(x8_s + (((wave ^ 4) * 8 + e) * 64 + lane) * 4);
+            y00 = y[0] + o.x; y01 = y[1] + o.y; y10 = y[2] + o.z; y11 = y[3] + o.w;
+        } else if constexpr (PS) {
+            float y[4];
+            if (wave_g == 0) partial_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, e, y);
+            else partial_out(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, e, y);
             const float4 o = *reinterpret_cast<const float4*>(xbuf + (((wave ^ 1) * 16 + e) * 64 + lane) * 4);
             // rows 0,1 + rows 2,3, whichever wave adds them
             y00 = y[0] + o.x; y01 = y[1] + o.y; y10 = y[2] + o.z; y11 = y[3] + o.w;
@@ -380,8 +421,8 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
             float tt[2][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                tt[0][j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
-                tt[1][j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
+                tt[0][j] = acc[j][e] + acc[4 + j][e] + acc[(8 + j) % NACC][e];
+                tt[1][j] = acc[4 + j][e] - acc[(8 + j) % NACC][e] - acc[(12 + j) % NACC][e];
             }
             y00 = tt[0][0] + tt[0][1] + tt[0][2]; y01 = tt[0][1] - tt[0][2] - tt[0][3];
             y10 = tt[1][0] + tt[1][1] + tt[1][2]; y11 = tt[1][1] - tt[1][2] - tt[1][3];
@@ -469,8 +510,10 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     const bool live = gx4 < a.W && gy < a.H;
     const int mw = mt * BM + wave_m * 32 + 4 * khalf;
     const unsigned pix = live ? (unsigned)gy * a.W + gx4 : 0u;
+    constexpr int NEB = W8 ? 2 : 4;                         // W8: this wave finishes accumulator rows 8 ph .. 8 ph + 7
 #pragma unroll
-    for (int eb = 0; eb < 4; ++eb) {
+    for (int ebl = 0; ebl < NEB; ++ebl) {
+        const int eb = W8 ? 2 * ph + ebl : ebl;
         const int mb = mw + 8 * eb;                         // rows mb .. mb+3 (e = 4 eb + 0..3)
         unsigned off[4];
         float4 mk[4], ij[4];
@@ -491,7 +534,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         }
 #pragma unroll
         for (int ee = 0; ee < 4; ++ee) {
-            const int e = 4 * eb + ee;
+            const int e = 4 * ebl + ee;                     // compile-time (W8: row within this wave's half)
             float y00, y01, y10, y11;
             out_xf(e, y00, y01, y10, y11);
             if (a.pool_out) {
@@ -544,6 +587,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_anyw(const Wi
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_anyw(const WinoKArgs a) { conv3x3_wino_body<2, 2, 0, false>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_ps64x256(const WinoKArgs a) { conv3x3_wino_body<2, 2, 0, true, true>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_ps64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1, true, true>(a); }
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_w8_128x128(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, true>(a); }
+__global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_w8_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1, true, false, true>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1>(a); }
 
@@ -580,6 +625,7 @@ int conv_wino_splits(int K, int M, int H, int W)
     if (off || !conv_wino_ok(K, M, H, W) || ((size_t)H * W) % 4 != 0) return 1;      // the combine pass works on float4
     int v = wino_default_variant(M, W);
     if (v == 3 && W % 4 != 0) v = 1;
+    if (v == 6 && W % 4 != 0) v = 0;
     const int bm = wino_variant_small(v) ? 64 : 128, prows = bm == 64 ? 8 : 4;
     const long long nblk = (long long)((W + 31) / 32) * ((H + prows - 1) / prows) * ((M + bm - 1) / bm);
     const int nch = K / WN_CH;
@@ -603,16 +649,19 @@ bool conv_wino_ok(int K, int M, int H, int W)
 
 // variant: 0 = 128 channels x 4x32 pixels, 1 = 64 channels x 8x32 pixels (tile groups split over the waves),
 // 3 = 64 channels x 8x32 pixels with the POSITIONS split over the waves (half the U stream), -1 = choose;
-// 2 / 5 / 4 = 0 / 1 / 3 with cycle stamps (diagnostic builds).
+// 6 = 128 channels x 4x32 pixels with EIGHT waves (two per SIMD, positions split between the partners);
+// 2 / 5 / 4 / 7 = 0 / 1 / 3 / 6 with cycle stamps (diagnostic builds).
 // p.wpack = the Winograd pack (pack_wino_weights_*); p.bias may be any length >= M
 static int wino_default_variant(int M, int W)
 {
     const char* fe = getenv("ST2_WINO_CFG");               // read per launch: the tests force every variant on every shape
     if (fe && *fe) return atoi(fe);
     const char* pe = getenv("ST2_WINO_PS");
-    const bool ps = !(pe && *pe == '0');
+    const bool ps = pe && *pe == '1';                      // measured (profiles/r02_c_*): no faster than variant 1 -- off unless asked for
     const int pad128 = (M + 127) / 128 * 128, pad64 = (M + 63) / 64 * 64;
     if (ps && W % 4 == 0) return 3;       // the any-width build of the position split would spill (it is not built)
+    const char* w8 = getenv("ST2_WINO_W8");                  // measured (profiles/r02_d_*): main loop 2 % slower, epilogue 25 % faster,
+    if (w8 && *w8 == '1' && W % 4 == 0 && pad128 <= pad64) return 6;   // layer times within 1 % of variant 0 -- off unless asked for
     return pad64 < pad128 ? 1 : 0;
 }
 static bool wino_variant_small(int variant) { return variant == 1 || variant == 3 || variant == 4 || variant == 5; }
@@ -624,7 +673,8 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     const bool forced_auto = variant < 0;           // split-K only on the automatic path
     if (variant < 0) variant = wino_default_variant(p.M, p.W);
     if (variant == 3 && !quad) variant = 1;
-    if (variant > 5) return hipErrorInvalidValue;
+    if (variant == 6 && !quad) variant = 0;
+    if (variant > 7) return hipErrorInvalidValue;
     const bool small = wino_variant_small(variant);
     const int bm = small ? 64 : 128, prows = small ? 8 : 4;
     WinoKArgs k{};
@@ -643,7 +693,7 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
         const int sp = conv_wino_splits(p.K, p.M, p.H, p.W);
         if (sp > 1 && p.scratch_floats >= (size_t)sp * p.M * p.H * p.W) { k.splits = sp; k.scratch = p.scratch; }
     }
-    const bool stamped = variant == 2 || variant == 4 || variant == 5;
+    const bool stamped = variant == 2 || variant == 4 || variant == 5 || variant == 7;
     if (stamped && (!quad || k.splits > 1)) return hipErrorInvalidValue;      // the stamped builds are quad-only, one pass
     if (k.splits > 1 && p.pool_out) return hipErrorInvalidValue;              // the caller asks conv_wino_can_pool() first
     const dim3 g((unsigned)(nblk * k.splits)), b(256);
@@ -653,6 +703,8 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     case 3: conv3x3_wino_f32_ps64x256<<<g, b, 0, s>>>(k); break;
     case 2: conv3x3_wino_f32_128x128_stamped<<<g, b, 0, s>>>(k); break;
     case 4: conv3x3_wino_f32_ps64x256_stamped<<<g, b, 0, s>>>(k); break;
+    case 6: conv3x3_wino_f32_w8_128x128<<<g, dim3(512), 0, s>>>(k); break;
+    case 7: conv3x3_wino_f32_w8_128x128_stamped<<<g, dim3(512), 0, s>>>(k); break;
     default: conv3x3_wino_f32_64x256_stamped<<<g, b, 0, s>>>(k); break;
     }
     hipError_t e = hipGetLastError();

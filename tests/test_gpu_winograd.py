@@ -16,10 +16,11 @@ pytestmark = pytest.mark.gpu
 F32 = np.float32
 
 
-@pytest.fixture(params=['auto', '0', '1', '3'])
+@pytest.fixture(params=['auto', '0', '1', '3', '6'])
 def wino_cfg(request):
     """ST2_WINO_CFG: 0 = 128 channels x 4x32 pixels per workgroup, 1 = 64 channels x 8x32 pixels, 3 = 64 channels x 8x32
-    pixels with the transform-domain positions split over the wave pairs (any-width shapes fall back to 1), unset = chosen by
+    pixels with the transform-domain positions split over the wave pairs (any-width shapes fall back to 1), 6 = 128 channels x
+    4x32 pixels with eight waves, two per SIMD (any-width shapes fall back to 0), unset = chosen by
     shape (which may also split K over 2-4 workgroups when the launch would leave most CUs idle)"""
     old = os.environ.get('ST2_WINO_CFG')
     if request.param == 'auto':

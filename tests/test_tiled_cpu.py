@@ -115,7 +115,7 @@ def _rank_main(rank, world, rows, cols, port, steps, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('rows,cols', [(1, 2), (2, 2)])
+@pytest.mark.parametrize('rows,cols', [(1, 2), (2, 2), (2, 4)])      # (2, 4) = the 8-rank layout of BASELINE configs[4]
 def test_tiled_adam_matches_single_process_oracle(rows, cols):
     steps, world = 3, rows * cols
     ref = single_process_reference(steps)

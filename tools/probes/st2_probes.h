@@ -11,7 +11,8 @@ extern "C" {
 const char* st_probe_last_error(void);
 /* isolated timing of the conv3x3 MFMA kernel on one layer shape (K input channels, M output channels, HxW, random
  * data).  cfg < 0: the engine's own tile choice (returned in *cfg_used); cfg >= 100: the Winograd kernel (100: its own
- * choice incl. split-K, 101: 128 ch x 4x32 px, 102: 64 ch x 8x32 px, 103 / 106: those with cycle stamps).
+ * choice incl. split-K, 101: 128 ch x 4x32 px, 102: 64 ch x 8x32 px, 104: 64 ch x 8x32 px position-split,
+ * 103 / 106 / 105: those with cycle stamps).
  * dgrad_epilogue != 0 adds the ReLU-mask + injected-diff epilogue of the backward pass. */
 int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_epilogue, int iters,
                   double* avg_ms, int* cfg_used);
