@@ -205,9 +205,13 @@ def device_eval_for_parity(job):
     loss, grad = job.opfunc()
     eng = job.engine
     signs = {}
+    from style_transfer2_amd import StError
     for layer in eng.topology[:17]:
         if layer[0] == 'conv':
-            signs[layer[1]] = np.packbits(eng.get_blob(layer[1])[0] > 0)
+            try:
+                signs[layer[1]] = np.packbits(eng.get_blob(layer[1])[0] > 0)
+            except StError:             # bf16 lean data flow: this blob exists only as a bf16 copy -- not part of the census
+                pass
     return loss, grad, signs
 
 

@@ -50,7 +50,10 @@ int st_load_conv_weights(st_ctx* ctx, const char* layer, const float* w, const f
  * 2.25x fewer multiplies, same IEEE fp32 products and sums in a different association.  0: direct kernel only. */
 int st_set_conv_algo(st_ctx* ctx, int winograd);
 /* 0 (default): fp32 throughout.  1: bf16 feature path (BASELINE config 3) -- conv operands (activations, weights,
- * backward diffs) in bf16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate; blobs, Gram, losses, optimizer stay fp32. */
+ * backward diffs) in bf16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate; Gram, losses, optimizer stay fp32.  Objective
+ * evaluations then write an fp32 blob / diff only where something reads fp32 (weighted layers, pools without a fused
+ * producer, the 3-channel first layer): st_get_blob reports the others as not materialised.  2: as 1 with every fp32 blob
+ * and diff written (same results bit for bit; the A/B reference of the tests; environment ST2_BF16_LEAN=0 forces it). */
 int st_set_precision(st_ctx* ctx, int bf16_features);
 /* CaffeModel.layers (worker.py:73-75): blob names in network order, "data" first */
 int st_num_blobs(st_ctx* ctx);

@@ -4,6 +4,11 @@
 // the convs (Gram, losses, TV, optimizer) stay fp32.  Each launch reads a bf16 channel-blocked copy of its input
 //      act16 [C/8][H][W][8]            (8 consecutive channels of one pixel = one 16-byte quad)
 // and writes the fp32 NCHW blob the rest of the engine uses plus, optionally, the bf16 copy for the next conv.
+// "Lean" launches (engine.cpp, bf16 objective evaluation) cut the HBM traffic that bounds the 64- and 128-channel layers:
+// the fp32 blob / fp32 diff is not written when its only consumer is another bf16 conv (out == nullptr), the ReLU mask
+// of the backward pass is read from the bf16 copy (mask16: 2 bytes instead of 4), and the forward epilogue can pool its
+// own output (Caffe MAX 2x2/2, ceil mode, first-max) into the bf16 copy the next conv reads plus a one-byte-per-element
+// arg-max map (bits 0-1 = window slot, bit 2 = the maximum is positive) that replaces the blob in the pool backward.
 //
 // Same pipeline as conv3x3_mfma.hip (LDS-DMA with buffer descriptors, double-buffered LDS, one barrier per chunk,
 // pinned issue order); what changes is the operand shape: K = 16 channels per MFMA, lane (l&31, l>>5) holds 8
@@ -60,7 +65,8 @@ void pack_conv_weights16_dgrad(const float* w, int Cout, int Cin, unsigned short
 
 struct Conv16KArgs {
     const unsigned short* in16; const unsigned short* wpack; const float* bias; float* out; unsigned short* out16;
-    const float* mask_src; const float* inject;
+    const float* mask_src; const float* inject; const unsigned short* mask16;
+    unsigned short* pool16; float* pool32; unsigned char* amap; int pool_h, pool_w;
     int K, M, MPad, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
     unsigned in_bytes, w_bytes;
 };
@@ -198,53 +204,67 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         }
     }
 
-    // ---- epilogue: fp32 blob (same as the fp32 kernel) + bf16 channel-blocked copy
+    // ---- epilogue: fp32 blob (same as the fp32 kernel, optional) + bf16 channel-blocked copy (optional) + fused pool (optional)
     const int gx = x0 + l31;
-    const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
+    const bool colv = gx < a.W;
+    const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr, has_mask16 = a.mask16 != nullptr;
+    const bool pooling = TN == 2 && (a.pool16 || a.pool32 || a.amap);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int gy = y0 + wave_n * TN + j;
-        if (gy >= a.H || gx >= a.W) continue;
-        const unsigned pix = (unsigned)gy * a.W + gx;
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int h = 0; h < 2; ++h) {
+            const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h;
+            float v[TN][8];
+            float bs[8];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h;
-                float v[8];
+            for (int e = 0; e < 8; ++e) bs[e] = has_bias ? a.bias[mbase + (e & 3) + 8 * (e >> 2)] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gy = y0 + wave_n * TN + j;
+                const bool live = colv && gy < a.H;
+                const unsigned pix = live ? (unsigned)gy * a.W + gx : 0u;
                 unsigned off[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int m = mbase + (e & 3) + 8 * (e >> 2);
                     off[e] = (unsigned)(m < a.M ? m : a.M - 1) * plane + pix;
-                    v[e] = acc[i][j][8 * h + e];
-                }
-                if (has_bias) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += a.bias[mbase + (e & 3) + 8 * (e >> 2)];
+                    v[j][e] = acc[i][j][8 * h + e] + bs[e];
                 }
                 if (a.relu) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : 0.0f;
+                    for (int e = 0; e < 8; ++e) v[j][e] = v[j][e] > 0.0f ? v[j][e] : 0.0f;
                 }
-                if (has_mask) {
+                if (has_mask16) {
+                    // the blob below is post-ReLU (>= 0): its bf16 copy is non-zero exactly where it is positive
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        const int mg = (mbase + 8 * g) < a.M ? mbase + 8 * g : 0;
+                        const uint2 mk = *reinterpret_cast<const uint2*>(a.mask16 + ((size_t)(mg >> 3) * plane + pix) * 8 + (mg & 7));
+                        v[j][4 * g + 0] = (mk.x & 0xffffu) ? v[j][4 * g + 0] : 0.0f;
+                        v[j][4 * g + 1] = (mk.x >> 16) ? v[j][4 * g + 1] : 0.0f;
+                        v[j][4 * g + 2] = (mk.y & 0xffffu) ? v[j][4 * g + 2] : 0.0f;
+                        v[j][4 * g + 3] = (mk.y >> 16) ? v[j][4 * g + 3] : 0.0f;
+                    }
+                } else if (has_mask) {
                     float mk[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) mk[e] = a.mask_src[off[e]];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = mk[e] > 0.0f ? v[e] : 0.0f;
+                    for (int e = 0; e < 8; ++e) v[j][e] = mk[e] > 0.0f ? v[j][e] : 0.0f;
                 }
                 if (has_inj) {
                     float ij[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ij[e] = a.inject[off[e]];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += ij[e];
+                    for (int e = 0; e < 8; ++e) v[j][e] += ij[e];
                 }
+                if (a.out && live) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[e];
-                if (a.out16) {
+                    for (int e = 0; e < 8; ++e)
+                        if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[j][e];
+                }
+                if (a.out16 && live) {
                     // rows mbase..+3 and mbase+8..+11: two groups of 4 consecutive channels -> two 8-byte stores
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
@@ -252,8 +272,55 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                         if (mg < a.M) {             // M is a multiple of 8 on this path (checked at launch)
                             bf16x4 pk;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[4 * g + e];
+                            for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[j][4 * g + e];
                             *reinterpret_cast<bf16x4*>(a.out16 + ((size_t)(mg >> 3) * plane + pix) * 8 + (mg & 7)) = pk;
+                        }
+                    }
+                }
+            }
+            if constexpr (TN == 2) {
+                if (pooling) {
+                    // Caffe MAX 2x2/2, ceil mode: this wave's two rows are one row of pooling windows (row origins are even),
+                    // lane pairs (even gx, gx + 1) are the two columns.  First maximum of a row-major scan, strictly greater
+                    // (oracle.caffe_net.maxpool_forward); windows are clipped at the right / bottom edge.
+                    const int gy0 = y0 + wave_n * 2;
+                    const bool row1 = gy0 + 1 < a.H, col1 = gx + 1 < a.W;
+                    const bool writer = !(l31 & 1) && colv && gy0 < a.H;
+                    const size_t pplane = (size_t)a.pool_h * a.pool_w;
+                    const size_t ppix = writer ? (size_t)(gy0 >> 1) * a.pool_w + (gx >> 1) : 0;
+                    float best[8];
+                    unsigned code[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[0][e]), 0xB1, 0xf, 0xf, true));
+                        const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[1][e]), 0xB1, 0xf, 0xf, true));
+                        float b = v[0][e];
+                        unsigned sl = 0;
+                        if (col1 && p0 > b) { b = p0; sl = 1; }
+                        if (row1 && v[1][e] > b) { b = v[1][e]; sl = 2; }
+                        if (row1 && col1 && p1 > b) { b = p1; sl = 3; }
+                        best[e] = b;
+                        code[e] = sl | (b > 0.0f ? 4u : 0u);
+                    }
+                    if (writer) {
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const int mg = mbase + 8 * g;
+                            if (mg >= a.M) continue;
+                            const size_t q8 = ((size_t)(mg >> 3) * pplane + ppix) * 8 + (mg & 7);
+                            if (a.pool16) {
+                                bf16x4 pk;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) pk[e] = (__bf16)best[4 * g + e];
+                                *reinterpret_cast<bf16x4*>(a.pool16 + q8) = pk;
+                            }
+                            if (a.amap)
+                                *reinterpret_cast<unsigned*>(a.amap + q8) = code[4 * g] | (code[4 * g + 1] << 8) | (code[4 * g + 2] << 16) | (code[4 * g + 3] << 24);
+                            if (a.pool32) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    if (mg + e < a.M) a.pool32[(size_t)(mg + e) * pplane + ppix] = best[4 * g + e];
+                            }
                         }
                     }
                 }
@@ -268,10 +335,8 @@ ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x256, 64, 8, 1, 4, 2)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_128x128, 128, 4, 2, 2, 1)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x128, 64, 4, 1, 4, 3)
 
-hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
+static int conv16_pick_cfg(const Conv16Problem& p)
 {
-    if (p.MPad % kCoutQuantum != 0 || p.MPad < p.M) return hipErrorInvalidValue;
-    if (p.out16 && p.M % 8 != 0) return hipErrorInvalidValue;
     const char* env = getenv("ST2_CONV16_CFG");             // forces one tile configuration (tests of every configuration)
     const int forced = env && *env ? atoi(env) : -1;
     const long long tx = (p.W + 31) / 32;
@@ -279,10 +344,27 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     if (forced >= 0) cfg = forced;
     else cfg = (tx * ((p.H + 7) / 8) * (p.MPad / 64) >= 512) ? 0 : 2;
     if (cfg == 1 && p.MPad % 128 != 0) cfg = 0;
+    return cfg;
+}
+
+// may this launch pool its own output (Conv16Problem::pool16 / pool32 / amap)?  Needs a tile configuration whose waves
+// hold two rows (0 and 1) and M % 8 == 0 (channel-blocked outputs).
+bool conv16_can_pool(const Conv16Problem& p) { return conv16_pick_cfg(p) != 2 && p.M % 8 == 0; }
+
+hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
+{
+    if (p.MPad % kCoutQuantum != 0 || p.MPad < p.M) return hipErrorInvalidValue;
+    if ((p.out16 || p.mask16) && p.M % 8 != 0) return hipErrorInvalidValue;
+    const bool pools = p.pool16 || p.pool32 || p.amap;
+    if (pools && !conv16_can_pool(p)) return hipErrorInvalidValue;
+    if (!p.out && !p.out16 && !pools) return hipErrorInvalidValue;          // nothing to write
+    const long long tx = (p.W + 31) / 32;
+    const int cfg = conv16_pick_cfg(p);
     const int BM = cfg == 1 ? 128 : 64, ROWS = cfg == 0 ? 8 : 4;
     Conv16KArgs k{};
     k.in16 = p.in16; k.wpack = p.wpack16; k.bias = p.bias; k.out = p.out; k.out16 = p.out16;
-    k.mask_src = p.mask_src; k.inject = p.inject;
+    k.mask_src = p.mask_src; k.inject = p.inject; k.mask16 = p.mask16;
+    k.pool16 = p.pool16; k.pool32 = p.pool32; k.amap = p.amap; k.pool_h = (p.H + 1) / 2; k.pool_w = (p.W + 1) / 2;
     k.K = p.K; k.M = p.M; k.MPad = p.MPad; k.H = p.H; k.W = p.W;
     k.nch = (p.K + 15) / 16;
     k.tiles_x = (int)tx; k.tiles_y = (p.H + ROWS - 1) / ROWS; k.n_mtiles = p.MPad / BM; k.relu = p.relu;
@@ -295,6 +377,44 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     if (cfg == 0) conv3x3_mfma_bf16_64x256<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else if (cfg == 1) conv3x3_mfma_bf16_128x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else conv3x3_mfma_bf16_64x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    return hipGetLastError();
+}
+
+// Max-pool backward from the arg-max map of the fused forward pool, all operands channel-blocked:
+//   dx16[cb][y][x][8] = (slot(amap[cb][y/2][x/2][j]) == 2 (y & 1) + (x & 1) and the maximum was positive) ? dy16[cb][y/2][x/2][j] : 0
+// The "positive" bit is the ReLU mask of the conv blob the pool reads (in-place ReLU: a window whose maximum is 0 passes
+// nothing on).  Routing only places values, so rounding dy to bf16 before or after it is the same.
+__global__ __launch_bounds__(256) void maxpool_bwd_idx16_k(const uint4* __restrict__ dy16, const uint2* __restrict__ amap,
+                                                           uint4* __restrict__ dx16, int CB, int H, int W)
+{
+    const int ph = (H + 1) / 2, pw = (W + 1) / 2;
+    const size_t total = (size_t)CB * H * W;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        const size_t r = idx / W;
+        const int y = (int)(r % H), cb = (int)(r / H);
+        const size_t pi = ((size_t)cb * ph + (y >> 1)) * pw + (x >> 1);
+        const uint4 d = dy16[pi];
+        const uint2 m = amap[pi];
+        const unsigned here = 2u * (y & 1) + (x & 1) + 4u;              // slot | positive
+        auto pick = [&](unsigned word, unsigned c0, unsigned c1) {
+            return ((c0 & 7u) == here ? (word & 0xffffu) : 0u) | ((c1 & 7u) == here ? (word & 0xffff0000u) : 0u);
+        };
+        uint4 o;
+        o.x = pick(d.x, m.x, m.x >> 8); o.y = pick(d.y, m.x >> 16, m.x >> 24);
+        o.z = pick(d.z, m.y, m.y >> 8); o.w = pick(d.w, m.y >> 16, m.y >> 24);
+        dx16[idx] = o;
+    }
+}
+
+hipError_t launch_maxpool_bwd_idx16(const unsigned short* dy16, const unsigned char* amap, unsigned short* dx16, int C, int H, int W, hipStream_t s)
+{
+    const int CB = (C + 7) / 8;
+    const size_t total = (size_t)CB * H * W;
+    size_t grid = (total + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    maxpool_bwd_idx16_k<<<(unsigned)grid, 256, 0, s>>>(reinterpret_cast<const uint4*>(dy16), reinterpret_cast<const uint2*>(amap),
+                                                        reinterpret_cast<uint4*>(dx16), CB, H, W);
     return hipGetLastError();
 }
 

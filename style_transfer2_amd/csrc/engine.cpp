@@ -67,6 +67,8 @@ struct ActSet {                    // activations of one forward geometry
     std::vector<int> C, h, w;
     std::vector<float*> data;      // data[0] is borrowed (the image itself)
     std::vector<unsigned short*> data16;   // bf16 channel-blocked copies of the blobs that feed a bf16 conv
+    std::vector<unsigned char*> amap;      // lean bf16 path: arg-max maps of the pools fused into the producing conv
+    std::vector<char> has32, amap_ok;      // per blob: fp32 copy / arg-max map written by the last forward
     int valid_to = -1;
 };
 
@@ -86,6 +88,7 @@ struct st_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool bf16 = false;                             // conv operands in bf16 (BASELINE config 3)
+    bool lean = false;                             // bf16 objective evaluations skip the fp32 tensors only bf16 convs would read
     bool wino = true;                              // Winograd F(2x2,3x3) for the eligible fp32 convs (ST2_WINO=0 disables)
     unsigned short *diff16A = nullptr, *diff16B = nullptr;
     std::vector<Layer> topo;
@@ -264,8 +267,10 @@ static void act_free(ActSet& a)
 {
     for (size_t i = 1; i < a.data.size(); ++i) dfree(a.data[i]);
     for (size_t i = 0; i < a.data16.size(); ++i) dfree16(a.data16[i]);
+    for (size_t i = 0; i < a.amap.size(); ++i) if (a.amap[i]) { (void)hipFree(a.amap[i]); a.amap[i] = nullptr; }
     a.data.clear();
     a.data16.clear();
+    a.amap.clear();
     a.H = a.W = 0;
     a.valid_to = -1;
 }
@@ -277,14 +282,27 @@ static int act_ensure(st_ctx* c, ActSet& a, int H, int W)
     shapes_for(c, H, W, a.C, a.h, a.w);
     a.data.assign(c->nb, nullptr);
     a.data16.assign(c->nb, nullptr);
+    a.amap.assign(c->nb, nullptr);
+    a.has32.assign(c->nb, 0);
+    a.amap_ok.assign(c->nb, 0);
     for (int i = 1; i < c->nb; ++i) ST_TRY(dmalloc(&a.data[i], (size_t)a.C[i] * a.h[i] * a.w[i]));
     a.H = H; a.W = W;
     return ST_OK;
 }
 
-static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
+static bool blob_active(const st_ctx* c, int b)
+{
+    for (const ActiveLayer& al : c->active) if (al.blob == b) return true;
+    return false;
+}
+
+// `lean` (bf16 objective evaluations only): a conv blob whose only consumers are bf16 convs / a fused pool is not written
+// in fp32 at all, and a pool that follows such a conv is computed in that conv's epilogue (bf16 pooled copy + arg-max map).
+static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean = false)
 {
     a.data[0] = const_cast<float*>(x);
+    a.has32.assign(c->nb, 0); a.amap_ok.assign(c->nb, 0);
+    a.has32[0] = 1;
     int pooled_by_conv = -1;
     for (int i = 1; i <= last; ++i) {
         const Layer& L = c->topo[i - 1];
@@ -294,12 +312,36 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
             // does the layer that consumes blob i run on the bf16 matrix cores?
             const bool next16 = c->bf16 && i < last && c->topo[i].is_conv && conv16_ok(c, L.cout);
             if (next16 && !a.data16[i]) ST_TRY(dmalloc16(&a.data16[i], act16_elems(a.C[i], (size_t)a.h[i] * a.w[i])));
+            a.has32[i] = 1;
             if (c->bf16 && conv16_ok(c, L.cin) && a.data16[i - 1]) {
                 Conv16Problem p{};
                 p.in16 = a.data16[i - 1]; p.wpack16 = L.w16_fwd; p.bias = L.bias; p.out = a.data[i];
                 p.out16 = next16 ? a.data16[i] : nullptr;
                 p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
-                ProfScope ps(c, P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, px * (2.0 * L.cin + 4.0 * L.cout));
+                double bytes = px * (2.0 * L.cin + 4.0 * L.cout + (next16 ? 2.0 * L.cout : 0.0));
+                if (lean && !blob_active(c, i) && i < last) {
+                    const bool next_pool = !c->topo[i].is_conv;
+                    if (next_pool && conv16_can_pool(p)) {
+                        // the pool rides on this launch: pooled bf16 copy for the conv after it, arg-max map for the backward
+                        const int pb = i + 1, pc = a.C[pb];
+                        const size_t phw = (size_t)a.h[pb] * a.w[pb];
+                        const bool pool_feeds16 = pb < last && c->topo[pb].is_conv && conv16_ok(c, pc);
+                        if (pool_feeds16 && !a.data16[pb]) ST_TRY(dmalloc16(&a.data16[pb], act16_elems(pc, phw)));
+                        if (!a.amap[pb]) HIP_TRY(hipMalloc((void**)&a.amap[pb], act16_elems(pc, phw)));
+                        p.pool16 = pool_feeds16 ? a.data16[pb] : nullptr;
+                        p.pool32 = (!pool_feeds16 || blob_active(c, pb) || pb == last) ? a.data[pb] : nullptr;
+                        p.amap = a.amap[pb];
+                        p.out = nullptr;
+                        a.has32[i] = 0; a.has32[pb] = p.pool32 != nullptr; a.amap_ok[pb] = 1;
+                        pooled_by_conv = pb;
+                        bytes = px * (2.0 * L.cin + 0.25 * L.cout * (1.0 + (pool_feeds16 ? 2.0 : 0.0) + (p.pool32 ? 4.0 : 0.0)));
+                    } else if (next16) {
+                        p.out = nullptr;                   // the next conv reads the bf16 copy; the backward masks with it too
+                        a.has32[i] = 0;
+                        bytes = px * (2.0 * L.cin + 2.0 * L.cout);
+                    }
+                }
+                ProfScope ps(c, P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, bytes);
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
             } else {
                 ConvProblem p{};
@@ -312,7 +354,7 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
                   if (wino) {
                       p.wpack = L.u_fwd; ST_TRY(wino_scratch(c, p));
                       // the max-pool that follows rides on this launch's epilogue (the pooled blob is written beside the conv blob)
-                      if (i < last && !c->topo[i].is_conv && !c->bf16 && conv_wino_can_pool(p.K, p.M, p.H, p.W)) { p.pool_out = a.data[i + 1]; pooled_by_conv = i + 1; }
+                      if (i < last && !c->topo[i].is_conv && !c->bf16 && conv_wino_can_pool(p.K, p.M, p.H, p.W)) { p.pool_out = a.data[i + 1]; pooled_by_conv = i + 1; a.has32[i + 1] = 1; }
                       HIP_TRY(launch_conv3x3_wino(p, c->stream));
                   }
                   else { if (next16 && L.cout % 8 == 0) { p.out16 = a.data16[i]; packed = true; }      // the epilogue writes the bf16 copy too
@@ -323,6 +365,7 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last)
             // written by the producing conv's epilogue
         } else {
             const double n_in = (double)a.C[i - 1] * a.h[i - 1] * a.w[i - 1];
+            a.has32[i] = 1;
             { ProfScope ps(c, P_POOL_FWD, 0, 4.0 * n_in * 1.25);
               HIP_TRY(launch_maxpool_fwd(a.data[i - 1], a.data[i], a.C[i - 1], a.h[i - 1], a.w[i - 1], c->stream)); }
             if (c->bf16 && i < last && c->topo[i].is_conv && conv16_ok(c, a.C[i])) {
@@ -370,21 +413,28 @@ static int gram_into(st_ctx* c, const float* F, int C, int hw, const float* targ
     return ST_OK;
 }
 
-// backward chain from blob `top` whose diff is `cur` down to data; returns pointer in *out
-static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<const float*>& inj, const float** out)
+// backward chain from blob `top` whose diff is `cur` down to data; returns pointer in *out.
+// `lean` must be what the forward that filled c->act ran with: the fp32 diff of a layer is then written only when its
+// consumer needs fp32 (a pool without arg-max map, the 3-channel conv1_1 kernel, a non-bf16 conv), ReLU masks come from the
+// bf16 copies, and pools fused into their producing conv are back-propagated through their arg-max maps in bf16.
+static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<const float*>& inj, const float** out, bool lean = false)
 {
     const ActSet& a = c->act;
     const float* cur = top_diff;
-    const unsigned short* cur16 = nullptr;             // bf16 copy of `cur`, when a producer already made it
+    const unsigned short* cur16 = nullptr;             // bf16 copy of the running diff, when a producer already made it
     if (c->bf16 && !c->diff16A) {
         const size_t cap = c->max_blob + 8 * (size_t)a.h[0] * a.w[0];
         ST_TRY(dmalloc16(&c->diff16A, cap)); ST_TRY(dmalloc16(&c->diff16B, cap));
     }
+    auto conv_takes16 = [&](int layer_index) {         // does conv layer `layer_index` (1-based blob index) run its dgrad in bf16?
+        const Layer& P = c->topo[layer_index - 1];
+        return P.is_conv && conv16_ok(c, P.cout) && !conv_dgrad_smallM_ok(P.cout, P.cin);
+    };
     for (int i = top; i >= 1; --i) {
         const Layer& L = c->topo[i - 1];
         const int below = i - 1;
         float* dst = (cur == c->diffA) ? c->diffB : c->diffA;
-        unsigned short* dst16 = (dst == c->diffA) ? c->diff16A : c->diff16B;
+        unsigned short* dst16 = (cur16 == c->diff16A) ? c->diff16B : c->diff16A;
         const bool below_is_conv = below >= 1 && c->topo[below - 1].is_conv;
         const float* mask_src = below_is_conv ? a.data[below] : nullptr;
         const float* inject = inj[below];
@@ -392,43 +442,73 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
             const double px = (double)a.h[i] * a.w[i];
             const bool small_m = !mask_src && conv_dgrad_smallM_ok(L.cout, L.cin);
             const bool wino_bwd = !small_m && !(c->bf16 && conv16_ok(c, L.cout)) && c->wino && L.u_bwd && conv_wino_ok(L.cout, L.cin, a.h[i], a.w[i]);
-            ProfScope ps(c, wino_bwd ? P_CONV_DGRAD_WINO : P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
             if (small_m) {
+                if (!cur) return fail(ST_ERR_STATE, "internal: fp32 diff missing above %s", L.name.c_str());
+                ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
                 HIP_TRY(launch_conv3x3_dgrad_smallM(cur, L.w_raw, dst, inject, L.cout, L.cin, a.h[i], a.w[i], c->stream));
-                cur16 = nullptr;
+                cur16 = nullptr; cur = dst;
             } else if (c->bf16 && conv16_ok(c, L.cout)) {
                 const size_t hw = (size_t)a.h[i] * a.w[i];
-                if (!cur16) {                                      // top diff / pool-backward output: make the bf16 copy
-                    unsigned short* tmp16 = (dst16 == c->diff16A) ? c->diff16B : c->diff16A;
+                if (!cur16) {                                      // top diff / classic pool-backward output: make the bf16 copy
+                    if (!cur) return fail(ST_ERR_STATE, "internal: no diff above %s", L.name.c_str());
+                    unsigned short* tmp16 = dst16;
+                    ProfScope ps(c, P_MISC, 0, hw * 6.0 * L.cout);
                     HIP_TRY(launch_pack_act16(cur, tmp16, L.cout, hw, c->stream));
                     cur16 = tmp16;
+                    dst16 = (cur16 == c->diff16A) ? c->diff16B : c->diff16A;
                 }
-                // the layer below consumes this launch's output as bf16 iff it is itself a bf16 dgrad conv
-                const bool below16 = below >= 1 && c->topo[below - 1].is_conv && conv16_ok(c, L.cin) &&
-                                     !conv_dgrad_smallM_ok(c->topo[below - 1].cout, c->topo[below - 1].cin);
+                // the consumer of this launch's output takes bf16 iff it is a bf16 dgrad conv, or (lean) a pool with an arg-max map
+                bool below16 = below >= 1 && conv_takes16(below);
+                if (lean && below >= 1 && !c->topo[below - 1].is_conv && a.amap_ok[below] && L.cin % 8 == 0) below16 = true;
                 Conv16Problem p{};
                 p.in16 = cur16; p.wpack16 = L.w16_bwd; p.bias = nullptr; p.out = dst; p.out16 = below16 ? dst16 : nullptr;
                 p.mask_src = mask_src; p.inject = inject;
+                if (lean && mask_src && a.data16[below]) { p.mask16 = a.data16[below]; p.mask_src = nullptr; }
+                if (p.mask_src && !a.has32[below]) return fail(ST_ERR_STATE, "internal: mask blob %d missing", below);
+                if (lean && below16) p.out = nullptr;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
+                ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px,
+                             px * (2.0 * L.cout + (p.out ? 4.0 : 0.0) * L.cin + (p.out16 ? 2.0 : 0.0) * L.cin + (mask_src ? (p.mask16 ? 2.0 : 4.0) : 0.0) * L.cin));
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
                 cur16 = below16 ? dst16 : nullptr;
+                cur = p.out ? dst : nullptr;
             } else {
+                if (!cur) return fail(ST_ERR_STATE, "internal: fp32 diff missing above %s", L.name.c_str());
                 cur16 = nullptr;
                 ConvProblem p{};
                 p.in = cur; p.wpack = L.w_bwd; p.bias = nullptr; p.out = dst;
                 p.mask_src = mask_src; p.inject = inject;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
+                ProfScope ps(c, wino_bwd ? P_CONV_DGRAD_WINO : P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
                 if (wino_bwd) { p.wpack = L.u_bwd; ST_TRY(wino_scratch(c, p)); HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
                 else HIP_TRY(launch_conv3x3(p, c->stream));
+                cur = dst;
             }
+        } else if (lean && a.amap_ok[i] && !inject && below >= 1 && conv_takes16(below)) {
+            // pool fused into its producing conv: route the bf16 diff through the arg-max map (ReLU mask of the conv blob included)
+            const int C = a.C[below];
+            const size_t hw_top = (size_t)a.h[i] * a.w[i], hw = (size_t)a.h[below] * a.w[below];
+            if (!cur16) {
+                if (!cur) return fail(ST_ERR_STATE, "internal: no diff above %s", L.name.c_str());
+                unsigned short* tmp16 = dst16;
+                ProfScope ps(c, P_MISC, 0, hw_top * 6.0 * C);
+                HIP_TRY(launch_pack_act16(cur, tmp16, C, hw_top, c->stream));
+                cur16 = tmp16;
+                dst16 = (cur16 == c->diff16A) ? c->diff16B : c->diff16A;
+            }
+            ProfScope ps(c, P_POOL_BWD, 0, (double)C * (hw_top * 3.0 + hw * 2.0));
+            HIP_TRY(launch_maxpool_bwd_idx16(cur16, a.amap[i], dst16, C, a.h[below], a.w[below], c->stream));
+            cur16 = dst16; cur = nullptr;
         } else {
+            if (!cur) return fail(ST_ERR_STATE, "internal: fp32 diff missing above %s", L.name.c_str());
+            if (!a.has32[below]) return fail(ST_ERR_STATE, "internal: pool input blob %d missing", below);
             const double n_in = (double)a.C[below] * a.h[below] * a.w[below];
             ProfScope ps(c, P_POOL_BWD, 0, 4.0 * n_in * 2.25);
             HIP_TRY(launch_maxpool_bwd(cur, a.data[below], dst, inject, mask_src != nullptr, a.C[below], a.h[below], a.w[below], c->stream));
-            cur16 = nullptr;
+            cur16 = nullptr; cur = dst;
         }
-        cur = dst;
     }
+    if (!cur) return fail(ST_ERR_STATE, "internal: the backward chain ended without an fp32 image gradient");
     *out = cur;
     return ST_OK;
 }
@@ -504,7 +584,8 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
             return fail(ST_ERR_STATE, "content features missing or of a different size than the input");
         if (al.s && !c->have_style) return fail(ST_ERR_STATE, "style Gram matrices missing");
     }
-    ST_TRY(forward_range(c, a, x, last));
+    const bool lean = c->bf16 && c->lean && !c->tile.on;
+    ST_TRY(forward_range(c, a, x, last, lean));
 
     std::vector<const float*> inj(c->nb, nullptr);
     std::fill(c->cnt.begin(), c->cnt.end(), 0);
@@ -574,7 +655,7 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
         if (last == 0) scd = inj[0];
         else {
             std::vector<const float*> below = inj;
-            ST_TRY(backward_chain(c, last, inj[last], below, &scd));
+            ST_TRY(backward_chain(c, last, inj[last], below, &scd, lean));
         }
     }
 
@@ -881,6 +962,10 @@ int st_set_precision(st_ctx* c, int bf16_features)
     if (c) c->epoch++;       // anything but st_step may change what a step launches: captured step graphs are stale
     if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
     c->bf16 = bf16_features != 0;
+    // 1: the lean data flow (objective evaluations write fp32 only where something reads fp32); 2: every fp32 blob and diff
+    // as in round 1 (A/B reference of the tests); environment ST2_BF16_LEAN=0 forces 2
+    const char* e = getenv("ST2_BF16_LEAN");
+    c->lean = bf16_features == 1 && !(e && *e == '0');
     return ST_OK;
 }
 
@@ -922,6 +1007,7 @@ int st_get_blob(st_ctx* c, int index, float* out)
 {
     if (!c || index < 0 || index >= c->nb || !out) return fail(ST_ERR_ARG, "bad argument");
     if (index > c->act.valid_to) return fail(ST_ERR_STATE, "blob %d was not computed by the last forward", index);
+    if (!c->act.has32[index]) return fail(ST_ERR_STATE, "blob %d (%s) is not materialised in fp32 by the lean bf16 evaluation (st_set_precision(ctx, 2) keeps every blob)", index, c->blob_names[index].c_str());
     const size_t n = (size_t)c->act.C[index] * c->act.h[index] * c->act.w[index];
     HIP_TRY(hipMemcpy(out, c->act.data[index], n * sizeof(float), hipMemcpyDeviceToHost));
     return ST_OK;

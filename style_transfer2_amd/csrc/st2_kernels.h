@@ -66,9 +66,18 @@ hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* d
 // ------------------------------------------------------------------------------------------
 struct Conv16Problem {
     const unsigned short* in16; const unsigned short* wpack16; const float* bias;
-    float* out; unsigned short* out16; const float* mask_src; const float* inject;
+    float* out;                             // fp32 [M][H][W]; nullptr: not written (the only consumer reads out16 / the pooled copy)
+    unsigned short* out16; const float* mask_src; const float* inject;
     int K, M, MPad, H, W, relu;
+    const unsigned short* mask16 = nullptr; // dgrad: ReLU mask from the bf16 copy of the blob below (instead of mask_src)
+    // forward, optional (conv16_can_pool): max-pool 2x2/2 (Caffe ceil mode, first-max) of this launch's output
+    unsigned short* pool16 = nullptr;       // bf16 channel-blocked pooled copy [M/8][ph][pw][8]
+    float* pool32 = nullptr;                // fp32 pooled blob [M][ph][pw]
+    unsigned char* amap = nullptr;          // [M/8][ph][pw][8] bytes: bits 0-1 arg-max slot (row-major in the window), bit 2 maximum > 0
 };
+bool conv16_can_pool(const Conv16Problem& p);
+// dx16 = pool backward of dy16 through the arg-max map (all channel-blocked, C % 8 == 0), ReLU mask of the pooled-from blob included
+hipError_t launch_maxpool_bwd_idx16(const unsigned short* dy16, const unsigned char* amap, unsigned short* dx16, int C, int H, int W, hipStream_t s);
 size_t conv16_pack_elems(int K, int M);
 void pack_conv_weights16_fwd(const float* w, int Cout, int Cin, unsigned short* dst);
 void pack_conv_weights16_dgrad(const float* w, int Cout, int Cin, unsigned short* dst);

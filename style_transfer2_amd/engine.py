@@ -57,9 +57,11 @@ class Engine:
                 d.name = name
                 d.cin, d.cout = (layer[2], layer[3]) if layer[0] == 'conv' else (0, 0)
             check(self.lib.st_create(byref(self._ctx), int(device), descs, len(self.topology)))
-        if precision not in ('fp32', 'bf16'):
-            raise ValueError('precision must be fp32 or bf16')
-        check(self.lib.st_set_precision(self._ctx, 1 if precision == 'bf16' else 0))
+        # 'bf16-full' = the bf16 feature path with every fp32 blob / diff materialised (A/B reference of the lean data flow)
+        modes = {'fp32': 0, 'bf16': 1, 'bf16-full': 2}
+        if precision not in modes:
+            raise ValueError('precision must be one of %s' % sorted(modes))
+        check(self.lib.st_set_precision(self._ctx, modes[precision]))
         n = self.lib.st_num_blobs(self._ctx)
         self.blob_names = [self.lib.st_blob_name(self._ctx, i).decode() for i in range(n)]
         self._index = {name: i for i, name in enumerate(self.blob_names)}

@@ -144,3 +144,69 @@ def test_bf16_lbfgs_trajectory_tracks_fp32_reference_vectors():
     losses = [st.step()[1]['loss'] for _ in range(20)]
     assert np.allclose(losses[:5], g['lbfgs_losses'][:5], rtol=5e-2)    # 2.7e-2 measured at the third step
     assert np.isclose(losses[-1], g['lbfgs_losses'][-1], rtol=0.15), (losses[-1], g['lbfgs_losses'][-1])
+
+
+# ------------------------------------------------------------------ the lean data flow (precision='bf16') vs 'bf16-full'
+LEAN_WEIGHTS = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
+                'deepdream': {}}
+
+
+def _bf16_job(precision, size, weights, optimizer, topo=None, params=None):
+    rs = np.random.RandomState
+    h, w = size
+    content, style, init = (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (h - 16, w, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
+    topo = topo if topo is not None else oracle.VGG19_TOPOLOGY
+    params = params if params is not None else oracle.he_init_weights(topo, seed=0)
+    st = st2.StyleTransfer(st2.HipModel(params, topology=topo, precision=precision))
+    st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+    st.set_weights(weights, {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2})
+    st.optimizer_cls = {'adam': st2.AdamOptimizer, 'lbfgs': st2.LBFGSOptimizer}[optimizer]
+    st.set_step_size({'adam': 10, 'lbfgs': 1}[optimizer])
+    st.reset()
+    assert st.start()
+    return st
+
+
+@pytest.mark.parametrize('size', [(512, 512), (160, 224), (75, 100)])
+def test_lean_bf16_data_flow_is_bit_identical_to_the_full_one(size, conv16_cfg):
+    """precision='bf16' skips the fp32 blobs / diffs that only bf16 convs would read, masks with the bf16 copies and fuses
+    the pools into the producing conv (arg-max map for the backward); 'bf16-full' writes everything as round 1 did.
+    Same arithmetic, so objective, gradient and trajectories agree bit for bit.  Tile configurations 0 and 1 pool in the
+    epilogue (forced: at every layer and size, clipped windows of the odd 75x100 included; auto: where the launch is big
+    enough, e.g. conv1_2 / conv2_2 at 512^2); configuration 2 and shapes that cannot fuse keep the separate pool kernels."""
+    if size == (512, 512) and conv16_cfg in ('1', '2'):
+        pytest.skip('one forced configuration is enough at the large size')
+    lean = _bf16_job('bf16', size, LEAN_WEIGHTS, 'adam')
+    full = _bf16_job('bf16-full', size, LEAN_WEIGHTS, 'adam')
+    l1, g1 = lean.opfunc()
+    l2, g2 = full.opfunc()
+    assert l1 == l2 and np.array_equal(g1, g2)
+    for name in ('conv1_1', 'conv3_1', 'conv5_1'):
+        assert np.array_equal(lean.engine.get_blob(name), full.engine.get_blob(name))
+    full.engine.get_blob('conv1_2')
+    if conv16_cfg in ('0', '1') or (conv16_cfg == 'auto' and size == (512, 512)):
+        with pytest.raises(st2.StError, match='not materialised'):
+            lean.engine.get_blob('conv1_2')
+    for _ in range(3):
+        i1, t1 = lean.step()
+        i2, t2 = full.step()
+        assert t1['loss'] == t2['loss'] and np.array_equal(i1, i2)
+
+
+def test_lean_bf16_with_weights_on_pools_and_pooled_convs(conv16_cfg):
+    """Losses on a pool blob and on the conv blob a pool reads (inject at the pool input: the classic pool backward
+    has to run there), deep-dream on a conv that feeds a conv: every branch of the lean bookkeeping."""
+    weights = {'content': {'conv2_2': 0.08, 'pool1': 0.2}, 'style': {'conv1_2': 1, 'conv2_1': 1, 'pool2': 0.5, 'conv3_2': 1},
+               'deepdream': {'conv3_1': 0.01}}
+    topo = oracle.VGG19_TOPOLOGY[:9]
+    params = oracle.he_init_weights(topo, seed=3)
+    lean = _bf16_job('bf16', (256, 320), weights, 'lbfgs', topo, params)
+    full = _bf16_job('bf16-full', (256, 320), weights, 'lbfgs', topo, params)
+    l1, g1 = lean.opfunc()
+    l2, g2 = full.opfunc()
+    assert l1 == l2 and np.array_equal(g1, g2)
+    for _ in range(3):
+        i1, t1 = lean.step()
+        i2, t2 = full.step()
+        assert t1['loss'] == t2['loss'] and np.array_equal(i1, i2)
