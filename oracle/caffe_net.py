@@ -228,6 +228,16 @@ class NetOracle:
             self._blobs[layer[1]] = x
         return OrderedDict((n, self._blobs[n][None]) for n in wanted)
 
+    def style_operand(self, name, f2):
+        """The features as the style-gradient GEMM S = D @ F sees them: bf16-rounded on the bf16 feature path for the
+        blobs whose gradient the engine computes on the bf16 matrix cores (conv outputs with C % 64 == 0), else as is."""
+        if self.operands != 'bf16' or f2.shape[0] % 64 != 0:
+            return f2
+        for layer in self.topology:
+            if layer[1] == name:
+                return bf16_round(f2) if layer[0] == 'conv' else f2
+        return f2
+
     def _weights16(self, name):
         if name not in self._w16:
             self._w16[name] = bf16_round(self.params[name][0])

@@ -183,7 +183,10 @@ class TransferOracle:
                 _, c, mh, mw = feat.shape
                 gd = gram(feat) - self.grams[layer]
                 f2 = feat.reshape(c, mh * mw)
-                sg = np.dot(gd, f2).reshape(1, c, mh, mw)
+                # bf16 feature path emulation (BASELINE config 3): the product D @ F takes the bf16-rounded features of a
+                # conv blob with C % 64 == 0 (the engine's style16.hip); D and everything else stay fp32
+                fop = self.model.style_operand(layer, f2) if hasattr(self.model, 'style_operand') else f2
+                sg = np.dot(gd, fop).reshape(1, c, mh, mw)
                 sg *= 2 / (gd.size * f2.size)
                 if layer not in sn:
                     sn[layer] = np.sqrt(np.mean(sg**2))

@@ -119,6 +119,7 @@ struct st_ctx {
     float *diffA = nullptr, *diffB = nullptr, *stmp = nullptr;
     size_t max_blob = 0;
     float *gram_slabs = nullptr, *gram_fold = nullptr, *dbuf = nullptr;
+    unsigned short* d16 = nullptr; size_t d16_cap = 0;            // bf16 path: hi/lo operand image of D (style16.hip)
     float* conv_scratch = nullptr; size_t conv_scratch_cap = 0;       // split-K partial sums of Winograd launches
     // hipGraph replay of the steady-state Adam step (launch-bound regime: small images)
     unsigned long long epoch = 0;                  // bumped by every API call that can change what a step launches
@@ -310,7 +311,11 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool le
             if (!L.loaded) return fail(ST_ERR_STATE, "weights of %s were never loaded", L.name.c_str());
             const double px = (double)a.h[i] * a.w[i];
             // does the layer that consumes blob i run on the bf16 matrix cores?
-            const bool next16 = c->bf16 && i < last && c->topo[i].is_conv && conv16_ok(c, L.cout);
+            bool next16 = c->bf16 && i < last && c->topo[i].is_conv && conv16_ok(c, L.cout);
+            const bool conv_next16 = next16;
+            // ... or does the style gradient of this blob (bf16 path: style16.hip reads the bf16 copy)?
+            if (c->bf16 && !c->tile.on && conv16_ok(c, L.cout) && style_grad16_ok(L.cout, (size_t)a.h[i] * a.w[i]))
+                for (const ActiveLayer& al : c->active) if (al.blob == i && al.s) next16 = true;
             if (next16 && !a.data16[i]) ST_TRY(dmalloc16(&a.data16[i], act16_elems(a.C[i], (size_t)a.h[i] * a.w[i])));
             a.has32[i] = 1;
             if (c->bf16 && conv16_ok(c, L.cin) && a.data16[i - 1]) {
@@ -335,7 +340,7 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool le
                         a.has32[i] = 0; a.has32[pb] = p.pool32 != nullptr; a.amap_ok[pb] = 1;
                         pooled_by_conv = pb;
                         bytes = px * (2.0 * L.cin + 0.25 * L.cout * (1.0 + (pool_feeds16 ? 2.0 : 0.0) + (p.pool32 ? 4.0 : 0.0)));
-                    } else if (next16) {
+                    } else if (conv_next16) {
                         p.out = nullptr;                   // the next conv reads the bf16 copy; the backward masks with it too
                         a.has32[i] = 0;
                         bytes = px * (2.0 * L.cin + 2.0 * L.cout);
@@ -629,16 +634,27 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
             }
             ST_TRY(gram_into(c, a.data[b], C, hw, c->style_gram[b], c->dbuf, conv_mpad(C), part + 4 * kMaxPartials, &cnt[4]));
             const float c2 = (float)(2.0 / ((double)C * C * (double)n));
-            const int need = style_grad_blocks(C, a.h[b], a.w[b]);
+            // bf16 path: F from its bf16 copy on the bf16 matrix cores (written by this forward: b <= last, a style layer)
+            const bool s16 = c->bf16 && !c->tile.on && a.data16[b] && b >= 1 && c->topo[b - 1].is_conv && style_grad16_ok(C, (size_t)hw);
+            const int need = s16 ? style_grad16_blocks(C, (size_t)hw) : style_grad_blocks(C, a.h[b], a.w[b]);
             if (c->s2_cap[b] < need) { dfree(c->s2_part[b]); ST_TRY(dmalloc(&c->s2_part[b], need)); c->s2_cap[b] = need; }
+            if (s16 && style_grad16_pack_elems(C) > c->d16_cap) {
+                dfree16(c->d16); c->d16_cap = 0;
+                ST_TRY(dmalloc16(&c->d16, style_grad16_pack_elems(C)));
+                c->d16_cap = style_grad16_pack_elems(C);
+            }
             const double fl = 2.0 * C * C * (double)hw;
+            auto style_launch = [&](float* dst, int fused, int accumulate) -> int {
+                ProfScope ps(c, P_STYLE_GRAD, fl, n * (s16 ? 6.0 : 8.0));
+                if (s16) HIP_TRY(launch_style_grad16(c->dbuf, conv_mpad(C), c->d16, a.data16[b], dst, c2, fused, al.sw, nrm + 1, accumulate, c->s2_part[b], &cnt[5], C, (size_t)hw, c->stream));
+                else HIP_TRY(launch_style_grad(c->dbuf, a.data[b], dst, c2, fused, al.sw, nrm + 1, accumulate, c->s2_part[b], &cnt[5], C, a.h[b], a.w[b], c->stream));
+                return ST_OK;
+            };
             if (c->norm_valid[b * 3 + 1]) {
-                ProfScope ps(c, P_STYLE_GRAD, fl, 4.0 * n * 2);
-                HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->inject[b], c2, 1, al.sw, nrm + 1, wrote, c->s2_part[b], &cnt[5], C, a.h[b], a.w[b], c->stream));
+                ST_TRY(style_launch(c->inject[b], 1, wrote));
             } else {              // first evaluation: S unscaled -> norm -> saxpy (worker.py:265-269)
                 if (!c->stmp) ST_TRY(dmalloc(&c->stmp, c->max_blob));
-                { ProfScope ps(c, P_STYLE_GRAD, fl, 4.0 * n * 2);
-                  HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->stmp, c2, 0, al.sw, nrm + 1, 0, c->s2_part[b], &cnt[5], C, a.h[b], a.w[b], c->stream)); }
+                ST_TRY(style_launch(c->stmp, 0, 0));
                 { ProfScope ps(c, P_FINALIZE, 0, 0);
                   HIP_TRY(launch_finalize_norm(c->s2_part[b], cnt[5], (double)n, nrm + 1, c->stream)); }
                 c->norm_valid[b * 3 + 1] = 1;
@@ -893,7 +909,7 @@ int st_destroy(st_ctx* c)
     for (auto& p : c->inject) dfree(p);
     for (auto& p : c->layer_part) dfree(p);
     for (auto& p : c->s2_part) dfree(p);
-    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->gram_fold); dfree(c->dbuf); dfree(c->conv_scratch);
+    dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->gram_fold); dfree(c->dbuf); dfree16(c->d16); dfree(c->conv_scratch);
     dfree(c->tile.p1); dfree(c->tile.p2); dfree(c->tile.p3); dfree(c->tile.pd); dfree(c->tile.wgrad);
     dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->lb_part); dfree(c->hwc_dev);
     if (c->lb_dev) (void)hipFree(c->lb_dev);

@@ -120,6 +120,13 @@ struct PixRoi { int y0, x0, y1, x1; };               // half-open pixel rectangl
 hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float c2, int fused, float sw, const float* norm,
                              int accumulate, float* partial, int* n_partial, int C, int H, int W, hipStream_t s,
                              const PixRoi* roi = nullptr);
+// bf16 feature path: the same S on the bf16 matrix cores, F read from its bf16 channel-blocked copy [C/8][hw][8], D split
+// on the device into hi + lo bf16 terms (A16 = scratch of style_grad16_pack_elems(C) bf16).  C % 64 == 0.
+bool style_grad16_ok(int C, size_t hw);
+size_t style_grad16_pack_elems(int C);
+int style_grad16_blocks(int C, size_t hw);
+hipError_t launch_style_grad16(const float* Dp, int ld, unsigned short* A16, const unsigned short* F16, float* dst, float c2, int fused,
+                               float sw, const float* norm, int accumulate, float* partial, int* n_partial, int C, size_t hw, hipStream_t s);
 // out[0] = sum(part[0..n)) in double, rounded to float (deterministic, one workgroup)
 hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t s);
 // inject = (sw / *norm) * S + (accumulate ? inject : 0)

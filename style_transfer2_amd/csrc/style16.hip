@@ -1,0 +1,218 @@
+// Style gradient of the bf16 feature path (BASELINE config 3) on the bf16 matrix cores:
+//     S = c2 * (D @ F)         D = G - G_style (C x C, fp32, symmetric), F = the blob [C][hw]        worker.py:262-269
+// F is read from the bf16 channel-blocked copy [C/8][hw][8] the forward pass already wrote for the next conv: the
+// contraction runs over CHANNELS, and a 16-byte quad of that copy is exactly the B fragment of v_mfma_f32_32x32x16_bf16
+// (8 consecutive k for one pixel).  D keeps fp32 accuracy: it is split on the device into D = hi + lo (two bf16 terms,
+// residual 2^-17) and both halves are multiplied with the same B fragment into one accumulator.  Output, scaling, the
+// fused saxpy into the layer diff and the per-block sum of S^2 are fp32, as in style_grad_mfma_f32_* (conv3x3_mfma.hip).
+// Bound: HBM for C <= 128 (2 + 4 bytes per element), the CU's vector-memory ingest for C >= 256 (F is re-read once per
+// 128-channel output tile, D once per 128-pixel tile, both from L2).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "reduce.cuh"
+#include "st2_kernels.h"
+
+namespace st2 {
+
+typedef float s16_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 s16_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* s16_lptr_t;
+
+constexpr int S16_PX = 128;          // pixels per workgroup (4 waves x 32)
+constexpr int S16_KC = 64;           // channels per staged chunk (4 MFMA k-steps)
+
+// A operand image of D for the whole layer: quad[((ks * 2 + hl) * 2 + half) * Mp + m] = 8 bf16 of row m, channels
+// 16 ks + 8 half .. + 7; hl = 0: hi = bf16(D), hl = 1: lo = bf16(D - hi).  Mp = C rounded up to 64.
+__global__ __launch_bounds__(256) void style16_pack_d_k(const float* __restrict__ D, int ld, int C, int Mp, unsigned short* __restrict__ A16)
+{
+    const int nq = (C / 16) * 2 * 2 * Mp;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256) {
+        const int m = q % Mp;
+        const int r = q / Mp;
+        const int half = r & 1, hl = (r >> 1) & 1, ks = r >> 2;
+        s16_bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * half + j;
+            const float d = m < C ? D[(size_t)m * ld + k] : 0.0f;
+            const __bf16 hi = (__bf16)d;
+            v[j] = hl ? (__bf16)(d - (float)hi) : hi;
+        }
+        *reinterpret_cast<s16_bf16x8*>(A16 + (size_t)q * 8) = v;
+    }
+}
+
+struct Style16Args {
+    const unsigned short* A16; const unsigned short* F16; float* out; const float* norm; float* partial;
+    float c2, sw; int fused, accumulate;
+    int C, Mp, n_mtiles; unsigned hw, a_bytes, f_bytes;
+};
+
+template <int BM>
+__device__ __forceinline__ void style_grad16_body(const Style16Args& a)
+{
+    constexpr int TM = BM / 32;
+    constexpr int AQ = 4 * 2 * 2 * BM;               // quads of the A slab of one chunk: [ks 4][hl 2][half 2][BM]
+    constexpr int BQ = 4 * 2 * S16_PX;               // quads of the B tile of one chunk: [ks 4][half 2][128 px]
+    constexpr int A_PW = AQ / 256, B_PW = BQ / 256;  // 1-KiB DMA pieces per wave
+    // ONE chunk buffer (48 / 32 KiB): the K loop is 1-8 chunks long, so the overlap of staging and MFMA comes from the
+    // 3-5 workgroups a CU holds, not from double-buffering inside one; the same memory stages the output rows afterwards
+    __shared__ __attribute__((aligned(16))) uint4 smem[AQ + BQ];
+    __shared__ float red[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = blockIdx.x % a.n_mtiles, pt = blockIdx.x / a.n_mtiles;        // the M tiles of one pixel tile run together (L2 reuse of F)
+    const int m0 = mt * BM;
+    const unsigned p0 = (unsigned)pt * S16_PX;
+    const int nch = a.C / S16_KC;
+
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.A16, 0, a.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc((void*)a.F16, 0, a.f_bytes, 0x00020000);
+    unsigned aoff[A_PW], boff[B_PW];
+#pragma unroll
+    for (int t = 0; t < A_PW; ++t) {
+        const int q = (wave + 4 * t) * 64 + lane;                   // [ks][hl][half][m]
+        const int m = q % BM, r = q / BM;                           // r = (ks * 2 + hl) * 2 + half
+        aoff[t] = ((unsigned)r * a.Mp + m0 + m) * 16u;
+    }
+#pragma unroll
+    for (int t = 0; t < B_PW; ++t) {
+        const int q = (wave + 4 * t) * 64 + lane;                   // [ks][half][px]
+        const int px = q % S16_PX, r = q / S16_PX;                  // r = ks * 2 + half = channel block within the chunk
+        boff[t] = p0 + px < a.hw ? ((unsigned)r * a.hw + p0 + px) * 16u : 0xffffffffu;
+    }
+
+    s16_f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.0f;
+
+    for (int ch = 0; ch < nch; ++ch) {
+        if (ch) __syncthreads();                                    // every wave is done with the previous chunk
+        const unsigned ca = (unsigned)ch * 16u * a.Mp * 16u;        // 4 k-steps x 2 x 2 rows of Mp quads
+        const unsigned cb = (unsigned)ch * 8u * a.hw * 16u;         // 8 channel blocks
+#pragma unroll
+        for (int t = 0; t < A_PW; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (s16_lptr_t)(smem + (wave + 4 * t) * 64), 16, aoff[t] + ca, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < B_PW; ++t)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_f, (s16_lptr_t)(smem + AQ + (wave + 4 * t) * 64), 16,
+                                                     boff[t] == 0xffffffffu ? boff[t] : boff[t] + cb, 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const uint4* A = smem;
+        const uint4* B = smem + AQ;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const s16_bf16x8 b = __builtin_bit_cast(s16_bf16x8, B[(ks * 2 + khalf) * S16_PX + wave * 32 + l31]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const s16_bf16x8 hi = __builtin_bit_cast(s16_bf16x8, A[((ks * 2 + 0) * 2 + khalf) * BM + i * 32 + l31]);
+                const s16_bf16x8 lo = __builtin_bit_cast(s16_bf16x8, A[((ks * 2 + 1) * 2 + khalf) * BM + i * 32 + l31]);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, b, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, b, acc[i], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue (C/D map: column = lane & 31 = pixel, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5))
+    const unsigned p = p0 + wave * 32 + l31;
+    const bool live = p < a.hw;
+    const float coef = a.fused ? a.sw / *a.norm : 0.0f;
+    float ss = 0.0f;
+    if ((a.hw & 3u) == 0) {
+        // Rows of 128 pixels through LDS: a lane-per-pixel store is 4 bytes per lane and channel (64 store instructions per
+        // wave, issue-bound); staged, every lane stores 16 bytes of one channel row (4x fewer instructions, whole lines).
+        float* stage = reinterpret_cast<float*>(smem);              // [64 channels][128 pixels]
+#pragma unroll
+        for (int half = 0; half < BM / 64; ++half) {
+            __syncthreads();                                        // the operand chunk / the previous half is consumed
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = 2 * half + ii;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ml = ii * 32 + (e & 3) + 8 * ((e >> 2) & 1) + 4 * khalf + 16 * (e >> 3);     // channel within this half
+                    const float v = live && m0 + 64 * half + ml < a.C ? acc[i][e] * a.c2 : 0.0f;
+                    ss += v * v;
+                    stage[ml * S16_PX + wave * 32 + l31] = a.fused ? coef * v : v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int idx = t * 256 + tid, row = idx >> 5, c4 = (idx & 31) * 4;
+                const int m = m0 + 64 * half + row;
+                if (m < a.C && p0 + c4 < a.hw) {
+                    float4 v = *reinterpret_cast<const float4*>(stage + row * S16_PX + c4);
+                    float* dst = a.out + (size_t)m * a.hw + p0 + c4;
+                    if (a.fused && a.accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *reinterpret_cast<float4*>(dst) = v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int mbase = m0 + i * 32 + 4 * khalf + 16 * h;
+                float v[8], old[8];
+                unsigned off[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int m = mbase + (e & 3) + 8 * (e >> 2);
+                    off[e] = (unsigned)(m < a.C ? m : a.C - 1) * a.hw + (live ? p : 0u);
+                    v[e] = live && m < a.C ? acc[i][8 * h + e] * a.c2 : 0.0f;
+                    ss += v[e] * v[e];
+                }
+                if (a.fused && a.accumulate) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) old[e] = a.out[off[e]];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float r2 = a.fused ? coef * v[e] + (a.accumulate ? old[e] : 0.0f) : v[e];
+                    if (live && mbase + (e & 3) + 8 * (e >> 2) < a.C) a.out[off[e]] = r2;
+                }
+            }
+    }
+    float sv[1] = {ss};
+    block_sum(sv, red);
+    if (tid == 0) a.partial[blockIdx.x] = sv[0];
+}
+
+// non-template entry points (a template kernel with a launch bound loses its host stub with this toolchain)
+__global__ __launch_bounds__(256) void style_grad16_128(const Style16Args a) { style_grad16_body<128>(a); }
+__global__ __launch_bounds__(256) void style_grad16_64(const Style16Args a) { style_grad16_body<64>(a); }
+
+bool style_grad16_ok(int C, size_t hw)
+{
+    return C >= 64 && C % 64 == 0 && hw > 0 && 16ull * (C / 8) * hw < 0xfffffff0ull && 4ull * C * hw < 0xfffffff0ull;
+}
+static int style16_bm(int C) { return C >= 128 ? 128 : 64; }
+size_t style_grad16_pack_elems(int C) { return (size_t)(C / 16) * 4 * ((C + 127) / 128 * 128) * 8; }
+int style_grad16_blocks(int C, size_t hw) { return (int)((hw + S16_PX - 1) / S16_PX) * ((C + style16_bm(C) - 1) / style16_bm(C)); }
+
+hipError_t launch_style_grad16(const float* Dp, int ld, unsigned short* A16, const unsigned short* F16, float* dst, float c2, int fused,
+                               float sw, const float* norm, int accumulate, float* partial, int* n_partial, int C, size_t hw, hipStream_t s)
+{
+    if (!style_grad16_ok(C, hw)) return hipErrorInvalidValue;
+    const int bm = style16_bm(C), Mp = (C + 127) / 128 * 128;
+    const int nq = (C / 16) * 4 * Mp;
+    style16_pack_d_k<<<(nq + 255) / 256, 256, 0, s>>>(Dp, ld, C, Mp, A16);
+    Style16Args a{};
+    a.A16 = A16; a.F16 = F16; a.out = dst; a.norm = norm; a.partial = partial;
+    a.c2 = c2; a.sw = sw; a.fused = fused; a.accumulate = accumulate;
+    a.C = C; a.Mp = Mp; a.n_mtiles = (C + bm - 1) / bm; a.hw = (unsigned)hw;
+    a.a_bytes = (unsigned)(style_grad16_pack_elems(C) * 2); a.f_bytes = (unsigned)(16ull * (C / 8) * hw);
+    const int grid = style_grad16_blocks(C, hw);
+    if (n_partial) *n_partial = grid;
+    if (bm == 128) style_grad16_128<<<grid, 256, 0, s>>>(a);
+    else style_grad16_64<<<grid, 256, 0, s>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace st2

@@ -210,3 +210,40 @@ def test_lean_bf16_with_weights_on_pools_and_pooled_convs(conv16_cfg):
         i1, t1 = lean.step()
         i2, t2 = full.step()
         assert t1['loss'] == t2['loss'] and np.array_equal(i1, i2)
+
+
+# ------------------------------------------------------------------ style gradient on the bf16 matrix cores (style16.hip)
+@pytest.mark.parametrize('C,h,w', [(64, 64, 96), (64, 50, 70), (128, 64, 64), (128, 37, 50), (256, 32, 48), (512, 24, 40), (192, 20, 28)])
+def test_style_gradient_on_the_bf16_matrix_cores_matches_rounded_operand_oracle(C, h, w):
+    """One conv (3 -> C, fp32 kernel on both sides, so the blob agrees to 1e-7) carrying a style and a content term:
+    S = c2 (D @ bf16(F)) with D split into hi + lo bf16 terms on the device, against the oracle's fp32 D @ bf16(F).
+    Both tile heights (64 / 128 channels), several channel chunks, pixel counts that are not multiples of 128."""
+    topo = (('conv', 'conv1_1', 3, C),)
+    params = oracle.he_init_weights(topo, seed=C, bias_std=0.2)
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (h + 6, w - 4, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
+    weights = {'content': {'conv1_1': 0.3}, 'style': {'conv1_1': 1.0}, 'deepdream': {}}
+    p4 = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+    cpu = oracle.TransferOracle(oracle.NetOracle(topo, params, operands='bf16'))
+    dev = st2.StyleTransfer(st2.HipModel(params, topology=topo, precision='bf16'))
+    for st in (cpu, dev):
+        st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+        st.set_weights(weights, p4)
+    for ev in (1, 2):                      # first evaluation: S unscaled -> norm -> saxpy; second: fused, accumulating
+        lo, go = cpu.opfunc(cpu.input if ev == 1 else x2)
+        ld, gd = dev.opfunc(None if ev == 1 else x2)
+        tc, td = cpu.traces[-1].data, dev.traces[-1].data
+        assert np.isclose(td['conv1_1_s_loss'], tc['conv1_1_s_loss'], rtol=2e-5), ev
+        assert np.isclose(td['conv1_1_s_grad'], tc['conv1_1_s_grad'], rtol=2e-5), ev
+        assert np.isclose(ld, lo, rtol=2e-5) and rel_l2(gd, go) <= 2e-5, (ev, rel_l2(gd, go))
+        if ev == 1:
+            g_first = gd.copy()
+        x2 = cpu.input + F32(2.0) * np.sign(go)
+    # the bf16 kernel really ran: the fp32-operand product differs at the bf16 level when C % 64 == 0
+    if C % 64 == 0:
+        ref32 = oracle.TransferOracle(oracle.NetOracle(topo, params))
+        ref32.set_input(init); ref32.set_content(content); ref32.set_style(style); ref32.reset()
+        ref32.set_weights(weights, p4)
+        _, g32 = ref32.opfunc(ref32.input)
+        assert 1e-5 < rel_l2(g_first, g32) < 5e-2
