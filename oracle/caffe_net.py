@@ -171,8 +171,9 @@ class NetOracle:
         # deepest requested blob: identical results, used only to time a leaner CPU baseline.
         self.full_forward = full_forward
         # operands='bf16': emulate the bf16 feature path -- a conv whose reduction depth (input channels forward,
-        # output channels backward) is a multiple of 8 sees its activation/diff and weight operands rounded to
-        # bf16; everything else (bias, ReLU, pooling, accumulation, the blobs themselves) stays fp32.
+        # output channels backward, the 3-channel first layer's data gradient included) is a multiple of 8 sees its
+        # activation/diff and weight operands rounded to bf16; everything else (bias, ReLU, pooling, accumulation,
+        # the blobs themselves) stays fp32.
         assert operands in ('fp32', 'bf16')
         self.operands = operands
         self._w16 = {}
@@ -285,7 +286,7 @@ class NetOracle:
                 inj = np.asarray(diffs[name], F32)[0]
                 g = inj.copy() if g is None else g + inj
             if layer[0] == 'conv':
-                if self.operands == 'bf16' and layer[3] % 8 == 0 and layer[2] > 4:
+                if self.operands == 'bf16' and layer[3] % 8 == 0:
                     g = conv3x3_backward_data(bf16_round(g), self._weights16(name))
                 else:
                     g = conv3x3_backward_data(g, self.params[name][0])

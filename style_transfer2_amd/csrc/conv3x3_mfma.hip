@@ -611,7 +611,108 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_smallM(const float* __restr
         }
 }
 
+// bf16 feature path: the same data gradient with dy read from the bf16 channel-blocked copy [Cout/8][H][W][8] the bf16
+// dgrad above wrote (no fp32 diff exists then); w holds bf16-representable values (rounded on the host); products and sums
+// stay fp32.  A chunk is one channel block: every thread fetches whole 16-byte quads (8 channels of one pixel) into
+// registers while the previous chunk is consumed from LDS, then unpacks them into the fp32 tile [8][TH][TW].
+template <int M>
+__global__ __launch_bounds__(256) void conv3x3_dgrad_smallM16(const uint4* __restrict__ dy16, const float* __restrict__ w,
+                                                              float* __restrict__ dx, const float* __restrict__ inject,
+                                                              int Cout, int H, int W)
+{
+    constexpr int TW = SM_TX + 2, TH = SM_TY + 2, CH = 8;
+    constexpr int NPIX = TH * TW, PER_T = (NPIX + 255) / 256;
+    __shared__ float t_s[CH * NPIX];
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * SM_TX, y0 = blockIdx.y * SM_TY;
+    const int lx = (tid & 31) * SM_PX, ly = tid >> 5;
+    const size_t plane = (size_t)H * W;
+    float acc[SM_PX][M];
+#pragma unroll
+    for (int q = 0; q < SM_PX; ++q)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[q][m] = 0.f;
+    int toff[PER_T];                          // halo-tile pixel -> offset inside one channel-block plane (or -1)
+#pragma unroll
+    for (int i = 0; i < PER_T; ++i) {
+        const int e = tid + i * 256;
+        const int rr = e / TW, col = e % TW;
+        const int gy = y0 - 1 + rr, gx = x0 - 1 + col;
+        toff[i] = (e < NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+    }
+    uint4 stage[PER_T];
+    auto load = [&](int cb) {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) stage[i] = toff[i] >= 0 ? dy16[(size_t)cb * plane + toff[i]] : make_uint4(0, 0, 0, 0);
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int e = tid + i * 256;
+            if (e < NPIX) {
+                const unsigned wv[4] = {stage[i].x, stage[i].y, stage[i].z, stage[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    t_s[(2 * j) * NPIX + e] = __builtin_bit_cast(float, wv[j] << 16);
+                    t_s[(2 * j + 1) * NPIX + e] = __builtin_bit_cast(float, wv[j] & 0xffff0000u);
+                }
+            }
+        }
+    };
+    const int ncb = Cout / CH;
+    load(0);
+    for (int cb = 0; cb < ncb; ++cb) {
+        if (cb) __syncthreads();                 // the previous chunk is consumed
+        store();
+        __syncthreads();
+        if (cb + 1 < ncb) load(cb + 1);          // in flight while this chunk is consumed
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const float* wc = w + (size_t)(cb * CH + c) * M * 9;      // uniform -> s_load
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                float g[SM_PX + 2];
+#pragma unroll
+                for (int j = 0; j < SM_PX + 2; ++j) g[j] = t_s[c * NPIX + (ly + 2 - ky) * TW + lx + j];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int q = 0; q < SM_PX; ++q)
+#pragma unroll
+                        for (int m = 0; m < M; ++m) acc[q][m] += wc[m * 9 + ky * 3 + kx] * g[q + 2 - kx];
+            }
+        }
+    }
+    const int gy = y0 + ly;
+    if (gy < H)
+#pragma unroll
+        for (int q = 0; q < SM_PX; ++q) {
+            const int gx = x0 + lx + q;
+            if (gx >= W) continue;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const size_t idx = (size_t)m * plane + (size_t)gy * W + gx;
+                dx[idx] = acc[q][m] + (inject ? inject[idx] : 0.f);
+            }
+        }
+}
+
 bool conv_dgrad_smallM_ok(int Cout, int Cin) { (void)Cout; return Cin >= 1 && Cin <= SM_MAXM; }
+
+hipError_t launch_conv3x3_dgrad_smallM16(const unsigned short* dy16, const float* w_rounded, float* dx, const float* inject,
+                                         int Cout, int Cin, int H, int W, hipStream_t s)
+{
+    if (!conv_dgrad_smallM_ok(Cout, Cin) || Cout % 8 != 0) return hipErrorInvalidValue;
+    dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
+    const uint4* q16 = reinterpret_cast<const uint4*>(dy16);
+    switch (Cin) {
+    case 1: conv3x3_dgrad_smallM16<1><<<grid, dim3(256), 0, s>>>(q16, w_rounded, dx, inject, Cout, H, W); break;
+    case 2: conv3x3_dgrad_smallM16<2><<<grid, dim3(256), 0, s>>>(q16, w_rounded, dx, inject, Cout, H, W); break;
+    case 3: conv3x3_dgrad_smallM16<3><<<grid, dim3(256), 0, s>>>(q16, w_rounded, dx, inject, Cout, H, W); break;
+    default: conv3x3_dgrad_smallM16<4><<<grid, dim3(256), 0, s>>>(q16, w_rounded, dx, inject, Cout, H, W); break;
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
                                        int Cout, int Cin, int H, int W, hipStream_t s)

@@ -56,7 +56,7 @@ struct Layer {
     bool is_conv = false;
     std::string name;
     int cin = 0, cout = 0;
-    float *w_fwd = nullptr, *w_bwd = nullptr, *w_raw = nullptr, *bias = nullptr;
+    float *w_fwd = nullptr, *w_bwd = nullptr, *w_raw = nullptr, *w_raw_r = nullptr, *bias = nullptr;   // w_raw_r: w_raw rounded to bf16 values
     unsigned short *w16_fwd = nullptr, *w16_bwd = nullptr;       // bf16 packs (bf16 feature path)
     float *u_fwd = nullptr, *u_bwd = nullptr;                    // Winograd F(2x2,3x3) packs (null: not eligible)
     bool loaded = false;
@@ -431,9 +431,11 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
         const size_t cap = c->max_blob + 8 * (size_t)a.h[0] * a.w[0];
         ST_TRY(dmalloc16(&c->diff16A, cap)); ST_TRY(dmalloc16(&c->diff16B, cap));
     }
-    auto conv_takes16 = [&](int layer_index) {         // does conv layer `layer_index` (1-based blob index) run its dgrad in bf16?
+    auto conv_takes16 = [&](int layer_index) {         // does conv layer `layer_index` (1-based blob index) read its diff as bf16?
         const Layer& P = c->topo[layer_index - 1];
-        return P.is_conv && conv16_ok(c, P.cout) && !conv_dgrad_smallM_ok(P.cout, P.cin);
+        if (!P.is_conv || !conv16_ok(c, P.cout)) return false;
+        const bool first_small = conv_dgrad_smallM_ok(P.cout, P.cin) && !(layer_index - 1 >= 1 && c->topo[layer_index - 2].is_conv);
+        return !conv_dgrad_smallM_ok(P.cout, P.cin) || (first_small && P.w_raw_r != nullptr);
     };
     for (int i = top; i >= 1; --i) {
         const Layer& L = c->topo[i - 1];
@@ -447,7 +449,19 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
             const double px = (double)a.h[i] * a.w[i];
             const bool small_m = !mask_src && conv_dgrad_smallM_ok(L.cout, L.cin);
             const bool wino_bwd = !small_m && !(c->bf16 && conv16_ok(c, L.cout)) && c->wino && L.u_bwd && conv_wino_ok(L.cout, L.cin, a.h[i], a.w[i]);
-            if (small_m) {
+            if (small_m && c->bf16 && L.w_raw_r) {
+                // bf16 feature path: this conv's operands are bf16 too -- the diff arrives as (or is packed into) a bf16 copy
+                const size_t hw = (size_t)a.h[i] * a.w[i];
+                if (!cur16) {
+                    if (!cur) return fail(ST_ERR_STATE, "internal: no diff above %s", L.name.c_str());
+                    ProfScope ps(c, P_MISC, 0, hw * 6.0 * L.cout);
+                    HIP_TRY(launch_pack_act16(cur, dst16, L.cout, hw, c->stream));
+                    cur16 = dst16;
+                }
+                ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, px * (2.0 * L.cout + 4.0 * L.cin));
+                HIP_TRY(launch_conv3x3_dgrad_smallM16(cur16, L.w_raw_r, dst, inject, L.cout, L.cin, a.h[i], a.w[i], c->stream));
+                cur16 = nullptr; cur = dst;
+            } else if (small_m) {
                 if (!cur) return fail(ST_ERR_STATE, "internal: fp32 diff missing above %s", L.name.c_str());
                 ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
                 HIP_TRY(launch_conv3x3_dgrad_smallM(cur, L.w_raw, dst, inject, L.cout, L.cin, a.h[i], a.w[i], c->stream));
@@ -896,7 +910,7 @@ int st_destroy(st_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 2; ++i) if (c->gexec[i]) { (void)hipGraphExecDestroy(c->gexec[i]); c->gexec[i] = nullptr; }
     dfree(c->adam_dyn);
-    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree(L.u_fwd); dfree(L.u_bwd); }
+    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree(L.u_fwd); dfree(L.u_bwd); }
     dfree16(c->diff16A); dfree16(c->diff16B);
     act_free(c->act);
     for (int i = 0; i < 2; ++i) dfree(c->x[i]);
@@ -934,7 +948,7 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
         pack_conv_weights_fwd(w, L.cout, L.cin, pf.data());
         pack_conv_weights_dgrad(w, L.cout, L.cin, pb.data());
         if (bias) memcpy(bp.data(), bias, L.cout * sizeof(float));
-        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree(L.u_fwd); dfree(L.u_bwd);
+        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree(L.u_fwd); dfree(L.u_bwd);
         for (int dir = 0; dir < 2; ++dir) {   // Winograd packs for the directions the Winograd kernel can take (any image size)
             const int K = dir ? L.cout : L.cin, M = dir ? L.cin : L.cout;
             if (!conv_wino_ok(K, M, 4, 4)) continue;
@@ -958,6 +972,16 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
         HIP_TRY(hipMemcpy(L.w_fwd, pf.data(), nf * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(L.w_bwd, pb.data(), nb * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(L.w_raw, w, (size_t)L.cout * L.cin * 9 * sizeof(float), hipMemcpyHostToDevice));
+        if (conv_dgrad_smallM_ok(L.cout, L.cin) && L.cout % 8 == 0) {       // bf16 path: the first layer's dgrad multiplies bf16 operands
+            std::vector<float> wr((size_t)L.cout * L.cin * 9);
+            for (size_t k = 0; k < wr.size(); ++k) {
+                unsigned u; memcpy(&u, &w[k], 4);
+                u = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;          // round to nearest even (weights are finite)
+                memcpy(&wr[k], &u, 4);
+            }
+            ST_TRY(dmalloc(&L.w_raw_r, wr.size()));
+            HIP_TRY(hipMemcpy(L.w_raw_r, wr.data(), wr.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
         HIP_TRY(hipMemcpy(L.bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
         L.loaded = true;
         return ST_OK;

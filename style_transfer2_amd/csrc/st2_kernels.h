@@ -58,6 +58,9 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
 bool conv_dgrad_smallM_ok(int Cout, int Cin);
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
                                        int Cout, int Cin, int H, int W, hipStream_t s);
+// bf16 feature path: dy as bf16 channel-blocked copy [Cout/8][H][W][8] (Cout % 8 == 0), weights already rounded to bf16 values
+hipError_t launch_conv3x3_dgrad_smallM16(const unsigned short* dy16, const float* w_rounded, float* dx, const float* inject,
+                                         int Cout, int Cin, int H, int W, hipStream_t s);
 
 // ------------------------------------------------------------------------------------------
 // bf16 feature path (BASELINE config 3): conv operands in bf16 (v_mfma_f32_32x32x16_bf16), fp32 accumulate and

@@ -236,7 +236,9 @@ def test_style_gradient_on_the_bf16_matrix_cores_matches_rounded_operand_oracle(
         tc, td = cpu.traces[-1].data, dev.traces[-1].data
         assert np.isclose(td['conv1_1_s_loss'], tc['conv1_1_s_loss'], rtol=2e-5), ev
         assert np.isclose(td['conv1_1_s_grad'], tc['conv1_1_s_grad'], rtol=2e-5), ev
-        assert np.isclose(ld, lo, rtol=2e-5) and rel_l2(gd, go) <= 2e-5, (ev, rel_l2(gd, go))
+        # the image gradient passes through conv1_1's data gradient, whose diff operand is rounded to bf16 on both sides: a 1e-7
+        # difference moves a few elements across a rounding boundary (2^-9 each), hence the looser bar than on the style terms above
+        assert np.isclose(ld, lo, rtol=2e-5) and rel_l2(gd, go) <= 1e-4, (ev, rel_l2(gd, go))
         if ev == 1:
             g_first = gd.copy()
         x2 = cpu.input + F32(2.0) * np.sign(go)

@@ -127,7 +127,10 @@ def test_production_conv_shapes_bf16_at_2048(name, K, M, edge, pooled):
     diffs = {n: rng.randn(*fg[n].shape).astype(F32) for n in names}
     berr = rel_l2(gpu.backward(diffs), cpu.backward(diffs))
     report('bf16 layer %s K%d M%d %dpx' % (name, K, M, edge), {'forward_rel_l2': ferr, 'backward_rel_l2': berr})
-    assert berr <= 5e-6, berr                   # measured 4.7e-7 .. 1.3e-6
+    # the chain ends in conv_a's data gradient, whose diff operand is rounded to bf16 on both sides: the 1e-6 difference of
+    # conv_b's output moves ~2.5e-4 of the elements across a rounding boundary (2^-9 each) -> ~2e-5 (4.7e-7 .. 1.3e-6 before
+    # the first layer's dgrad took bf16 operands)
+    assert berr <= 5e-5, berr
 
 
 # ------------------------------------------------------------------------------ 2 + 3. whole objective, configs[1]
