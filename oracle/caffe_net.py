@@ -239,6 +239,17 @@ class NetOracle:
                 return bf16_round(f2) if layer[0] == 'conv' else f2
         return f2
 
+    def gram_operand(self, name, feat):
+        """The features (1, C, h, w) as the per-iteration Gram GEMM sees them on the bf16 feature path: bf16-rounded for conv
+        blobs with C % 64 == 0 and h w % 64 == 0 (the engine's gram16.hip conditions), else as is."""
+        _, c, h, w = feat.shape
+        if self.operands != 'bf16' or c % 64 != 0 or (h * w) % 64 != 0:
+            return feat
+        for layer in self.topology:
+            if layer[1] == name:
+                return bf16_round(feat) if layer[0] == 'conv' else feat
+        return feat
+
     def _weights16(self, name):
         if name not in self._w16:
             self._w16[name] = bf16_round(self.params[name][0])

@@ -181,7 +181,10 @@ class TransferOracle:
 
             if abs(sw) > EPS_W:                                   # worker.py:258-269
                 _, c, mh, mw = feat.shape
-                gd = gram(feat) - self.grams[layer]
+                # bf16 feature path emulation: the Gram of the CURRENT features is the fp32-accumulated product of their
+                # bf16-rounded values where the engine takes it from the bf16 copy (gram16.hip); the style targets stay fp32
+                gop = self.model.gram_operand(layer, feat) if hasattr(self.model, 'gram_operand') else feat
+                gd = gram(gop) - self.grams[layer]
                 f2 = feat.reshape(c, mh * mw)
                 # bf16 feature path emulation (BASELINE config 3): the product D @ F takes the bf16-rounded features of a
                 # conv blob with C % 64 == 0 (the engine's style16.hip); D and everything else stay fp32

@@ -25,6 +25,7 @@ SOURCES = (
     ('passes.hip', ('-ffp-contract=off',)),      # NumPy-like one-rounding-per-operation arithmetic
     ('lbfgs.hip', ('-ffp-contract=off',)),
     ('style16.hip', ()),
+    ('gram16.hip', ()),
     ('engine.cpp', ('-x', 'hip')),
 )
 HEADERS = ('st2_kernels.h', 'reduce.cuh', os.path.join('..', '..', 'include', 'st2.h'))

@@ -385,9 +385,9 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool le
     return ST_OK;
 }
 
-static int ensure_gram_bufs(st_ctx* c, int C, int hw, GramPlan& pl)
+static int ensure_gram_bufs(st_ctx* c, int C, int hw, GramPlan& pl, bool plan16 = false)
 {
-    pl = gram_plan(C, hw);
+    pl = plan16 ? gram_plan16(C, hw) : gram_plan(C, hw);
     if (pl.slab_floats > c->gram_slab_cap) {
         dfree(c->gram_slabs);
         ST_TRY(dmalloc(&c->gram_slabs, pl.slab_floats));
@@ -403,13 +403,17 @@ static int ensure_gram_bufs(st_ctx* c, int C, int hw, GramPlan& pl)
 }
 
 // G (or G - target) of blob data F -> out (C*C); optional sum-of-squares partials
-static int gram_into(st_ctx* c, const float* F, int C, int hw, const float* target, float* out, int out_ld, float* partial, int* n_partial)
+// F16 (optional): the bf16 channel-blocked copy of the blob -- the bf16 feature path then takes the partials on the bf16 matrix cores
+static int gram_into(st_ctx* c, const float* F, int C, int hw, const float* target, float* out, int out_ld, float* partial, int* n_partial,
+                     const unsigned short* F16 = nullptr)
 {
     GramPlan pl;
-    ST_TRY(ensure_gram_bufs(c, C, hw, pl));
+    const bool use16 = F16 && C % 8 == 0 && hw % 64 == 0 && gram16_ok(C, hw, gram_plan16(C, hw));
+    ST_TRY(ensure_gram_bufs(c, C, hw, pl, use16));
     {
-        ProfScope ps(c, P_GRAM, 2.0 * C * C * (double)hw, 4.0 * C * (double)hw);
-        HIP_TRY(launch_gram_partial(F, c->gram_slabs, C, hw, pl, c->stream));
+        ProfScope ps(c, P_GRAM, 2.0 * C * C * (double)hw, (use16 ? 2.0 : 4.0) * C * (double)hw);
+        if (use16) HIP_TRY(launch_gram16_partial(F16, c->gram_slabs, C, hw, pl, c->stream));
+        else HIP_TRY(launch_gram_partial(F, c->gram_slabs, C, hw, pl, c->stream));
     }
     {
         ProfScope ps(c, P_GRAM_REDUCE, 0, 4.0 * (double)pl.slab_floats);
@@ -646,7 +650,9 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
                 ST_TRY(dmalloc(&c->dbuf, cc));
                 HIP_TRY(hipMemsetAsync(c->dbuf, 0, cc * sizeof(float), c->stream));
             }
-            ST_TRY(gram_into(c, a.data[b], C, hw, c->style_gram[b], c->dbuf, conv_mpad(C), part + 4 * kMaxPartials, &cnt[4]));
+            // bf16 path: the Gram of the CURRENT features is taken from their bf16 copy (the style targets stay fp32 Grams)
+            const bool f16_fresh = c->bf16 && !c->tile.on && a.data16[b] && b >= 1 && c->topo[b - 1].is_conv && style_grad16_ok(C, (size_t)hw);
+            ST_TRY(gram_into(c, a.data[b], C, hw, c->style_gram[b], c->dbuf, conv_mpad(C), part + 4 * kMaxPartials, &cnt[4], f16_fresh ? a.data16[b] : nullptr));
             const float c2 = (float)(2.0 / ((double)C * C * (double)n));
             // bf16 path: F from its bf16 copy on the bf16 matrix cores (written by this forward: b <= last, a style layer)
             const bool s16 = c->bf16 && !c->tile.on && a.data16[b] && b >= 1 && c->topo[b - 1].is_conv && style_grad16_ok(C, (size_t)hw);

@@ -39,6 +39,16 @@ GramPlan gram_plan(int C, int hw)
     return p;
 }
 
+// the same plan with slabs of whole 64-pixel steps (gram16.hip stages 64 pixels per step)
+GramPlan gram_plan16(int C, int hw)
+{
+    GramPlan p = gram_plan(C, hw);
+    p.kslab = (p.kslab + 63) / 64 * 64;
+    p.splits = (hw + p.kslab - 1) / p.kslab;
+    p.slab_floats = (size_t)p.splits * C * C;
+    return p;
+}
+
 template <int BT>
 __global__ __launch_bounds__(256) void gram_partial_k(const float* __restrict__ F, float* __restrict__ slabs,
                                                       int C, int hw, int tiles_1d, int kslab, GramRoi roi)

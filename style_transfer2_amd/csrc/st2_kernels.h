@@ -101,6 +101,11 @@ hipError_t launch_maxpool_bwd(const float* dy, const float* x, float* dx, const 
 // ------------------------------------------------------------------------------------------
 struct GramPlan { int bt, tiles, splits, kslab; size_t slab_floats; };
 GramPlan gram_plan(int C, int hw);
+// bf16 feature path (gram16.hip): partials from the bf16 channel-blocked copy [C/8][hw][8] on the bf16 matrix cores, fp32
+// accumulation; same slab format (gram_reduce finishes it).  Needs C % 8 == 0, hw % 64 == 0 and a gram_plan16 plan.
+GramPlan gram_plan16(int C, int hw);
+bool gram16_ok(int C, int hw, const GramPlan& pl);
+hipError_t launch_gram16_partial(const unsigned short* F16, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s);
 // region of interest of a blob [C][H][W]: hw (= rw * rows) pixels starting at (y0, x0); pitch = W, plane = H*W
 struct GramRoi { int y0, x0, rw, pitch; size_t plane; };
 hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s,
