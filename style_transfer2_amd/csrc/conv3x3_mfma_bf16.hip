@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace st2 {
 
@@ -205,128 +206,162 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     }
 
     // ---- epilogue: fp32 blob (same as the fp32 kernel, optional) + bf16 channel-blocked copy (optional) + fused pool (optional)
+    // Written for the memory system, not for brevity: every load the epilogue needs (the bf16 ReLU masks of the whole tile,
+    // the bias) is issued up front and unconditionally (clamped addresses instead of branches: a per-element "load or zero"
+    // makes hipcc branch around each load and wait for it alone), and the per-channel bounds tests of the stores vanish on
+    // the (wave-uniform) fast path of a tile that lies inside M.
     const int gx = x0 + l31;
     const bool colv = gx < a.W;
     const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr, has_mask16 = a.mask16 != nullptr;
     const bool pooling = TN == 2 && (a.pool16 || a.pool32 || a.amap);
+    const bool full_m = m0 + BM <= a.M;                          // uniform: no channel of this tile is padding
+    unsigned pixj[TN];
+    bool livej[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j) {
+        const int gy = y0 + wave_n * TN + j;
+        livej[j] = colv && gy < a.H;
+        pixj[j] = livej[j] ? (unsigned)gy * a.W + gx : 0u;
+    }
+    uint2 mk16[TM][2][TN][2];
+    if (has_mask16) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h;
-            float v[TN][8];
-            float bs[8];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) bs[e] = has_bias ? a.bias[mbase + (e & 3) + 8 * (e >> 2)] : 0.0f;
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int gy = y0 + wave_n * TN + j;
-                const bool live = colv && gy < a.H;
-                const unsigned pix = live ? (unsigned)gy * a.W + gx : 0u;
-                unsigned off[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int m = mbase + (e & 3) + 8 * (e >> 2);
-                    off[e] = (unsigned)(m < a.M ? m : a.M - 1) * plane + pix;
-                    v[j][e] = acc[i][j][8 * h + e] + bs[e];
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[j][e] = v[j][e] > 0.0f ? v[j][e] : 0.0f;
-                }
-                if (has_mask16) {
-                    // the blob below is post-ReLU (>= 0): its bf16 copy is non-zero exactly where it is positive
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
-                        const int mg = (mbase + 8 * g) < a.M ? mbase + 8 * g : 0;
-                        const uint2 mk = *reinterpret_cast<const uint2*>(a.mask16 + ((size_t)(mg >> 3) * plane + pix) * 8 + (mg & 7));
-                        v[j][4 * g + 0] = (mk.x & 0xffffu) ? v[j][4 * g + 0] : 0.0f;
-                        v[j][4 * g + 1] = (mk.x >> 16) ? v[j][4 * g + 1] : 0.0f;
-                        v[j][4 * g + 2] = (mk.y & 0xffffu) ? v[j][4 * g + 2] : 0.0f;
-                        v[j][4 * g + 3] = (mk.y >> 16) ? v[j][4 * g + 3] : 0.0f;
+                        const int mg0 = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h + 8 * g;
+                        const int mg = mg0 < a.M ? mg0 : 0;
+                        mk16[i][h][j][g] = *reinterpret_cast<const uint2*>(a.mask16 + ((size_t)(mg >> 3) * plane + pixj[j]) * 8 + (mg & 7));
                     }
-                } else if (has_mask) {
-                    float mk[8];
+    }
+    auto tile_out = [&](auto full_t) {
+        constexpr bool FULL = decltype(full_t)::value;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) mk[e] = a.mask_src[off[e]];
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[j][e] = mk[e] > 0.0f ? v[j][e] : 0.0f;
+            for (int h = 0; h < 2; ++h) {
+                const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h;
+                float v[TN][8];
+                float bs[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bs[e] = 0.0f;
+                if (has_bias) {                                   // the bias array is MPad long: no bounds test
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bs[e] = a.bias[mbase + (e & 3) + 8 * (e >> 2)];
                 }
-                if (has_inj) {
-                    float ij[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ij[e] = a.inject[off[e]];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[j][e] += ij[e];
-                }
-                if (a.out && live) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[j][e];
-                }
-                if (a.out16 && live) {
-                    // rows mbase..+3 and mbase+8..+11: two groups of 4 consecutive channels -> two 8-byte stores
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const int mg = mbase + 8 * g;
-                        if (mg < a.M) {             // M is a multiple of 8 on this path (checked at launch)
-                            bf16x4 pk;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[j][4 * g + e];
-                            *reinterpret_cast<bf16x4*>(a.out16 + ((size_t)(mg >> 3) * plane + pix) * 8 + (mg & 7)) = pk;
-                        }
-                    }
-                }
-            }
-            if constexpr (TN == 2) {
-                if (pooling) {
-                    // Caffe MAX 2x2/2, ceil mode: this wave's two rows are one row of pooling windows (row origins are even),
-                    // lane pairs (even gx, gx + 1) are the two columns.  First maximum of a row-major scan, strictly greater
-                    // (oracle.caffe_net.maxpool_forward); windows are clipped at the right / bottom edge.
-                    const int gy0 = y0 + wave_n * 2;
-                    const bool row1 = gy0 + 1 < a.H, col1 = gx + 1 < a.W;
-                    const bool writer = !(l31 & 1) && colv && gy0 < a.H;
-                    const size_t pplane = (size_t)a.pool_h * a.pool_w;
-                    const size_t ppix = writer ? (size_t)(gy0 >> 1) * a.pool_w + (gx >> 1) : 0;
-                    float best[8];
-                    unsigned code[8];
+                for (int j = 0; j < TN; ++j) {
+                    const bool live = livej[j];
+                    const unsigned pix = pixj[j];
+                    unsigned off[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[0][e]), 0xB1, 0xf, 0xf, true));
-                        const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[1][e]), 0xB1, 0xf, 0xf, true));
-                        float b = v[0][e];
-                        unsigned sl = 0;
-                        if (col1 && p0 > b) { b = p0; sl = 1; }
-                        if (row1 && v[1][e] > b) { b = v[1][e]; sl = 2; }
-                        if (row1 && col1 && p1 > b) { b = p1; sl = 3; }
-                        best[e] = b;
-                        code[e] = sl | (b > 0.0f ? 4u : 0u);
+                        const int m = mbase + (e & 3) + 8 * (e >> 2);
+                        off[e] = (unsigned)((FULL || m < a.M) ? m : a.M - 1) * plane + pix;
+                        v[j][e] = acc[i][j][8 * h + e] + bs[e];
                     }
-                    if (writer) {
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[j][e] = v[j][e] > 0.0f ? v[j][e] : 0.0f;
+                    }
+                    if (has_mask16) {
+                        // the blob below is post-ReLU (>= 0): its bf16 copy is non-zero exactly where it is positive
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const uint2 mk = mk16[i][h][j][g];
+                            v[j][4 * g + 0] = (mk.x & 0xffffu) ? v[j][4 * g + 0] : 0.0f;
+                            v[j][4 * g + 1] = (mk.x >> 16) ? v[j][4 * g + 1] : 0.0f;
+                            v[j][4 * g + 2] = (mk.y & 0xffffu) ? v[j][4 * g + 2] : 0.0f;
+                            v[j][4 * g + 3] = (mk.y >> 16) ? v[j][4 * g + 3] : 0.0f;
+                        }
+                    } else if (has_mask) {
+                        float mk[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) mk[e] = a.mask_src[off[e]];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[j][e] = mk[e] > 0.0f ? v[j][e] : 0.0f;
+                    }
+                    if (has_inj) {
+                        float ij[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ij[e] = a.inject[off[e]];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[j][e] += ij[e];
+                    }
+                    if (a.out && live) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (FULL || mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[j][e];
+                    }
+                    if (a.out16 && live) {
+                        // rows mbase..+3 and mbase+8..+11: two groups of 4 consecutive channels -> two 8-byte stores
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
                             const int mg = mbase + 8 * g;
-                            if (mg >= a.M) continue;
-                            const size_t q8 = ((size_t)(mg >> 3) * pplane + ppix) * 8 + (mg & 7);
-                            if (a.pool16) {
+                            if (FULL || mg < a.M) {         // M is a multiple of 8 on this path (checked at launch)
                                 bf16x4 pk;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) pk[e] = (__bf16)best[4 * g + e];
-                                *reinterpret_cast<bf16x4*>(a.pool16 + q8) = pk;
+                                for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[j][4 * g + e];
+                                *reinterpret_cast<bf16x4*>(a.out16 + ((size_t)(mg >> 3) * plane + pix) * 8 + (mg & 7)) = pk;
                             }
-                            if (a.amap)
-                                *reinterpret_cast<unsigned*>(a.amap + q8) = code[4 * g] | (code[4 * g + 1] << 8) | (code[4 * g + 2] << 16) | (code[4 * g + 3] << 24);
-                            if (a.pool32) {
+                        }
+                    }
+                }
+                if constexpr (TN == 2) {
+                    if (pooling) {
+                        // Caffe MAX 2x2/2, ceil mode: this wave's two rows are one row of pooling windows (row origins are even),
+                        // lane pairs (even gx, gx + 1) are the two columns.  First maximum of a row-major scan, strictly greater
+                        // (oracle.caffe_net.maxpool_forward); windows are clipped at the right / bottom edge.
+                        const int gy0 = y0 + wave_n * 2;
+                        const bool row1 = gy0 + 1 < a.H, col1 = gx + 1 < a.W;
+                        const bool writer = !(l31 & 1) && colv && gy0 < a.H;
+                        const size_t pplane = (size_t)a.pool_h * a.pool_w;
+                        const size_t ppix = writer ? (size_t)(gy0 >> 1) * a.pool_w + (gx >> 1) : 0;
+                        float best[8];
+                        unsigned code[8];
 #pragma unroll
-                                for (int e = 0; e < 4; ++e)
-                                    if (mg + e < a.M) a.pool32[(size_t)(mg + e) * pplane + ppix] = best[4 * g + e];
+                        for (int e = 0; e < 8; ++e) {
+                            const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[0][e]), 0xB1, 0xf, 0xf, true));
+                            const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[1][e]), 0xB1, 0xf, 0xf, true));
+                            float bb = v[0][e];
+                            unsigned sl = 0;
+                            if (col1 && p0 > bb) { bb = p0; sl = 1; }
+                            if (row1 && v[1][e] > bb) { bb = v[1][e]; sl = 2; }
+                            if (row1 && col1 && p1 > bb) { bb = p1; sl = 3; }
+                            best[e] = bb;
+                            code[e] = sl | (bb > 0.0f ? 4u : 0u);
+                        }
+                        if (writer) {
+#pragma unroll
+                            for (int g = 0; g < 2; ++g) {
+                                const int mg = mbase + 8 * g;
+                                if (!FULL && mg >= a.M) continue;
+                                const size_t q8 = ((size_t)(mg >> 3) * pplane + ppix) * 8 + (mg & 7);
+                                if (a.pool16) {
+                                    bf16x4 pk;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) pk[e] = (__bf16)best[4 * g + e];
+                                    *reinterpret_cast<bf16x4*>(a.pool16 + q8) = pk;
+                                }
+                                if (a.amap)
+                                    *reinterpret_cast<unsigned*>(a.amap + q8) = code[4 * g] | (code[4 * g + 1] << 8) | (code[4 * g + 2] << 16) | (code[4 * g + 3] << 24);
+                                if (a.pool32) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (FULL || mg + e < a.M) a.pool32[(size_t)(mg + e) * pplane + ppix] = best[4 * g + e];
+                                }
                             }
                         }
                     }
                 }
             }
         }
-    }
+    };
+    if (full_m) tile_out(std::true_type{}); else tile_out(std::false_type{});
 }
 
 #define ST2_CONV16_KERNEL(NAME, BM, ROWS, WM, WN, WPE) \
