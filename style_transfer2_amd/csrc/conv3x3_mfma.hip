@@ -15,6 +15,7 @@
 // The next chunk's global loads are issued before the MFMA block and parked in registers.
 // fp32 MFMA == a k-ordered fmaf chain, so results are plain IEEE fp32.
 #include "st2_kernels.h"
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -269,6 +270,9 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
         // S = c2 * (D @ F); partial[block] = sum S^2; raw: out = S; fused: out = (sw / norm) * S (+ out)
         const float coef = a.fused ? a.sw / *a.norm : 0.f;
         float ss = 0.f;
+        const bool full_m = m0 + BM <= a.M;                  // uniform: no per-channel bounds tests on a tile inside M
+        auto style_out = [&](auto full_t) {
+        constexpr bool FULL = decltype(full_t)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int gy = y0 + wave_n * TN + j;
@@ -286,9 +290,9 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const int m = mbase + (e & 3) + 8 * (e >> 2);
-                        off[e] = (unsigned)(m < a.M ? m : a.M - 1) * plane + pix;
+                        off[e] = (unsigned)((FULL || m < a.M) ? m : a.M - 1) * plane + pix;
                         v[e] = in_roi ? acc[i][j][8 * h + e] * a.c2 : 0.f;
-                        if (m < a.M) ss += v[e] * v[e];
+                        if (FULL || m < a.M) ss += v[e] * v[e];
                     }
                     if (a.fused && a.accumulate) {
 #pragma unroll
@@ -297,10 +301,12 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float r2 = a.fused ? coef * v[e] + (a.accumulate ? old[e] : 0.f) : v[e];
-                        if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = r2;
+                        if (FULL || mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = r2;
                     }
                 }
         }
+        };
+        if (full_m) style_out(std::true_type{}); else style_out(std::false_type{});
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
         __syncthreads();                     // every wave is done with the staged tiles
@@ -310,6 +316,9 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
         return;
     }
     const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr;
+    const bool full_m = m0 + BM <= a.M;                      // uniform: no per-channel bounds tests on a tile inside M
+    auto conv_out = [&](auto full_t) {
+    constexpr bool FULL = decltype(full_t)::value;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int gy = y0 + wave_n * TN + j;
@@ -325,7 +334,7 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int m = mbase + (e & 3) + 8 * (e >> 2);
-                    off[e] = (unsigned)(m < a.M ? m : a.M - 1) * plane + pix;
+                    off[e] = (unsigned)((FULL || m < a.M) ? m : a.M - 1) * plane + pix;
                     v[e] = acc[i][j][8 * h + e];
                 }
                 if (has_bias) {
@@ -352,14 +361,14 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[e];
+                    if (FULL || mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[e];
                 if (a.out16) {
                     // rows mbase..+3 and mbase+8..+11: two groups of 4 consecutive channels -> two 8-byte stores
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
                     for (int g = 0; g < 2; ++g) {
                         const int mg = mbase + 8 * g;
-                        if (mg < a.M) {             // M is a multiple of 8 on this path (checked at launch)
+                        if (FULL || mg < a.M) {     // M is a multiple of 8 on this path (checked at launch)
                             bf16x4 pk;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[4 * g + e];
@@ -370,6 +379,8 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
             }
         }
     }
+    };
+    if (full_m) conv_out(std::true_type{}); else conv_out(std::false_type{});
 }
 
 // Non-template kernel entry points (the waves-per-SIMD launch bound must be a literal).
