@@ -155,6 +155,9 @@ int st_tile_update(st_ctx* ctx, const float* ring_dev, float** dev_ptr, int* n_f
 /* which: 0 current x (3,wh,ww), 1 next x, 2 local sum D^2 per style layer, 3 norms [blob][c,s,d] */
 int st_tile_buffer(st_ctx* ctx, int which, float** dev_ptr);
 int st_tile_swap(st_ctx* ctx);
+/* strips exchanged with ONE neighbour: rects [n][4] = {y0, x0, h, w} (window coordinates, n <= 12) of the (C, wh, ww) device
+ * tensor <-> one contiguous device buffer (rect r stored as (C, h_r, w_r), in order).  mode 0 pack, 1 unpack, 2 unpack-add. */
+int st_tile_strips(st_ctx* ctx, void* tensor_dev, int C, int wh, int ww, int n, const int* rects, void* buf_dev, int mode);
 
 #ifdef __cplusplus
 }

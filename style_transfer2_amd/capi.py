@@ -81,6 +81,7 @@ PROTOTYPES = {
     'st_tile_update': (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_int)]),
     'st_tile_buffer': (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
     'st_tile_swap': (c_int, [c_void_p]),
+    'st_tile_strips': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), c_void_p, c_int]),
 }
 
 _lib = None

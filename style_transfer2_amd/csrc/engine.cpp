@@ -1819,6 +1819,28 @@ int st_tile_buffer(st_ctx* c, int which, float** dev_ptr)
     return ST_OK;
 }
 
+// Pack (mode 0) the rectangles `rects` ([n][4] = y0, x0, h, w in window coordinates) of the (C, wh, ww) device tensor into
+// the contiguous device buffer `buf`, or unpack them from it (mode 1 assign, 2 add): one launch per neighbour and phase.
+int st_tile_strips(st_ctx* c, void* tensor_dev, int C, int wh, int ww, int n, const int* rects, void* buf_dev, int mode)
+{
+    if (!c || !tensor_dev || !buf_dev || n < 0 || n > kMaxStripRects || (n && !rects) || mode < 0 || mode > 2) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    StripTable t{};
+    t.n = n;
+    int total = 0;
+    for (int r = 0; r < n; ++r) {
+        t.y0[r] = rects[4 * r]; t.x0[r] = rects[4 * r + 1]; t.h[r] = rects[4 * r + 2]; t.w[r] = rects[4 * r + 3];
+        if (t.y0[r] < 0 || t.x0[r] < 0 || t.h[r] <= 0 || t.w[r] <= 0 || t.y0[r] + t.h[r] > wh || t.x0[r] + t.w[r] > ww)
+            return fail(ST_ERR_ARG, "strip %d lies outside the %dx%d window", r, wh, ww);
+        t.off[r] = total;
+        total += C * t.h[r] * t.w[r];
+    }
+    t.total = total;
+    HIP_TRY(launch_strip_copy((float*)tensor_dev, (float*)buf_dev, t, C, wh, ww, mode, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
 int st_tile_swap(st_ctx* c)
 {
     if (c) c->epoch++;       // anything but st_step may change what a step launches: captured step graphs are stale

@@ -616,6 +616,34 @@ hipError_t launch_finalize_trace(const TraceArgs& a, hipStream_t s)
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ tile-sharded mode: strip pack / unpack
+// All rectangles one neighbour receives travel as ONE contiguous buffer: rect r of a (C, wh, ww) window tensor is stored as
+// (C, h_r, w_r) at offset off_r.  mode 0: pack (tensor -> buffer), 1: unpack (buffer -> tensor), 2: unpack and ADD.
+__global__ __launch_bounds__(256) void strip_copy_k(float* __restrict__ tensor, float* __restrict__ buf, const StripTable t, int C, int wh, int ww, int mode)
+{
+    const size_t plane = (size_t)wh * ww;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < (size_t)t.total; idx += (size_t)gridDim.x * 256) {
+        int r = 0;
+#pragma unroll
+        for (int k = 1; k < kMaxStripRects; ++k) r += (k < t.n && idx >= (size_t)t.off[k]) ? 1 : 0;     // rects are stored in offset order
+        const size_t e = idx - t.off[r];
+        const int w = t.w[r], h = t.h[r];
+        const int x = (int)(e % w), y = (int)((e / w) % h), c = (int)(e / ((size_t)w * h));
+        float* tp = tensor + (size_t)c * plane + (size_t)(t.y0[r] + y) * ww + t.x0[r] + x;
+        if (mode == 0) buf[idx] = *tp;
+        else if (mode == 1) *tp = buf[idx];
+        else *tp += buf[idx];
+    }
+}
+
+hipError_t launch_strip_copy(float* tensor, float* buf, const StripTable& t, int C, int wh, int ww, int mode, hipStream_t s)
+{
+    if (t.n <= 0 || t.total <= 0) return hipSuccess;
+    const int grid = reduce_grid((size_t)t.total, 256 * 4, 2048);
+    strip_copy_k<<<grid, 256, 0, s>>>(tensor, buf, t, C, wh, ww, mode);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------- deterministic final sums
 __global__ __launch_bounds__(256) void dot_final_k(const float* part, int n_part, float* out)
 {

@@ -195,6 +195,12 @@ struct ImageTileArgs {
 };
 hipError_t launch_image_pass_tile(const ImageTileArgs& a, int* n_partial, hipStream_t s);
 
+// Tile-sharded mode: the rectangles exchanged with ONE neighbour, packed into / unpacked from one contiguous buffer
+constexpr int kMaxStripRects = 12;
+struct StripTable { int n; int total; int y0[kMaxStripRects], x0[kMaxStripRects], h[kMaxStripRects], w[kMaxStripRects], off[kMaxStripRects]; };
+// mode 0: buf = pack(tensor rects); 1: tensor rects = buf; 2: tensor rects += buf   (tensor is (C, wh, ww))
+hipError_t launch_strip_copy(float* tensor, float* buf, const StripTable& t, int C, int wh, int ww, int mode, hipStream_t s);
+
 // Pillow-exact separable resampling of float planes (utils.py:130-160).  Tables live on the device:
 // lo[i] = first source index, n[i] = window length, k[i*kmax + j] = normalised double coefficients.
 struct ResampleTable { const int* lo; const int* n; const double* k; int kmax; };

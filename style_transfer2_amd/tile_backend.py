@@ -76,6 +76,14 @@ class HipTileBackend:
         torch.cuda.synchronize(self.device)
         check(self.lib.st_tile_swap(self.ctx))
 
+    def strips(self, tensor, rects, buf, mode):
+        """One kernel per neighbour and phase: pack (mode 0) the rects [(y0, x0, h, w)] of the (3, wh, ww) device tensor into
+        the 1-D device buffer `buf`, or unpack them from it (1 assign, 2 add)."""
+        torch.cuda.synchronize(self.device)
+        flat = (c_int * (4 * len(rects)))(*[int(v) for r in rects for v in r])
+        check(self.lib.st_tile_strips(self.ctx, c_void_p(tensor.data_ptr()), tensor.shape[0], tensor.shape[1], tensor.shape[2],
+                                      len(rects), flat, c_void_p(buf.data_ptr()), mode))
+
     # ---- phases -------------------------------------------------------------------------------------------
     def forward_partials(self):
         torch.cuda.synchronize(self.device)

@@ -78,60 +78,82 @@ class TiledTransfer:
         self._ring = grid.ring_plan()
 
     # -- communication phases ------------------------------------------------------------------------------
+    # Everything one neighbour gets in a phase travels as ONE message: its rectangles are packed into a contiguous buffer
+    # (one kernel per neighbour on the HIP backend, `backend.strips`) and unpacked the same way on the other side.
+    MAX_RECTS = 12                              # st2_kernels.h kMaxStripRects
+
+    def _pack(self, t, rects):
+        n = sum(t.shape[0] * r[2] * r[3] for r in rects)
+        if t.is_cuda and hasattr(self.backend, 'strips') and len(rects) <= self.MAX_RECTS:
+            buf = torch.empty(n, dtype=t.dtype, device=t.device)
+            self.backend.strips(t, rects, buf, 0)
+            return buf
+        return torch.cat([t[:, y:y + h, x:x + w].reshape(-1) for y, x, h, w in rects])
+
+    def _unpack(self, t, rects, buf, add):
+        if t.is_cuda and hasattr(self.backend, 'strips') and len(rects) <= self.MAX_RECTS:
+            self.backend.strips(t, rects, buf, 2 if add else 1)
+            return
+        pos = 0
+        for y, x, h, w in rects:
+            n = t.shape[0] * h * w
+            piece = buf[pos:pos + n].reshape(t.shape[0], h, w)
+            if add:
+                t[:, y:y + h, x:x + w] += piece
+            else:
+                t[:, y:y + h, x:x + w] = piece
+            pos += n
+
+    def _exchange(self, src, send_rects, dst, recv_rects, add):
+        """send_rects / recv_rects: {peer: [(y0, x0, h, w), ...]} in plan order (local coordinates of src / dst)."""
+        sends = [(peer, self._pack(src, rects)) for peer, rects in sorted(send_rects.items())]
+        recvs = [(peer, torch.empty(sum(dst.shape[0] * r[2] * r[3] for r in rects), dtype=dst.dtype, device=dst.device))
+                 for peer, rects in sorted(recv_rects.items())]
+        self.comm.exchange(sends, recvs)
+        for (peer, buf) in recvs:                   # ascending peer, plan order inside: deterministic sums
+            self._unpack(dst, recv_rects[peer], buf, add)
+
+    @staticmethod
+    def _lrect(rect, origin):
+        return (rect.y0 - origin.y0, rect.x0 - origin.x0, rect.y1 - rect.y0, rect.x1 - rect.x0)
+
     def refresh_aprons(self, x):
         """x: (3, wh, ww) window tensor whose TILE part is current: fill the apron from the owners."""
-        sends, recvs, dst_slices = [], [], []
+        sends, recvs = {}, {}
         for src, dst, rect in self._refresh:
             if src == self.rank:
-                ys, xs = _local(rect, self.window)
-                sends.append((dst, x[:, ys, xs].contiguous()))
+                sends.setdefault(dst, []).append(self._lrect(rect, self.window))
             elif dst == self.rank:
-                ys, xs = _local(rect, self.window)
-                buf = torch.empty((3, rect.y1 - rect.y0, rect.x1 - rect.x0), dtype=x.dtype, device=x.device)
-                recvs.append((src, buf))
-                dst_slices.append((ys, xs, buf))
-        self.comm.exchange(sends, recvs)
-        for ys, xs, buf in dst_slices:
-            x[:, ys, xs] = buf
+                recvs.setdefault(src, []).append(self._lrect(rect, self.window))
+        self._exchange(x, sends, x, recvs, add=False)
 
     def overlap_add(self, g):
         """g: (3, wh, ww) window gradient: add the neighbours' contributions to MY tile pixels."""
-        sends, recvs, adds = [], [], []
+        sends, recvs = {}, {}
         for src, dst, rect in self._overlap:
             if src == self.rank:
-                ys, xs = _local(rect, self.window)
-                sends.append((dst, g[:, ys, xs].contiguous()))
+                sends.setdefault(dst, []).append(self._lrect(rect, self.window))
             elif dst == self.rank:
-                ys, xs = _local(rect, self.window)
-                buf = torch.empty((3, rect.y1 - rect.y0, rect.x1 - rect.x0), dtype=g.dtype, device=g.device)
-                recvs.append((src, buf))
-                adds.append((ys, xs, buf))
-        self.comm.exchange(sends, recvs)
-        for ys, xs, buf in adds:                 # fixed plan order -> deterministic sums
-            g[:, ys, xs] += buf
+                recvs.setdefault(src, []).append(self._lrect(rect, self.window))
+        self._exchange(g, sends, g, recvs, add=True)
 
     def gather_ring(self, x):
         """(3, th+2, tw+2) tensor: the tile's 1-px neighbourhood under the image's periodic wrap."""
         th, tw = self.tile.y1 - self.tile.y0, self.tile.x1 - self.tile.x0
         ring = torch.zeros((3, th + 2, tw + 2), dtype=x.dtype, device=x.device)
-        sends, recvs, places = [], [], []
+        sends, recvs = {}, {}
         for dst, items in enumerate(self._ring):
             for src, rect, ry, rx in items:
                 h, w = rect.y1 - rect.y0, rect.x1 - rect.x0
                 if src == self.rank:
                     ys, xs = _local(rect, self.window)      # my own tile pixels, in my window
-                    piece = x[:, ys, xs]
                     if dst == self.rank:
-                        ring[:, ry:ry + h, rx:rx + w] = piece
+                        ring[:, ry:ry + h, rx:rx + w] = x[:, ys, xs]
                     else:
-                        sends.append((dst, piece.contiguous()))
+                        sends.setdefault(dst, []).append(self._lrect(rect, self.window))
                 elif dst == self.rank:
-                    buf = torch.empty((3, h, w), dtype=x.dtype, device=x.device)
-                    recvs.append((src, buf))
-                    places.append((ry, rx, h, w, buf))
-        self.comm.exchange(sends, recvs)
-        for ry, rx, h, w, buf in places:
-            ring[:, ry:ry + h, rx:rx + w] = buf
+                    recvs.setdefault(src, []).append((ry, rx, h, w))
+        self._exchange(x, sends, ring, recvs, add=False)
         return ring
 
     # -- one iteration ----------------------------------------------------------------------------------------

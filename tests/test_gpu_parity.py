@@ -511,7 +511,8 @@ def test_vgg19_odd_default_size_225x300_unaligned_paths():
 
 
 # ------------------------------------------------------------------- the worker loop on the real engine
-def test_worker_end_to_end_on_gpu_with_resample_and_optimizer_switch():
+@pytest.mark.parametrize('precision,cfg16', [('fp32', None), ('bf16', None), ('bf16', '0')])
+def test_worker_end_to_end_on_gpu_with_resample_and_optimizer_switch(precision, cfg16, monkeypatch):
     """The drop-in worker.py driven through its message protocol (in-process sockets) on the HIP engine:
     SetImages / SetWeights / SetOptimizer / Start, iterates, a RESAMPLE of input+content to a new size with a live
     Adam optimizer (host Pillow path, optimizers.py:29-40), an optimizer switch, pause, shutdown."""
@@ -543,8 +544,12 @@ def test_worker_end_to_end_on_gpu_with_resample_and_optimizer_switch():
             if isinstance(obj, messages.Iterate) and n_it in script:
                 self.inbound.extend(script.pop(n_it) if n_it in script else [])
 
+    # bf16: the lean data flow (fused pools + arg-max maps when the tile configuration is forced to 0) through a resample
+    # to another size, an optimizer switch and a pause -- every buffer of the bf16 path is re-created with the geometry
+    if cfg16 is not None:
+        monkeypatch.setenv('ST2_CONV16_CFG', cfg16)
     topo = oracle.tiny_topology((8, 16), (2, 2))
-    tr = st2.StyleTransfer(st2.HipModel(oracle.he_init_weights(topo, 0, 0.1), topology=topo))
+    tr = st2.StyleTransfer(st2.HipModel(oracle.he_init_weights(topo, 0, 0.1), topology=topo, precision=precision))
     rs = np.random.RandomState
     content, style, init = (rs(1).randint(0, 256, (32, 40, 3)).astype(np.uint8), rs(2).randint(0, 256, (24, 24, 3)).astype(np.uint8),
                             rs(3).randint(0, 256, (32, 40, 3)).astype(np.uint8))
