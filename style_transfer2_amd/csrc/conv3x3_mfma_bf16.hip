@@ -213,7 +213,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     const int gx = x0 + l31;
     const bool colv = gx < a.W;
     const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr, has_mask16 = a.mask16 != nullptr;
-    const bool pooling = TN == 2 && (a.pool16 || a.pool32 || a.amap);
+    const bool pooling = TN % 2 == 0 && (a.pool16 || a.pool32 || a.amap);
     const bool full_m = m0 + BM <= a.M;                          // uniform: no channel of this tile is padding
     unsigned pixj[TN];
     bool livej[TN];
@@ -223,25 +223,31 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         livej[j] = colv && gy < a.H;
         pixj[j] = livej[j] ? (unsigned)gy * a.W + gx : 0u;
     }
-    uint2 mk16[TM][2][TN][2];
-    if (has_mask16) {
+    // masks of the whole tile up front when that fits the register file, otherwise per 32-channel group
+    constexpr bool MK_ALL = TM * TN <= 4;
+    constexpr int MK_I = MK_ALL ? TM : 1;
+    uint2 mk16[MK_I][2][TN][2];
+    auto load_masks = [&](int i, uint2 (&mk)[2][TN][2]) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int g = 0; g < 2; ++g) {
+                    const int mg0 = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h + 8 * g;
+                    const int mg = mg0 < a.M ? mg0 : 0;
+                    mk[h][j][g] = *reinterpret_cast<const uint2*>(a.mask16 + ((size_t)(mg >> 3) * plane + pixj[j]) * 8 + (mg & 7));
+                }
+    };
+    if (MK_ALL && has_mask16) {
 #pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        const int mg0 = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h + 8 * g;
-                        const int mg = mg0 < a.M ? mg0 : 0;
-                        mk16[i][h][j][g] = *reinterpret_cast<const uint2*>(a.mask16 + ((size_t)(mg >> 3) * plane + pixj[j]) * 8 + (mg & 7));
-                    }
+        for (int i = 0; i < TM; ++i) load_masks(i, mk16[i]);
     }
     auto tile_out = [&](auto full_t) {
         constexpr bool FULL = decltype(full_t)::value;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            if (!MK_ALL && has_mask16) load_masks(i, mk16[0]);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h;
@@ -272,7 +278,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                         // the blob below is post-ReLU (>= 0): its bf16 copy is non-zero exactly where it is positive
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
-                            const uint2 mk = mk16[i][h][j][g];
+                            const uint2 mk = mk16[MK_ALL ? i : 0][h][j][g];
                             v[j][4 * g + 0] = (mk.x & 0xffffu) ? v[j][4 * g + 0] : 0.0f;
                             v[j][4 * g + 1] = (mk.x >> 16) ? v[j][4 * g + 1] : 0.0f;
                             v[j][4 * g + 2] = (mk.y & 0xffffu) ? v[j][4 * g + 2] : 0.0f;
@@ -311,48 +317,51 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                         }
                     }
                 }
-                if constexpr (TN == 2) {
+                if constexpr (TN % 2 == 0) {
                     if (pooling) {
-                        // Caffe MAX 2x2/2, ceil mode: this wave's two rows are one row of pooling windows (row origins are even),
-                        // lane pairs (even gx, gx + 1) are the two columns.  First maximum of a row-major scan, strictly greater
-                        // (oracle.caffe_net.maxpool_forward); windows are clipped at the right / bottom edge.
-                        const int gy0 = y0 + wave_n * 2;
-                        const bool row1 = gy0 + 1 < a.H, col1 = gx + 1 < a.W;
-                        const bool writer = !(l31 & 1) && colv && gy0 < a.H;
-                        const size_t pplane = (size_t)a.pool_h * a.pool_w;
-                        const size_t ppix = writer ? (size_t)(gy0 >> 1) * a.pool_w + (gx >> 1) : 0;
-                        float best[8];
-                        unsigned code[8];
+                        // Caffe MAX 2x2/2, ceil mode: each pair of this wave's rows is one row of pooling windows (row origins are
+                        // even), lane pairs (even gx, gx + 1) are the two columns.  First maximum of a row-major scan, strictly
+                        // greater (oracle.caffe_net.maxpool_forward); windows are clipped at the right / bottom edge.
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[0][e]), 0xB1, 0xf, 0xf, true));
-                            const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[1][e]), 0xB1, 0xf, 0xf, true));
-                            float bb = v[0][e];
-                            unsigned sl = 0;
-                            if (col1 && p0 > bb) { bb = p0; sl = 1; }
-                            if (row1 && v[1][e] > bb) { bb = v[1][e]; sl = 2; }
-                            if (row1 && col1 && p1 > bb) { bb = p1; sl = 3; }
-                            best[e] = bb;
-                            code[e] = sl | (bb > 0.0f ? 4u : 0u);
-                        }
-                        if (writer) {
+                        for (int jp = 0; jp < TN; jp += 2) {
+                            const int gy0 = y0 + wave_n * TN + jp;
+                            const bool row1 = gy0 + 1 < a.H, col1 = gx + 1 < a.W;
+                            const bool writer = !(l31 & 1) && colv && gy0 < a.H;
+                            const size_t pplane = (size_t)a.pool_h * a.pool_w;
+                            const size_t ppix = writer ? (size_t)(gy0 >> 1) * a.pool_w + (gx >> 1) : 0;
+                            float best[8];
+                            unsigned code[8];
 #pragma unroll
-                            for (int g = 0; g < 2; ++g) {
-                                const int mg = mbase + 8 * g;
-                                if (!FULL && mg >= a.M) continue;
-                                const size_t q8 = ((size_t)(mg >> 3) * pplane + ppix) * 8 + (mg & 7);
-                                if (a.pool16) {
-                                    bf16x4 pk;
+                            for (int e = 0; e < 8; ++e) {
+                                const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[jp][e]), 0xB1, 0xf, 0xf, true));
+                                const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[jp + 1][e]), 0xB1, 0xf, 0xf, true));
+                                float bb = v[jp][e];
+                                unsigned sl = 0;
+                                if (col1 && p0 > bb) { bb = p0; sl = 1; }
+                                if (row1 && v[jp + 1][e] > bb) { bb = v[jp + 1][e]; sl = 2; }
+                                if (row1 && col1 && p1 > bb) { bb = p1; sl = 3; }
+                                best[e] = bb;
+                                code[e] = sl | (bb > 0.0f ? 4u : 0u);
+                            }
+                            if (writer) {
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) pk[e] = (__bf16)best[4 * g + e];
-                                    *reinterpret_cast<bf16x4*>(a.pool16 + q8) = pk;
-                                }
-                                if (a.amap)
-                                    *reinterpret_cast<unsigned*>(a.amap + q8) = code[4 * g] | (code[4 * g + 1] << 8) | (code[4 * g + 2] << 16) | (code[4 * g + 3] << 24);
-                                if (a.pool32) {
+                                for (int g = 0; g < 2; ++g) {
+                                    const int mg = mbase + 8 * g;
+                                    if (!FULL && mg >= a.M) continue;
+                                    const size_t q8 = ((size_t)(mg >> 3) * pplane + ppix) * 8 + (mg & 7);
+                                    if (a.pool16) {
+                                        bf16x4 pk;
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        if (FULL || mg + e < a.M) a.pool32[(size_t)(mg + e) * pplane + ppix] = best[4 * g + e];
+                                        for (int e = 0; e < 4; ++e) pk[e] = (__bf16)best[4 * g + e];
+                                        *reinterpret_cast<bf16x4*>(a.pool16 + q8) = pk;
+                                    }
+                                    if (a.amap)
+                                        *reinterpret_cast<unsigned*>(a.amap + q8) = code[4 * g] | (code[4 * g + 1] << 8) | (code[4 * g + 2] << 16) | (code[4 * g + 3] << 24);
+                                    if (a.pool32) {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                            if (FULL || mg + e < a.M) a.pool32[(size_t)(mg + e) * pplane + ppix] = best[4 * g + e];
+                                    }
                                 }
                             }
                         }
@@ -369,16 +378,21 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x256, 64, 8, 1, 4, 2)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_128x128, 128, 4, 2, 2, 1)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x128, 64, 4, 1, 4, 3)
+ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x512, 64, 16, 1, 4, 2)     // 4 rows per wave: twice the MFMA work per staged weight slab
 
 static int conv16_pick_cfg(const Conv16Problem& p)
 {
     const char* env = getenv("ST2_CONV16_CFG");             // forces one tile configuration (tests of every configuration)
     const int forced = env && *env ? atoi(env) : -1;
     const long long tx = (p.W + 31) / 32;
-    int cfg;                                               // 0: 64x256px, 1: 128x128px, 2: 64x128px
+    const char* big = getenv("ST2_CONV16_BIG_MIN");         // tuning knob: least number of 64x512 workgroups that selects that tile
+    const long long big_min = big && *big ? atoll(big) : 512;
+    int cfg;                                               // 0: 64x256px, 1: 128x128px, 2: 64x128px, 3: 64x512px
     if (forced >= 0) cfg = forced;
+    else if (tx * ((p.H + 15) / 16) * (p.MPad / 64) >= big_min) cfg = 3;    // enough workgroups even at 512 pixels each
     else cfg = (tx * ((p.H + 7) / 8) * (p.MPad / 64) >= 512) ? 0 : 2;
     if (cfg == 1 && p.MPad % 128 != 0) cfg = 0;
+    if (cfg > 3) cfg = 0;
     return cfg;
 }
 
@@ -395,7 +409,7 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     if (!p.out && !p.out16 && !pools) return hipErrorInvalidValue;          // nothing to write
     const long long tx = (p.W + 31) / 32;
     const int cfg = conv16_pick_cfg(p);
-    const int BM = cfg == 1 ? 128 : 64, ROWS = cfg == 0 ? 8 : 4;
+    const int BM = cfg == 1 ? 128 : 64, ROWS = cfg == 0 ? 8 : cfg == 3 ? 16 : 4;
     Conv16KArgs k{};
     k.in16 = p.in16; k.wpack = p.wpack16; k.bias = p.bias; k.out = p.out; k.out16 = p.out16;
     k.mask_src = p.mask_src; k.inject = p.inject; k.mask16 = p.mask16;
@@ -409,7 +423,8 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     k.in_bytes = (unsigned)in_bytes; k.w_bytes = (unsigned)w_bytes;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (cfg == 0) conv3x3_mfma_bf16_64x256<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    if (cfg == 3) conv3x3_mfma_bf16_64x512<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    else if (cfg == 0) conv3x3_mfma_bf16_64x256<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else if (cfg == 1) conv3x3_mfma_bf16_128x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else conv3x3_mfma_bf16_64x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     return hipGetLastError();

@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 F32 = np.float32
 
 
-@pytest.fixture(params=['auto', '0', '1', '2'])
+@pytest.fixture(params=['auto', '0', '1', '2', '3'])
 def conv16_cfg(request):
     old = os.environ.get('ST2_CONV16_CFG')
     if request.param == 'auto':
@@ -172,7 +172,7 @@ def _bf16_job(precision, size, weights, optimizer, topo=None, params=None):
 def test_lean_bf16_data_flow_is_bit_identical_to_the_full_one(size, conv16_cfg):
     """precision='bf16' skips the fp32 blobs / diffs that only bf16 convs would read, masks with the bf16 copies and fuses
     the pools into the producing conv (arg-max map for the backward); 'bf16-full' writes everything as round 1 did.
-    Same arithmetic, so objective, gradient and trajectories agree bit for bit.  Tile configurations 0 and 1 pool in the
+    Same arithmetic, so objective, gradient and trajectories agree bit for bit.  Tile configurations 0, 1 and 3 pool in the
     epilogue (forced: at every layer and size, clipped windows of the odd 75x100 included; auto: where the launch is big
     enough, e.g. conv1_2 / conv2_2 at 512^2); configuration 2 and shapes that cannot fuse keep the separate pool kernels."""
     if size == (512, 512) and conv16_cfg in ('1', '2'):
@@ -185,7 +185,7 @@ def test_lean_bf16_data_flow_is_bit_identical_to_the_full_one(size, conv16_cfg):
     for name in ('conv1_1', 'conv3_1', 'conv5_1'):
         assert np.array_equal(lean.engine.get_blob(name), full.engine.get_blob(name))
     full.engine.get_blob('conv1_2')
-    if conv16_cfg in ('0', '1') or (conv16_cfg == 'auto' and size == (512, 512)):
+    if conv16_cfg in ('0', '1', '3') or (conv16_cfg == 'auto' and size == (512, 512)):
         with pytest.raises(st2.StError, match='not materialised'):
             lean.engine.get_blob('conv1_2')
     for _ in range(3):
