@@ -117,14 +117,23 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 // QUAD = true : W % 4 == 0 -- activation rows staged as aligned quads (40 floats, x0-4 .. x0+35), 16-byte epilogue accesses.
 // QUAD = false: any W     -- one staged row = one dword LDS-DMA piece of 64 lanes (x0-1 .. x0+62, 34 used; the row part of
 //                the address is scalar, the lane part is computed once), 8-byte (W even) or 4-byte epilogue accesses.
-template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false>
+// H4 = true (WM = 2, TG = 1): FOUR waves, 64 channels x 4 rows x 32 columns: wave (m, ph) keeps positions 8 ph .. 8 ph + 7 of
+//                channel slice m -- 128 accumulator registers, so TWO workgroups share a CU (two waves per SIMD that belong to
+//                DIFFERENT workgroups: no barrier couples them, and one workgroup's prologue / epilogue runs under the other's
+//                MFMAs).  For layers whose K loop is short (conv1_2: 8 chunks) the epilogue of the one-wave-per-SIMD kernels
+//                is ~40 % of a workgroup's time and nothing overlaps it.  Epilogue exchange as W8 (partner = wave ^ 2), the
+//                exchange buffer is the dead V images.
+template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false, bool H4 = false>
 __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
-    static_assert(WM * TG == 4 && (TG == 1 || TG == 2), "4 waves");
+    static_assert(H4 || (WM * TG == 4 && (TG == 1 || TG == 2)), "4 waves");
     static_assert(!PS || (WM == 2 && TG == 2), "position split: 2 channel slices x 2 position halves");
     static_assert(!W8 || (WM == 4 && TG == 1 && QUAD && !PS), "eight waves: 4 channel slices x 2 position halves, aligned widths");
+    static_assert(!H4 || (WM == 2 && TG == 1 && QUAD && !PS && !W8), "half tile: 2 channel slices x 2 position halves, aligned widths");
+    constexpr bool RS = W8 || H4;                        // accumulator ROWS of a channel slice are finished by two partner waves
     constexpr int NW = W8 ? 8 : 4;                       // waves per workgroup
-    constexpr bool SPLIT = PS || W8;                     // the 16 positions are split over two waves
+    constexpr int PARTNER = W8 ? 4 : 2;                  // RS: wave ^ PARTNER holds the other position half of the same channel slice
+    constexpr bool SPLIT = PS || RS;                     // the 16 positions are split over two waves
     constexpr int BM = 32 * WM;
     constexpr int PROWS = 4 * TG;                        // pixel rows per block
     constexpr int IN_ROWS = PROWS + 2;
@@ -138,14 +147,16 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 
     __shared__ __attribute__((aligned(16))) float raw_s[2][RAW];
     __shared__ __attribute__((aligned(16))) float v_s[2][TG][WN_V];
-    __shared__ __attribute__((aligned(16))) float x8_s[W8 ? 8 * 8 * 64 * 4 : 4];     // W8: partial outputs for the partner, [wave][row][lane][4]
+    __shared__ __attribute__((aligned(16))) float x8_own[W8 ? 8 * 8 * 64 * 4 : 4];     // W8: partial outputs for the partner, [wave][row][lane][4]
+    static_assert(!H4 || 4 * 8 * 64 * 4 <= 2 * TG * WN_V, "H4: the exchange buffer fits the V images");
+    float* const x8_s = H4 ? &v_s[0][0][0] : x8_own;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // PS: wave_g is the position half in the main loop and the tile group the wave finishes in the epilogue
-    const int wave_m = W8 ? (wave & 3) : wave / TG, wave_g = W8 ? 0 : wave % TG;
-    const int ph = W8 ? wave >> 2 : wave_g;              // position half (SPLIT builds)
+    const int wave_m = W8 ? (wave & 3) : H4 ? (wave & 1) : wave / TG, wave_g = RS ? 0 : wave % TG;
+    const int ph = W8 ? wave >> 2 : H4 ? wave >> 1 : wave_g;              // position half (SPLIT builds)
 
     // XCD-aware bijective block -> tile map, pixel tile fastest: the co-resident blocks of one XCD work on the
     // same channel slice of U (the dominant stream) and on neighbouring pixel tiles.
@@ -265,20 +276,20 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         if constexpr (SPLIT) asm volatile("" : "+v"(ua[set][0]), "+v"(ua[set][1]));
         else asm volatile("" : "+v"(ua[set][0]), "+v"(ua[set][1]), "+v"(ua[set][2]), "+v"(ua[set][3]));
     };
-    constexpr int NACC = W8 ? 8 : 16;   // 32x32 accumulators per wave
+    constexpr int NACC = RS ? 8 : 16;   // 32x32 accumulators per wave
     constexpr int NBQ = NACC / 4;
     f32x4 bq[2][NBQ];                   // B operands of two k-pairs, four positions per quad (PS: [tile group][quad of the half])
     auto b_fetch = [&](int buf, int kpl, int set) {
 #pragma unroll
         for (int pg = 0; pg < NBQ; ++pg) {
             const float* vimg = PS ? v_s[buf][pg >> 1] : v_s[buf][wave_g];
-            const int quad = PS ? 2 * ph + (pg & 1) : (W8 ? 2 * ph + pg : pg);
+            const int quad = PS ? 2 * ph + (pg & 1) : (RS ? 2 * ph + pg : pg);
             bq[set][pg] = *reinterpret_cast<const f32x4*>(vimg + ((kpl * 4 + quad) * 64 + lane) * 4);
         }
     };
     // one wait for the rest of a B set (its first quad is awaited by the k-pair's first MFMA) instead of one per quad
     auto b_pin = [&](int set) {
-        if constexpr (W8) asm volatile("" : "+v"(bq[set][1]));
+        if constexpr (RS) asm volatile("" : "+v"(bq[set][1]));
         else asm volatile("" : "+v"(bq[set][1]), "+v"(bq[set][2]), "+v"(bq[set][3]));
     };
 
@@ -393,7 +404,8 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         }
         __syncthreads();
     }
-    if constexpr (W8) {
+    if constexpr (RS) {
+        if constexpr (H4) __syncthreads();                     // every wave is done with the V images (the exchange buffer)
 #pragma unroll
         for (int el = 0; el < 8; ++el) {                       // the rows the partner finishes
             float y[4];
@@ -404,11 +416,11 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         __syncthreads();
     }
     auto out_xf = [&](int e, float& y00, float& y01, float& y10, float& y11) {
-        if constexpr (W8) {                                    // e = row index WITHIN this wave's half (0..7)
+        if constexpr (RS) {                                    // e = row index WITHIN this wave's half (0..7)
             float y[4];
             if (ph == 0) partial_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, e, y);
             else partial_out(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, e, y);
-            const float4 o = *reinterpret_cast<const float4*>(x8_s + (((wave ^ 4) * 8 + e) * 64 + lane) * 4);
+            const float4 o = *reinterpret_cast<const float4*>(x8_s + (((wave ^ PARTNER) * 8 + e) * 64 + lane) * 4);
             y00 = y[0] + o.x; y01 = y[1] + o.y; y10 = y[2] + o.z; y11 = y[3] + o.w;
         } else if constexpr (PS) {
             float y[4];
@@ -510,10 +522,10 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     const bool live = gx4 < a.W && gy < a.H;
     const int mw = mt * BM + wave_m * 32 + 4 * khalf;
     const unsigned pix = live ? (unsigned)gy * a.W + gx4 : 0u;
-    constexpr int NEB = W8 ? 2 : 4;                         // W8: this wave finishes accumulator rows 8 ph .. 8 ph + 7
+    constexpr int NEB = RS ? 2 : 4;                         // W8 / H4: this wave finishes accumulator rows 8 ph .. 8 ph + 7
 #pragma unroll
     for (int ebl = 0; ebl < NEB; ++ebl) {
-        const int eb = W8 ? 2 * ph + ebl : ebl;
+        const int eb = RS ? 2 * ph + ebl : ebl;
         const int mb = mw + 8 * eb;                         // rows mb .. mb+3 (e = 4 eb + 0..3)
         unsigned off[4];
         float4 mk[4], ij[4];
@@ -589,6 +601,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_ps64x256(const WinoKA
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_ps64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1, true, true>(a); }
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_w8_128x128(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, true>(a); }
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_w8_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1, true, false, true>(a); }
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true>(a); }
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 1, 1, true, false, false, true>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1>(a); }
 
@@ -626,7 +640,9 @@ int conv_wino_splits(int K, int M, int H, int W)
     int v = wino_default_variant(M, W);
     if (v == 3 && W % 4 != 0) v = 1;
     if (v == 6 && W % 4 != 0) v = 0;
-    const int bm = wino_variant_small(v) ? 64 : 128, prows = bm == 64 ? 8 : 4;
+    if ((v == 8 || v == 9) && W % 4 != 0) v = 1;
+    const bool half = v == 8 || v == 9;
+    const int bm = (wino_variant_small(v) || half) ? 64 : 128, prows = wino_variant_small(v) ? 8 : 4;
     const long long nblk = (long long)((W + 31) / 32) * ((H + prows - 1) / prows) * ((M + bm - 1) / bm);
     const int nch = K / WN_CH;
     int sp = 1;
@@ -650,7 +666,8 @@ bool conv_wino_ok(int K, int M, int H, int W)
 // variant: 0 = 128 channels x 4x32 pixels, 1 = 64 channels x 8x32 pixels (tile groups split over the waves),
 // 3 = 64 channels x 8x32 pixels with the POSITIONS split over the waves (half the U stream), -1 = choose;
 // 6 = 128 channels x 4x32 pixels with EIGHT waves (two per SIMD, positions split between the partners);
-// 2 / 5 / 4 / 7 = 0 / 1 / 3 / 6 with cycle stamps (diagnostic builds).
+// 8 = 64 channels x 4x32 pixels, positions split between two waves, two workgroups per CU;
+// 2 / 5 / 4 / 7 / 9 = 0 / 1 / 3 / 6 / 8 with cycle stamps (diagnostic builds).
 // p.wpack = the Winograd pack (pack_wino_weights_*); p.bias may be any length >= M
 static int wino_default_variant(int M, int W)
 {
@@ -662,7 +679,13 @@ static int wino_default_variant(int M, int W)
     if (ps && W % 4 == 0) return 3;       // the any-width build of the position split would spill (it is not built)
     const char* w8 = getenv("ST2_WINO_W8");                  // measured (profiles/r02_d_*): main loop 2 % slower, epilogue 25 % faster,
     if (w8 && *w8 == '1' && W % 4 == 0 && pad128 <= pad64) return 6;   // layer times within 1 % of variant 0 -- off unless asked for
-    return pad64 < pad128 ? 1 : 0;
+    if (pad64 < pad128) {
+        // <= 64 useful channels per 128: the half tile with two workgroups per CU where the width allows it (measured,
+        // profiles/r02_v_*: conv1_2 -10 %, conv2_1 dgrad -8 % against variant 1; within 3 % of variant 0 elsewhere)
+        const char* h4 = getenv("ST2_WINO_H4");
+        return (W % 4 == 0 && !(h4 && *h4 == '0')) ? 8 : 1;
+    }
+    return 0;
 }
 static bool wino_variant_small(int variant) { return variant == 1 || variant == 3 || variant == 4 || variant == 5; }
 
@@ -674,9 +697,10 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     if (variant < 0) variant = wino_default_variant(p.M, p.W);
     if (variant == 3 && !quad) variant = 1;
     if (variant == 6 && !quad) variant = 0;
-    if (variant > 7) return hipErrorInvalidValue;
-    const bool small = wino_variant_small(variant);
-    const int bm = small ? 64 : 128, prows = small ? 8 : 4;
+    if ((variant == 8 || variant == 9) && !quad) variant = 1;
+    if (variant > 9) return hipErrorInvalidValue;
+    const bool small = wino_variant_small(variant), half = variant == 8 || variant == 9;
+    const int bm = (small || half) ? 64 : 128, prows = small ? 8 : 4;
     WinoKArgs k{};
     k.in = p.in; k.upack = reinterpret_cast<const float4*>(p.wpack); k.bias = p.bias; k.out = p.out;
     k.mask_src = p.mask_src; k.inject = p.inject;
@@ -693,7 +717,7 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
         const int sp = conv_wino_splits(p.K, p.M, p.H, p.W);
         if (sp > 1 && p.scratch_floats >= (size_t)sp * p.M * p.H * p.W) { k.splits = sp; k.scratch = p.scratch; }
     }
-    const bool stamped = variant == 2 || variant == 4 || variant == 5 || variant == 7;
+    const bool stamped = variant == 2 || variant == 4 || variant == 5 || variant == 7 || variant == 9;
     if (stamped && (!quad || k.splits > 1)) return hipErrorInvalidValue;      // the stamped builds are quad-only, one pass
     if (k.splits > 1 && p.pool_out) return hipErrorInvalidValue;              // the caller asks conv_wino_can_pool() first
     const dim3 g((unsigned)(nblk * k.splits)), b(256);
@@ -705,6 +729,8 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     case 4: conv3x3_wino_f32_ps64x256_stamped<<<g, b, 0, s>>>(k); break;
     case 6: conv3x3_wino_f32_w8_128x128<<<g, dim3(512), 0, s>>>(k); break;
     case 7: conv3x3_wino_f32_w8_128x128_stamped<<<g, dim3(512), 0, s>>>(k); break;
+    case 8: conv3x3_wino_f32_h4_64x128<<<g, b, 0, s>>>(k); break;
+    case 9: conv3x3_wino_f32_h4_64x128_stamped<<<g, b, 0, s>>>(k); break;
     default: conv3x3_wino_f32_64x256_stamped<<<g, b, 0, s>>>(k); break;
     }
     hipError_t e = hipGetLastError();

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 F32 = np.float32
 
 
-@pytest.fixture(params=['auto', '0', '1', '3', '6'])
+@pytest.fixture(params=['auto', '0', '1', '3', '6', '8'])
 def wino_cfg(request):
     """ST2_WINO_CFG: 0 = 128 channels x 4x32 pixels per workgroup, 1 = 64 channels x 8x32 pixels, 3 = 64 channels x 8x32
     pixels with the transform-domain positions split over the wave pairs (any-width shapes fall back to 1), 6 = 128 channels x

@@ -486,7 +486,7 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     // from a cycle-bound loop (MI355X_MICROARCH.md, DVFS give-back)
     const bool zero_in = getenv("ST2_BENCH_ZERO") && *getenv("ST2_BENCH_ZERO") == '1';
     for (auto& x : hin) x = zero_in ? 0.f : rnd();
-    const bool wino = cfg >= 100;      // 100: choose, 101: 128 ch x 4x32 px, 102: 64 ch x 8x32 px, 104: 64 ch x 8x32 px position-split, 107: 128 ch x 4x32 px with 8 waves; 103/106/105/108: those stamped
+    const bool wino = cfg >= 100;      // 100: choose, 101: 128 ch x 4x32 px, 102: 64 ch x 8x32 px, 104: 64 ch x 8x32 px position-split, 107: 128 ch x 4x32 px with 8 waves, 109: 64 ch x 4x32 px half tile (two workgroups per CU); 103/106/105/108/110: those stamped
     if (wino) {
         if (!conv_wino_ok(K, M, H, W)) return fail(ST_ERR_ARG, "shape not eligible for the Winograd kernel");
         pk.assign(wino_pack_floats(K, M), 0.f);
@@ -519,7 +519,7 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     }
     unsigned long long* dstamps = nullptr;
     const size_t max_blocks = (size_t)((W + 31) / 32) * ((H + 3) / 4) * (p.MPad / 64);
-    if (cfg == 6 || cfg == 103 || cfg == 105 || cfg == 106 || cfg == 108) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
+    if (cfg == 6 || cfg == 103 || cfg == 105 || cfg == 106 || cfg == 108 || cfg == 110) { HIP_TRY(hipMalloc((void**)&dstamps, max_blocks * 16)); HIP_TRY(hipMemset(dstamps, 0, max_blocks * 16)); p.stamps = dstamps; }
     hipStream_t s;
     HIP_TRY(hipStreamCreate(&s));
     auto launch = [&]() { return wino ? launch_conv3x3_wino_cfg(p, cfg - 101, s) : launch_conv3x3_cfg(p, cfg, s); };

@@ -13,8 +13,8 @@ for name, cin, cout, div in LAYERS:
     for mode, (K, M) in (('fwd', (cin, cout)), ('bwd', (cout, cin))):
         fl = 2.0 * 9 * K * M * hw * hw
         out = []
-        for cfg in (101, 102, 107, 100):
+        for cfg in (101, 102, 109, 100):
             ms = ctypes.c_double(); used = ctypes.c_int()
             rc = lib.st_bench_conv(0, K, M, hw, hw, cfg, 1 if mode == 'bwd' else 0, ITERS, ctypes.byref(ms), ctypes.byref(used))
             out.append('%7.3f ms %6.1f TF/s' % (ms.value, fl / ms.value / 1e9) if rc == 0 else '      (not eligible)   ')
-        print('%-8s %s K=%-3d M=%-3d %4dx%-4d wino 128x(4x32): %s | 64x(8x32): %s | 128x(4x32) 8 waves: %s | auto (+split-K): %s' % (name, mode, K, M, hw, hw, out[0], out[1], out[2], out[3]), flush=True)
+        print('%-8s %s K=%-3d M=%-3d %4dx%-4d wino 128x(4x32): %s | 64x(8x32): %s | 64x(4x32) half, 2 WG/CU: %s | auto (+split-K): %s' % (name, mode, K, M, hw, hw, out[0], out[1], out[2], out[3]), flush=True)
