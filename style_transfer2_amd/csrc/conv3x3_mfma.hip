@@ -359,9 +359,11 @@ __device__ __forceinline__ void conv3x3_body(const ConvKArgs& a)
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += ij[e];
                 }
+                if (a.out) {                         // optional: the bf16 feature path may want the bf16 copy only
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (FULL || mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[e];
+                    for (int e = 0; e < 8; ++e)
+                        if (FULL || mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[e];
+                }
                 if (a.out16) {
                     // rows mbase..+3 and mbase+8..+11: two groups of 4 consecutive channels -> two 8-byte stores
                     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -411,6 +413,7 @@ static hipError_t run(const ConvProblem& p, int BM, int ROWS, int CCK, conv_kern
     k.in = p.in; k.wpack = p.wpack; k.bias = p.bias; k.out = p.out;
     k.mask_src = p.mask_src; k.inject = p.inject;
     if (p.out16 && p.M % 8 != 0) return hipErrorInvalidValue;
+    if (!p.out && (style || !p.out16)) return hipErrorInvalidValue;       // nothing to write
     k.out16 = style ? nullptr : p.out16;
     k.K = p.K; k.M = p.M; k.MPad = p.MPad; k.H = p.H; k.W = p.W;
     k.nch = (p.K + CCK - 1) / CCK;

@@ -297,6 +297,24 @@ static bool blob_active(const st_ctx* c, int b)
     return false;
 }
 
+// Will the style term of blob b (a style layer) run entirely on the blob's bf16 copy (gram16.hip + style16.hip)?  Decided from
+// shapes only, so that the forward (which may then skip the fp32 blob) and the objective agree.
+static bool style_runs16(const st_ctx* c, const ActSet& a, int b)
+{
+    if (!c->bf16 || c->tile.on || b < 1 || !c->topo[b - 1].is_conv) return false;
+    const int C = a.C[b], hw = a.h[b] * a.w[b];
+    return conv16_ok(c, C) && style_grad16_ok(C, (size_t)hw) && C % 8 == 0 && hw % 64 == 0 && gram16_ok(C, hw, gram_plan16(C, hw));
+}
+
+// lean evaluation: does anything read blob b in fp32?  Content / deep-dream terms do (layer_elem_k); a style term only when
+// its Gram / gradient cannot run on the bf16 copy.
+static bool blob_needs32(const st_ctx* c, const ActSet& a, int b)
+{
+    for (const ActiveLayer& al : c->active)
+        if (al.blob == b && (al.c || al.d || (al.s && !style_runs16(c, a, b)))) return true;
+    return false;
+}
+
 // `lean` (bf16 objective evaluations only): a conv blob whose only consumers are bf16 convs / a fused pool is not written
 // in fp32 at all, and a pool that follows such a conv is computed in that conv's epilogue (bf16 pooled copy + arg-max map).
 static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean = false)
@@ -324,9 +342,9 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool le
                 p.out16 = next16 ? a.data16[i] : nullptr;
                 p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
                 double bytes = px * (2.0 * L.cin + 4.0 * L.cout + (next16 ? 2.0 * L.cout : 0.0));
-                if (lean && !blob_active(c, i) && i < last) {
+                if (lean && !blob_needs32(c, a, i) && i < last) {
                     const bool next_pool = !c->topo[i].is_conv;
-                    if (next_pool && conv16_can_pool(p)) {
+                    if (next_pool && !blob_active(c, i) && conv16_can_pool(p)) {       // (a weighted blob gets an injected diff: classic pool backward)
                         // the pool rides on this launch: pooled bf16 copy for the conv after it, arg-max map for the backward
                         const int pb = i + 1, pc = a.C[pb];
                         const size_t phw = (size_t)a.h[pb] * a.w[pb];
@@ -363,6 +381,8 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool le
                       HIP_TRY(launch_conv3x3_wino(p, c->stream));
                   }
                   else { if (next16 && L.cout % 8 == 0) { p.out16 = a.data16[i]; packed = true; }      // the epilogue writes the bf16 copy too
+                         // lean: conv1_1's fp32 blob is written only if something reads it (conv1_2, the ReLU mask and a style term take the copy)
+                         if (lean && packed && conv_next16 && i < last && !blob_needs32(c, a, i)) { p.out = nullptr; a.has32[i] = 0; }
                          HIP_TRY(launch_conv3x3(p, c->stream)); } }
                 if (next16 && !packed) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
             }
@@ -652,6 +672,7 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
             }
             // bf16 path: the Gram of the CURRENT features is taken from their bf16 copy (the style targets stay fp32 Grams)
             const bool f16_fresh = c->bf16 && !c->tile.on && a.data16[b] && b >= 1 && c->topo[b - 1].is_conv && style_grad16_ok(C, (size_t)hw);
+            if (!a.has32[b] && !(a.data16[b] && style_runs16(c, a, b))) return fail(ST_ERR_STATE, "internal: style blob %d has neither an fp32 nor a usable bf16 copy", b);
             ST_TRY(gram_into(c, a.data[b], C, hw, c->style_gram[b], c->dbuf, conv_mpad(C), part + 4 * kMaxPartials, &cnt[4], f16_fresh ? a.data16[b] : nullptr));
             const float c2 = (float)(2.0 / ((double)C * C * (double)n));
             // bf16 path: F from its bf16 copy on the bf16 matrix cores (written by this forward: b <= last, a style layer)

@@ -182,8 +182,15 @@ def test_lean_bf16_data_flow_is_bit_identical_to_the_full_one(size, conv16_cfg):
     l1, g1 = lean.opfunc()
     l2, g2 = full.opfunc()
     assert l1 == l2 and np.array_equal(g1, g2)
-    for name in ('conv1_1', 'conv3_1', 'conv5_1'):
-        assert np.array_equal(lean.engine.get_blob(name), full.engine.get_blob(name))
+    for name, div in (('conv1_1', 1), ('conv3_1', 4), ('conv5_1', 16)):
+        # a style-only blob whose Gram and gradient run on its bf16 copy (whole 64-pixel steps) has no fp32 copy in the lean flow;
+        # the last blob (conv5_1: the top of the backward chain) always has one
+        hw = -(-size[0] // div) * -(-size[1] // div)
+        if name != 'conv5_1' and hw % 64 == 0:
+            with pytest.raises(st2.StError, match='not materialised'):
+                lean.engine.get_blob(name)
+        else:
+            assert np.array_equal(lean.engine.get_blob(name), full.engine.get_blob(name))
     full.engine.get_blob('conv1_2')
     if conv16_cfg in ('0', '1', '3') or (conv16_cfg == 'auto' and size == (512, 512)):
         with pytest.raises(st2.StError, match='not materialised'):
