@@ -70,6 +70,8 @@ struct Conv16KArgs {
     unsigned short* pool16; float* pool32; unsigned char* amap; int pool_h, pool_w;
     int K, M, MPad, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
     unsigned in_bytes, w_bytes;
+    // fused style term (data-gradient launches): out = mask(conv) + D' @ F, F = the bf16 copy of the blob this launch differentiates
+    const unsigned short* s_in16; const unsigned short* s_wpack; int s_nch; unsigned s_in_bytes, s_w_bytes;
 };
 
 template <int BM, int ROWS, int WAVES_M, int WAVES_N>
@@ -212,7 +214,8 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     // the (wave-uniform) fast path of a tile that lies inside M.
     const int gx = x0 + l31;
     const bool colv = gx < a.W;
-    const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr, has_mask16 = a.mask16 != nullptr;
+    const bool fuse_style = a.s_nch > 0;                         // the ReLU mask is then applied in registers, before the style chunks
+    const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr, has_mask16 = a.mask16 != nullptr && !fuse_style;
     const bool pooling = TN % 2 == 0 && (a.pool16 || a.pool32 || a.amap);
     const bool full_m = m0 + BM <= a.M;                          // uniform: no channel of this tile is padding
     unsigned pixj[TN];
@@ -239,6 +242,80 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                     mk[h][j][g] = *reinterpret_cast<const uint2*>(a.mask16 + ((size_t)(mg >> 3) * plane + pixj[j]) * 8 + (mg & 7));
                 }
     };
+    if (fuse_style) {
+        // ---- fused style gradient (worker.py:262-269 behind the ranged backward of :100-106): this launch's output is the diff of a
+        // style layer's blob, diff = mask(dgrad) + sw / norm * c2 * (D @ F).  The conv sum is masked in registers, then C / 16 more
+        // chunks accumulate D' @ F on top: A = D' = D scaled, as hi + lo bf16 terms (slab [hl][k half][BM] per 16 channels, packed by
+        // style16_pack_d_scaled_k), B = the blob's own bf16 copy, staged as the conv's activation tile (its centre tap is the pixel).
+        // Saves the separate style-gradient kernel, its fp32 output and this epilogue's read of it.
+        if (a.mask16) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                uint2 mk[2][TN][2];
+                load_masks(i, mk);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const uint2 m2 = mk[h][j][g];
+                            acc[i][j][8 * h + 4 * g + 0] = (m2.x & 0xffffu) ? acc[i][j][8 * h + 4 * g + 0] : 0.0f;
+                            acc[i][j][8 * h + 4 * g + 1] = (m2.x >> 16) ? acc[i][j][8 * h + 4 * g + 1] : 0.0f;
+                            acc[i][j][8 * h + 4 * g + 2] = (m2.y & 0xffffu) ? acc[i][j][8 * h + 4 * g + 2] : 0.0f;
+                            acc[i][j][8 * h + 4 * g + 3] = (m2.y >> 16) ? acc[i][j][8 * h + 4 * g + 3] : 0.0f;
+                        }
+            }
+        }
+        constexpr int SW_QUADS = 4 * BM;                         // [hl][k half][BM]
+        constexpr int SW_INSTR = SW_QUADS / 64;
+        static_assert(SW_QUADS <= W_QUADS, "the style slab fits the weight region");
+        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.s_wpack, 0, a.s_w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)a.s_in16, 0, a.s_in_bytes, 0x00020000);
+        auto s_dma = [&](int ch, int buf) {
+            uint4* dst = smem + buf * BUF_Q;
+#pragma unroll
+            for (int t = 0; t < (SW_INSTR + 3) / 4; ++t) {
+                const int i = wave + 4 * t;
+                if (SW_INSTR % 4 == 0 || i < SW_INSTR) {
+                    const int q = i * 64 + lane, r = q / BM, m = q - r * BM;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)(dst + i * 64), 16, ((unsigned)(ch * 4 + r) * a.MPad + m0 + m) * 16u, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < I_PER_WAVE; ++u) {
+                const int j = wave + 4 * u;
+                if (I_INSTR % 4 == 0 || j < I_INSTR) {
+                    const unsigned coff = (unsigned)ch * 2u * plane * 16u;
+                    const unsigned vo = ioff[u] == kOOB16 ? kOOB16 : ioff[u] + coff;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)(dst + W_QUADS + j * 64), 16, vo, 0, 0, 0);
+                }
+            }
+        };
+        __syncthreads();                                         // every wave has left the main loop's buffers
+        s_dma(0, 0);
+        for (int ch = 0; ch < a.s_nch; ++ch) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                     // chunk ch has landed; the other buffer is free again
+            if (ch + 1 < a.s_nch) s_dma(ch + 1, (ch + 1) & 1);
+            const uint4* base = smem + (ch & 1) * BUF_Q;
+            bf16x8 ahi[TM], alo[TM], bq[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ahi[i] = __builtin_bit_cast(bf16x8, base[khalf * BM + wave_m * (TM * 32) + i * 32 + l31]);
+                alo[i] = __builtin_bit_cast(bf16x8, base[(2 + khalf) * BM + wave_m * (TM * 32) + i * 32 + l31]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[j] = __builtin_bit_cast(bf16x8, base[b_off + (j + 1) * PXW + 1]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bq[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bq[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
     if (MK_ALL && has_mask16) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) load_masks(i, mk16[i]);
@@ -420,6 +497,12 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     const unsigned long long in_bytes = 16ull * ((p.K + 7) / 8) * p.H * p.W, w_bytes = 2ull * conv16_pack_elems(p.K, p.M);
     const unsigned long long out_bytes = 4ull * p.M * p.H * p.W;
     if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull || out_bytes >= 0xfffffff0ull) return hipErrorInvalidValue;
+    if (p.s_in16 || p.s_wpack16) {          // fused style term: a data-gradient launch whose output blob has M % 16 == 0 channels
+        const unsigned long long s_in = 16ull * (p.M / 8) * p.H * p.W, s_w = 2ull * style_fuse_pack_elems(p.M, p.MPad);
+        if (!p.s_in16 || !p.s_wpack16 || p.M % 16 != 0 || p.relu || p.bias || p.mask_src || pools || s_in >= 0xfffffff0ull || s_w >= 0xfffffff0ull) return hipErrorInvalidValue;
+        if ((reinterpret_cast<uintptr_t>(p.s_in16) & 15) != 0 || (reinterpret_cast<uintptr_t>(p.s_wpack16) & 15) != 0) return hipErrorInvalidValue;
+        k.s_in16 = p.s_in16; k.s_wpack = p.s_wpack16; k.s_nch = p.M / 16; k.s_in_bytes = (unsigned)s_in; k.s_w_bytes = (unsigned)s_w;
+    }
     k.in_bytes = (unsigned)in_bytes; k.w_bytes = (unsigned)w_bytes;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;

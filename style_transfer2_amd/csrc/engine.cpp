@@ -120,6 +120,10 @@ struct st_ctx {
     size_t max_blob = 0;
     float *gram_slabs = nullptr, *gram_fold = nullptr, *dbuf = nullptr;
     unsigned short* d16 = nullptr; size_t d16_cap = 0;            // bf16 path: hi/lo operand image of D (style16.hip)
+    // bf16 path, style term fused into the data-gradient conv above the style blob: per blob the scaled hi/lo image of D (kept until
+    // that conv has run) and, during one objective evaluation, the operands handed to backward_chain
+    std::vector<unsigned short*> sfuse_w; std::vector<size_t> sfuse_cap;
+    std::vector<const unsigned short*> sf_in, sf_w;
     float* conv_scratch = nullptr; size_t conv_scratch_cap = 0;       // split-K partial sums of Winograd launches
     // hipGraph replay of the steady-state Adam step (launch-bound regime: small images)
     unsigned long long epoch = 0;                  // bumped by every API call that can change what a step launches
@@ -315,6 +319,15 @@ static bool blob_needs32(const st_ctx* c, const ActSet& a, int b)
     return false;
 }
 
+// May the style gradient of blob b ride on the data-gradient conv of the layer above it (conv3x3_mfma_bf16.hip, fused style term)?
+static bool style_fuse_ok(const st_ctx* c, const ActSet& a, int b, int last)
+{
+    const char* e = getenv("ST2_STYLE_FUSE");           // read per evaluation: the tests compare both flows in one process
+    if ((e && *e == '0') || !style_runs16(c, a, b) || b + 1 > last || a.C[b] % 32 != 0) return false;
+    const Layer& up = c->topo[b];                       // layer b + 1: consumes blob b
+    return up.is_conv && up.loaded && conv16_ok(c, up.cout) && up.cin == a.C[b];
+}
+
 // `lean` (bf16 objective evaluations only): a conv blob whose only consumers are bf16 convs / a fused pool is not written
 // in fp32 at all, and a pool that follows such a conv is computed in that conv's epilogue (bf16 pooled copy + arg-max map).
 static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean = false)
@@ -507,11 +520,16 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
                 p.in16 = cur16; p.wpack16 = L.w16_bwd; p.bias = nullptr; p.out = dst; p.out16 = below16 ? dst16 : nullptr;
                 p.mask_src = mask_src; p.inject = inject;
                 if (lean && mask_src && a.data16[below]) { p.mask16 = a.data16[below]; p.mask_src = nullptr; }
+                const bool fused = below >= 1 && (size_t)below < c->sf_w.size() && c->sf_w[below] != nullptr;
+                if (fused) {                // the style gradient of blob `below` rides on this launch: out = mask(conv) + D' @ F (+ inject)
+                    p.s_in16 = c->sf_in[below]; p.s_wpack16 = c->sf_w[below];
+                    if (mask_src) { p.mask16 = a.data16[below]; p.mask_src = nullptr; }      // the mask is applied in registers, from the bf16 copy
+                }
                 if (p.mask_src && !a.has32[below]) return fail(ST_ERR_STATE, "internal: mask blob %d missing", below);
                 if (lean && below16) p.out = nullptr;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
-                ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px,
-                             px * (2.0 * L.cout + (p.out ? 4.0 : 0.0) * L.cin + (p.out16 ? 2.0 : 0.0) * L.cin + (mask_src ? (p.mask16 ? 2.0 : 4.0) : 0.0) * L.cin));
+                ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px + (fused ? 2.0 * L.cin * L.cin * px : 0.0),
+                             px * (2.0 * L.cout + (fused ? 2.0 : 0.0) * L.cin + (p.out ? 4.0 : 0.0) * L.cin + (p.out16 ? 2.0 : 0.0) * L.cin + (mask_src ? (p.mask16 ? 2.0 : 4.0) : 0.0) * L.cin));
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
                 cur16 = below16 ? dst16 : nullptr;
                 cur = p.out ? dst : nullptr;
@@ -632,6 +650,7 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
 
     std::vector<const float*> inj(c->nb, nullptr);
     std::fill(c->cnt.begin(), c->cnt.end(), 0);
+    c->sf_in.assign(c->nb, nullptr); c->sf_w.assign(c->nb, nullptr);
     for (const ActiveLayer& al : c->active) {
         const int b = al.blob;
         const int C = a.C[b], hw = a.h[b] * a.w[b];
@@ -677,7 +696,9 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
             const float c2 = (float)(2.0 / ((double)C * C * (double)n));
             // bf16 path: F from its bf16 copy on the bf16 matrix cores (written by this forward: b <= last, a style layer)
             const bool s16 = c->bf16 && !c->tile.on && a.data16[b] && b >= 1 && c->topo[b - 1].is_conv && style_grad16_ok(C, (size_t)hw);
-            const int need = s16 ? style_grad16_blocks(C, (size_t)hw) : style_grad_blocks(C, a.h[b], a.w[b]);
+            // bf16 path, norm known: the gradient rides on the data-gradient conv above this blob; only its trace value is taken here
+            const bool fuse = want_grad && s16 && c->norm_valid[b * 3 + 1] && style_fuse_ok(c, a, b, last);
+            const int need = fuse ? style_s2_trace_blocks(C) : s16 ? style_grad16_blocks(C, (size_t)hw) : style_grad_blocks(C, a.h[b], a.w[b]);
             if (c->s2_cap[b] < need) { dfree(c->s2_part[b]); ST_TRY(dmalloc(&c->s2_part[b], need)); c->s2_cap[b] = need; }
             if (s16 && style_grad16_pack_elems(C) > c->d16_cap) {
                 dfree16(c->d16); c->d16_cap = 0;
@@ -691,7 +712,15 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
                 else HIP_TRY(launch_style_grad(c->dbuf, a.data[b], dst, c2, fused, al.sw, nrm + 1, accumulate, c->s2_part[b], &cnt[5], C, a.h[b], a.w[b], c->stream));
                 return ST_OK;
             };
-            if (c->norm_valid[b * 3 + 1]) {
+            if (fuse) {
+                const size_t pe = style_fuse_pack_elems(C, conv_mpad(C));
+                if (c->sfuse_cap[b] < pe) { dfree16(c->sfuse_w[b]); c->sfuse_cap[b] = 0; ST_TRY(dmalloc16(&c->sfuse_w[b], pe)); c->sfuse_cap[b] = pe; }
+                { ProfScope ps(c, P_MISC, 0, 4.0 * C * C + 2.0 * pe);
+                  HIP_TRY(launch_style_fuse_pack(c->dbuf, conv_mpad(C), C, conv_mpad(C), c2, al.sw, nrm + 1, c->sfuse_w[b], c->stream)); }
+                { ProfScope ps(c, P_STYLE_GRAD, 2.0 * C * C * (double)C, 12.0 * C * C);
+                  HIP_TRY(launch_style_s2_trace(c->dbuf, conv_mpad(C), c->style_gram[b], C, (double)C * hw, c2, c->s2_part[b], &cnt[5], c->stream)); }
+                c->sf_in[b] = a.data16[b]; c->sf_w[b] = c->sfuse_w[b];
+            } else if (c->norm_valid[b * 3 + 1]) {
                 ST_TRY(style_launch(c->inject[b], 1, wrote));
             } else {              // first evaluation: S unscaled -> norm -> saxpy (worker.py:265-269)
                 if (!c->stmp) ST_TRY(dmalloc(&c->stmp, c->max_blob));
@@ -703,7 +732,7 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
                 HIP_TRY(launch_scaled_accumulate(c->stmp, c->inject[b], al.sw, nrm + 1, wrote, n, c->stream));
             }
         }
-        inj[b] = c->inject[b];
+        inj[b] = (c->sf_w[b] && !wrote) ? nullptr : c->inject[b];          // (a fused style term writes nothing into the inject buffer)
     }
 
     const float* scd = nullptr;
@@ -712,7 +741,9 @@ static int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad
         if (last == 0) scd = inj[0];
         else {
             std::vector<const float*> below = inj;
-            ST_TRY(backward_chain(c, last, inj[last], below, &scd, lean));
+            const int rc = backward_chain(c, last, inj[last], below, &scd, lean);
+            c->sf_in.assign(c->nb, nullptr); c->sf_w.assign(c->nb, nullptr);      // (the ranged-backward entry points never fuse)
+            ST_TRY(rc);
         }
     }
 
@@ -912,6 +943,7 @@ int st_create(st_ctx** out, int device_id, const st_layer_desc* layers, int n_la
     c->inject.assign(c->nb, nullptr);
     c->layer_part.assign(c->nb, nullptr);
     c->s2_part.assign(c->nb, nullptr);
+    c->sfuse_w.assign(c->nb, nullptr); c->sfuse_cap.assign(c->nb, 0);
     c->s2_cap.assign(c->nb, 0);
     c->cnt.assign(c->nb * 6, 0);
     c->norm_valid.assign(c->nb * 3, 0);
@@ -950,6 +982,7 @@ int st_destroy(st_ctx* c)
     for (auto& p : c->inject) dfree(p);
     for (auto& p : c->layer_part) dfree(p);
     for (auto& p : c->s2_part) dfree(p);
+    for (auto& p : c->sfuse_w) dfree16(p);
     dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->gram_fold); dfree(c->dbuf); dfree16(c->d16); dfree(c->conv_scratch);
     dfree(c->tile.p1); dfree(c->tile.p2); dfree(c->tile.p3); dfree(c->tile.pd); dfree(c->tile.wgrad);
     dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->lb_part); dfree(c->hwc_dev);

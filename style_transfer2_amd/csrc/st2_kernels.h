@@ -77,7 +77,17 @@ struct Conv16Problem {
     unsigned short* pool16 = nullptr;       // bf16 channel-blocked pooled copy [M/8][ph][pw][8]
     float* pool32 = nullptr;                // fp32 pooled blob [M][ph][pw]
     unsigned char* amap = nullptr;          // [M/8][ph][pw][8] bytes: bits 0-1 arg-max slot (row-major in the window), bit 2 maximum > 0
+    // data-gradient, optional: the style gradient of the blob this launch differentiates rides on the launch,
+    //     out = mask(conv) + D' @ F        (D' = sw / norm * c2 * D as hi + lo bf16 terms: launch_style_fuse_pack; F = s_in16, M channels)
+    const unsigned short* s_in16 = nullptr; const unsigned short* s_wpack16 = nullptr;
 };
+// A-operand image of the scaled D for the fused style term: [M / 16][hl][k half][MPad] quads
+size_t style_fuse_pack_elems(int C, int MPad);
+hipError_t launch_style_fuse_pack(const float* D, int ld, int C, int MPad, float c2, float sw, const float* norm, unsigned short* A16, hipStream_t s);
+// partial sums of || c2 * D @ F ||^2 = c2^2 * n * sum_ij (D (D + A))_ij D_ij  (F F^T = n (D + A), n = C * hw): the trace value of the
+// style gradient without materialising it; *n_partial partials in `partial`
+int style_s2_trace_blocks(int C);
+hipError_t launch_style_s2_trace(const float* D, int ld, const float* A, int C, double n, float c2, float* partial, int* n_partial, hipStream_t s);
 bool conv16_can_pool(const Conv16Problem& p);
 // dx16 = pool backward of dy16 through the arg-max map (all channel-blocked, C % 8 == 0), ReLU mask of the pooled-from blob included
 hipError_t launch_maxpool_bwd_idx16(const unsigned short* dy16, const unsigned char* amap, unsigned short* dx16, int C, int H, int W, hipStream_t s);

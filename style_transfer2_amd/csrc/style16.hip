@@ -42,6 +42,84 @@ __global__ __launch_bounds__(256) void style16_pack_d_k(const float* __restrict_
     }
 }
 
+// The same image for the style term fused into the data-gradient conv (conv3x3_mfma_bf16.hip): one k-step = one chunk of that
+// kernel, Mp = the conv's padded channel count, and D is scaled by sw / norm * c2 BEFORE the split (the conv epilogue has no
+// per-term scaling): quad[((ks * 2 + hl) * 2 + half) * Mp + m].
+__global__ __launch_bounds__(256) void style16_pack_d_scaled_k(const float* __restrict__ D, int ld, int C, int Mp, float c2, float sw,
+                                                                const float* __restrict__ norm, unsigned short* __restrict__ A16)
+{
+    const int nq = (C / 16) * 2 * 2 * Mp;
+    const float coef = sw / *norm;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < nq; q += gridDim.x * 256) {
+        const int m = q % Mp;
+        const int r = q / Mp;
+        const int half = r & 1, hl = (r >> 1) & 1, ks = r >> 2;
+        s16_bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * half + j;
+            const float d = m < C ? coef * (D[(size_t)m * ld + k] * c2) : 0.0f;      // same association as style_grad16: coef * (c2 * .)
+            const __bf16 hi = (__bf16)d;
+            v[j] = hl ? (__bf16)(d - (float)hi) : hi;
+        }
+        *reinterpret_cast<s16_bf16x8*>(A16 + (size_t)q * 8) = v;
+    }
+}
+
+size_t style_fuse_pack_elems(int C, int MPad) { return (size_t)(C / 16) * 4 * MPad * 8; }
+
+hipError_t launch_style_fuse_pack(const float* D, int ld, int C, int MPad, float c2, float sw, const float* norm, unsigned short* A16, hipStream_t s)
+{
+    if (C % 16 != 0 || MPad < C) return hipErrorInvalidValue;
+    const int nq = (C / 16) * 4 * MPad;
+    style16_pack_d_scaled_k<<<(nq + 255) / 256, 256, 0, s>>>(D, ld, C, MPad, c2, sw, norm, A16);
+    return hipGetLastError();
+}
+
+// sum_ij (D (D + A))_ij D_ij, one wave per 32 x 32 tile of the product, on the fp32 matrix cores.  D and A are symmetric, so both
+// operands are read along rows: lane l (0..31) of k-half h holds D[i0 + l][2 kp + h] and (D + A)[j0 + l][2 kp + h].
+__global__ __launch_bounds__(64) void style_s2_trace_k(const float* __restrict__ D, int ld, const float* __restrict__ A, int C, float scale,
+                                                       float* __restrict__ partial)
+{
+    const int t1 = C / 32;
+    const int ti = blockIdx.x / t1, tj = blockIdx.x - ti * t1;
+    const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+    const float* drow = D + (size_t)(32 * ti + l31) * ld;
+    const float* grow_d = D + (size_t)(32 * tj + l31) * ld;
+    const float* grow_a = A + (size_t)(32 * tj + l31) * C;
+    s16_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (int k = 0; k < C; k += 4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(drow + k);
+        const float4 d4 = *reinterpret_cast<const float4*>(grow_d + k);
+        const float4 t4 = *reinterpret_cast<const float4*>(grow_a + k);
+        const float b0 = h ? d4.y + t4.y : d4.x + t4.x, b1 = h ? d4.w + t4.w : d4.z + t4.z;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4.y : a4.x, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4.w : a4.z, b1, acc, 0, 0, 0);
+    }
+    float ss = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = 32 * ti + (e & 3) + 8 * (e >> 2) + 4 * h, col = 32 * tj + l31;
+        ss += acc[e] * D[(size_t)row * ld + col];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if (lane == 0) partial[blockIdx.x] = ss * scale;
+}
+
+int style_s2_trace_blocks(int C) { return (C / 32) * (C / 32); }
+
+hipError_t launch_style_s2_trace(const float* D, int ld, const float* A, int C, double n, float c2, float* partial, int* n_partial, hipStream_t s)
+{
+    if (C % 32 != 0 || ld % 4 != 0 || (reinterpret_cast<uintptr_t>(D) & 15) != 0 || (reinterpret_cast<uintptr_t>(A) & 15) != 0) return hipErrorInvalidValue;
+    const int nb = style_s2_trace_blocks(C);
+    style_s2_trace_k<<<nb, 64, 0, s>>>(D, ld, A, C, (float)((double)c2 * (double)c2 * n), partial);
+    if (n_partial) *n_partial = nb;
+    return hipGetLastError();
+}
+
 struct Style16Args {
     const unsigned short* A16; const unsigned short* F16; float* out; const float* norm; float* partial;
     float c2, sw; int fused, accumulate;

@@ -219,6 +219,34 @@ def test_lean_bf16_with_weights_on_pools_and_pooled_convs(conv16_cfg):
         assert t1['loss'] == t2['loss'] and np.array_equal(i1, i2)
 
 
+@pytest.mark.parametrize('size', [(256, 320), (160, 224)])
+def test_style_term_fused_into_the_dgrad_conv_matches_the_separate_kernel(size, conv16_cfg, monkeypatch):
+    """From the second evaluation on (norms known) the style gradient of a conv blob rides on the data-gradient conv above it:
+    out = mask(conv) + D' @ F with D' = sw / norm * c2 * D as hi + lo bf16 terms in the conv's own accumulators, and the trace value
+    || c2 D F ||^2 comes from C x C matrices (c2^2 n <D (D + A), D>).  ST2_STYLE_FUSE=0 keeps the separate style16 kernel.  Same
+    loss (the forward is untouched); gradient and trace agree to what one bf16 rounding of the layer diffs allows.  Weights: style on
+    conv blobs that feed convs (fused), on one that feeds a pool and on the last blob (not fused), content on a fused style layer
+    (its injected diff stays)."""
+    weights = {'content': {'conv2_1': 0.05}, 'style': {'conv1_1': 1, 'conv1_2': 0.5, 'conv2_1': 1, 'conv3_1': 1, 'conv3_3': 0.7}, 'deepdream': {}}
+    topo = oracle.VGG19_TOPOLOGY[:9]
+    params = oracle.he_init_weights(topo, seed=5)
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('ST2_STYLE_FUSE', flag)
+        job = _bf16_job('bf16', size, weights, 'adam', topo, params)
+        job.opfunc()                                   # first evaluation: norms are captured, never fused
+        loss, grad = job.opfunc()
+        out[flag] = (loss, grad.copy(), dict(job.traces[-1].data))
+    (l1, g1, t1), (l0, g0, t0) = out['1'], out['0']
+    assert l1 == l0
+    assert rel_l2(g1, g0) <= 2e-3, rel_l2(g1, g0)
+    cos = float(np.vdot(g1, g0) / (np.linalg.norm(g1) * np.linalg.norm(g0)))
+    assert cos >= 0.99999, cos
+    assert list(t1) == list(t0)
+    for k in t0:
+        assert np.isclose(t1[k], t0[k], rtol=2e-4 if k.endswith('_s_grad') else 2e-3, atol=1e-12), (k, t1[k], t0[k])
+
+
 # ------------------------------------------------------------------ style gradient on the bf16 matrix cores (style16.hip)
 @pytest.mark.parametrize('C,h,w', [(64, 64, 96), (64, 50, 70), (128, 64, 64), (128, 37, 50), (256, 32, 48), (512, 24, 40), (192, 20, 28)])
 def test_style_gradient_on_the_bf16_matrix_cores_matches_rounded_operand_oracle(C, h, w):
