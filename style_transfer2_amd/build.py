@@ -26,6 +26,7 @@ SOURCES = (
     ('lbfgs.hip', ('-ffp-contract=off',)),
     ('style16.hip', ()),
     ('gram16.hip', ()),
+    ('conv3x3_dgrad_first.hip', ()),
     ('engine.cpp', ('-x', 'hip')),
 )
 HEADERS = ('st2_kernels.h', 'reduce.cuh', os.path.join('..', '..', 'include', 'st2.h'))

@@ -1,0 +1,202 @@
+// Data gradient of the FIRST conv (conv1_1: 64 -> 3 channels, pycaffe Convolution backward behind worker.py:100-106) on the
+// matrix cores.  With M <= 3 output channels the implicit GEMM of the other layers has nothing to tile, and a direct VALU kernel
+// (conv3x3_dgrad_smallM*) spends 27 M FMAs per pixel and input channel.  The sum factorises instead:
+//     dx[m][y][x] = sum_c sum_tap w[c][m][tap] dy[c][(y, x) - off(tap)]
+//                 = sum_tap Z[m, tap][(y, x) - off(tap)],        Z[r][p] = sum_c A[r][c] dy[c][p],  r = 9 m + tap, A[r][c] = w[c][m][tap]
+// Z is a 1x1 convolution from Cout channels to 9 M <= 27 (padded to 32) rows -- exactly one 32-row MFMA tile, K = Cout -- and the
+// second step is 9 M shifted adds per pixel out of LDS.  One workgroup = 8 x 32 output pixels: it takes Z on the 10 x 34 halo tile
+// (11 groups of 32 pixels spread over the 4 waves, operands straight from global memory into the MFMA's B registers: the diff is
+// read once, coalesced along x), parks the 27 rows in LDS and adds.  Bound: HBM (the diff of conv1_1's blob: 4 or 2 bytes per
+// element, 1.33x for the halo -- served by L2).  Every product and sum is fp32 (bf16 variant: exact bf16 products, fp32 sums).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include "st2_kernels.h"
+
+namespace st2 {
+
+typedef float df_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 df_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int DF_TH = 8, DF_TW = 32;                     // output pixels per workgroup
+constexpr int DF_HH = DF_TH + 2, DF_HW = DF_TW + 2;      // halo tile
+constexpr int DF_NPIX = DF_HH * DF_HW;                   // 340
+constexpr int DF_NG = (DF_NPIX + 31) / 32;               // 11 groups of 32 halo pixels
+constexpr int DF_ZS = DF_NG * 32 + 1;                    // padded row stride of Z in LDS
+constexpr int DF_ROWS = 27;
+
+// second step, shared by both variants: thread = one output pixel, 9 M shifted reads of Z
+template <int M>
+__device__ __forceinline__ void dgrad_first_gather(const float* z_s, float* __restrict__ dx, const float* __restrict__ inject,
+                                                   int x0, int y0, int H, int W)
+{
+    const int tid = threadIdx.x, px = tid & 31, py = tid >> 5;
+    const int gx = x0 + px, gy = y0 + py;
+    if (gx >= W || gy >= H) return;
+    const size_t plane = (size_t)H * W;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)      // source pixel (y - ky + 1, x - kx + 1) = halo (py + 2 - ky, px + 2 - kx)
+                acc += z_s[(m * 9 + ky * 3 + kx) * DF_ZS + (py + 2 - ky) * DF_HW + (px + 2 - kx)];
+        const size_t idx = (size_t)m * plane + (size_t)gy * W + gx;
+        dx[idx] = acc + (inject ? inject[idx] : 0.f);
+    }
+}
+
+// rows 0 .. 26 of one 32 x 32 accumulator tile (C/D map: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)) -> LDS
+__device__ __forceinline__ void dgrad_first_park(float* z_s, const df_f32x16& acc, int group, int lane)
+{
+    const int l31 = lane & 31, khalf = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * khalf;
+        if (row < DF_ROWS) z_s[row * DF_ZS + group * 32 + l31] = acc[e];
+    }
+}
+
+// fp32: dy [Cout][H][W], w (Cout, M, 3, 3); v_mfma_f32_32x32x2_f32, one k-pair = two channels
+template <int M>
+__global__ __launch_bounds__(256) void conv3x3_dgrad_first_f32(const float* __restrict__ dy, const float* __restrict__ w,
+                                                               float* __restrict__ dx, const float* __restrict__ inject,
+                                                               int Cout, int H, int W)
+{
+    __shared__ float z_s[DF_ROWS * DF_ZS];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * DF_TW, y0 = blockIdx.y * DF_TH;
+    const size_t plane = (size_t)H * W;
+    constexpr int KC = 32;                                   // k-pairs per chunk (64 channels)
+    // this wave's groups: wave, wave + 4, wave + 8
+    df_f32x16 acc[3];
+    int off[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        const int hp = (wave + 4 * t) * 32 + l31;
+        const int hy = hp / DF_HW, hx = hp - hy * DF_HW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        off[t] = (wave + 4 * t < DF_NG && hp < DF_NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+    }
+    const int r = l31, m_r = r / 9, tap_r = r - 9 * m_r;     // this lane's row of A
+    for (int c0 = 0; c0 < Cout; c0 += 2 * KC) {
+        float a[KC];
+#pragma unroll
+        for (int kp = 0; kp < KC; ++kp) {
+            const int c = c0 + 2 * kp + khalf;
+            a[kp] = (r < 9 * M && c < Cout) ? w[((size_t)c * M + m_r) * 9 + tap_r] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (wave + 4 * t >= DF_NG) continue;             // wave-uniform
+            float b[KC];
+#pragma unroll
+            for (int kp = 0; kp < KC; ++kp) {
+                const int c = c0 + 2 * kp + khalf;
+                b[kp] = (off[t] >= 0 && c < Cout) ? dy[(size_t)c * plane + off[t]] : 0.f;
+            }
+#pragma unroll
+            for (int kp = 0; kp < KC; ++kp) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], b[kp], acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (wave + 4 * t < DF_NG) dgrad_first_park(z_s, acc[t], wave + 4 * t, lane);
+    __syncthreads();
+    dgrad_first_gather<M>(z_s, dx, inject, x0, y0, H, W);
+}
+
+// bf16 feature path: dy16 = the channel-blocked bf16 copy [Cout/8][H][W][8] (a quad IS the B fragment), w holds
+// bf16-representable values (rounded on the host); v_mfma_f32_32x32x16_bf16, one k-step = 16 channels
+template <int M>
+__global__ __launch_bounds__(256) void conv3x3_dgrad_first_bf16(const uint4* __restrict__ dy16, const float* __restrict__ w,
+                                                                float* __restrict__ dx, const float* __restrict__ inject,
+                                                                int Cout, int H, int W)
+{
+    __shared__ float z_s[DF_ROWS * DF_ZS];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * DF_TW, y0 = blockIdx.y * DF_TH;
+    const size_t plane = (size_t)H * W;
+    constexpr int KC = 4;                                    // k-steps per chunk (64 channels)
+    df_f32x16 acc[3];
+    int off[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        const int hp = (wave + 4 * t) * 32 + l31;
+        const int hy = hp / DF_HW, hx = hp - hy * DF_HW;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        off[t] = (wave + 4 * t < DF_NG && hp < DF_NPIX && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+    }
+    const int r = l31, m_r = r / 9, tap_r = r - 9 * m_r;
+    const int nks = Cout / 16;
+    for (int k0 = 0; k0 < nks; k0 += KC) {
+        df_bf16x8 a[KC];
+#pragma unroll
+        for (int ks = 0; ks < KC; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * (k0 + ks) + 8 * khalf + j;
+                a[ks][j] = (__bf16)((r < 9 * M && k0 + ks < nks) ? w[((size_t)c * M + m_r) * 9 + tap_r] : 0.f);     // exact: w is bf16-representable
+            }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (wave + 4 * t >= DF_NG) continue;
+            uint4 b[KC];
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks)
+                b[ks] = (off[t] >= 0 && k0 + ks < nks) ? dy16[(size_t)(2 * (k0 + ks) + khalf) * plane + off[t]] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(df_bf16x8, b[ks]), acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (wave + 4 * t < DF_NG) dgrad_first_park(z_s, acc[t], wave + 4 * t, lane);
+    __syncthreads();
+    dgrad_first_gather<M>(z_s, dx, inject, x0, y0, H, W);
+}
+
+// ST2_DGRAD_FIRST=0 keeps the VALU kernels (conv3x3_dgrad_smallM*); read per launch (the tests run both)
+static bool dgrad_first_enabled() { const char* e = getenv("ST2_DGRAD_FIRST"); return !(e && *e == '0'); }
+
+bool conv_dgrad_first_ok(int Cout, int Cin, int H, int W, bool bf16)
+{
+    return dgrad_first_enabled() && Cin >= 1 && Cin <= 3 && Cout >= 2 && Cout % (bf16 ? 16 : 2) == 0 && H >= 1 && W >= 1 &&
+           (unsigned long long)H * W < 0x7fffffffull;
+}
+
+hipError_t launch_conv3x3_dgrad_first(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s)
+{
+    if (!conv_dgrad_first_ok(Cout, Cin, H, W, false)) return hipErrorInvalidValue;
+    const dim3 grid((W + DF_TW - 1) / DF_TW, (H + DF_TH - 1) / DF_TH);
+    switch (Cin) {
+    case 1: conv3x3_dgrad_first_f32<1><<<grid, 256, 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    case 2: conv3x3_dgrad_first_f32<2><<<grid, 256, 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    default: conv3x3_dgrad_first_f32<3><<<grid, 256, 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_conv3x3_dgrad_first16(const unsigned short* dy16, const float* w_rounded, float* dx, const float* inject, int Cout, int Cin,
+                                        int H, int W, hipStream_t s)
+{
+    if (!conv_dgrad_first_ok(Cout, Cin, H, W, true) || (reinterpret_cast<uintptr_t>(dy16) & 15) != 0) return hipErrorInvalidValue;
+    const dim3 grid((W + DF_TW - 1) / DF_TW, (H + DF_TH - 1) / DF_TH);
+    const uint4* q16 = reinterpret_cast<const uint4*>(dy16);
+    switch (Cin) {
+    case 1: conv3x3_dgrad_first_bf16<1><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, Cout, H, W); break;
+    case 2: conv3x3_dgrad_first_bf16<2><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, Cout, H, W); break;
+    default: conv3x3_dgrad_first_bf16<3><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, Cout, H, W); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace st2

@@ -717,6 +717,7 @@ hipError_t launch_conv3x3_dgrad_smallM16(const unsigned short* dy16, const float
                                          int Cout, int Cin, int H, int W, hipStream_t s)
 {
     if (!conv_dgrad_smallM_ok(Cout, Cin) || Cout % 8 != 0) return hipErrorInvalidValue;
+    if (conv_dgrad_first_ok(Cout, Cin, H, W, true)) return launch_conv3x3_dgrad_first16(dy16, w_rounded, dx, inject, Cout, Cin, H, W, s);   // matrix cores
     dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
     const uint4* q16 = reinterpret_cast<const uint4*>(dy16);
     switch (Cin) {
@@ -732,6 +733,7 @@ hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* d
                                        int Cout, int Cin, int H, int W, hipStream_t s)
 {
     if (!conv_dgrad_smallM_ok(Cout, Cin)) return hipErrorInvalidValue;
+    if (conv_dgrad_first_ok(Cout, Cin, H, W, false)) return launch_conv3x3_dgrad_first(dy, w, dx, inject, Cout, Cin, H, W, s);              // matrix cores
     dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
     switch (Cin) {
     case 1: conv3x3_dgrad_smallM<1><<<grid, dim3(256), 0, s>>>(dy, w, dx, inject, Cout, H, W); break;

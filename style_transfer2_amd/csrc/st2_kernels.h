@@ -55,6 +55,11 @@ int conv_wino_splits(int K, int M, int H, int W);   // split-K factor the automa
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);
 hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s);   // 0: 128 ch x 4x32 px, 1: 64 ch x 8x32 px
 // conv1_1-style dgrad (tiny M): direct VALU kernel, w is the ORIGINAL (Cout,Cin,3,3) layout
+// conv1_1's data gradient on the matrix cores (conv3x3_dgrad_first.hip): Z = A @ dy (1x1, 9 M rows) + 9 M shifted adds; Cin <= 3
+bool conv_dgrad_first_ok(int Cout, int Cin, int H, int W, bool bf16);
+hipError_t launch_conv3x3_dgrad_first(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s);
+hipError_t launch_conv3x3_dgrad_first16(const unsigned short* dy16, const float* w_rounded, float* dx, const float* inject, int Cout, int Cin,
+                                        int H, int W, hipStream_t s);
 bool conv_dgrad_smallM_ok(int Cout, int Cin);
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
                                        int Cout, int Cin, int H, int W, hipStream_t s);

@@ -58,13 +58,20 @@ class Engine:
                 d.cin, d.cout = (layer[2], layer[3]) if layer[0] == 'conv' else (0, 0)
             check(self.lib.st_create(byref(self._ctx), int(device), descs, len(self.topology)))
         # 'bf16-full' = the bf16 feature path with every fp32 blob / diff materialised (A/B reference of the lean data flow)
-        modes = {'fp32': 0, 'bf16': 1, 'bf16-full': 2}
-        if precision not in modes:
-            raise ValueError('precision must be one of %s' % sorted(modes))
-        check(self.lib.st_set_precision(self._ctx, modes[precision]))
+        self.set_precision(precision)
         n = self.lib.st_num_blobs(self._ctx)
         self.blob_names = [self.lib.st_blob_name(self._ctx, i).decode() for i in range(n)]
         self._index = {name: i for i, name in enumerate(self.blob_names)}
+
+    PRECISIONS = {'fp32': 0, 'bf16': 1, 'bf16-full': 2}
+
+    def set_precision(self, precision):
+        """'fp32', 'bf16' (lean data flow: blobs only bf16 convs read are not materialised in fp32) or 'bf16-full' (same arithmetic,
+        every blob / diff written in fp32 as well).  Takes effect from the next evaluation."""
+        if precision not in self.PRECISIONS:
+            raise ValueError('precision must be one of %s' % sorted(self.PRECISIONS))
+        check(self.lib.st_set_precision(self._ctx, self.PRECISIONS[precision]))
+        self.precision = precision
 
     def graph_replays(self):
         """Number of steps that ran as a hipGraph replay (steady-state Adam steps at small image sizes)."""

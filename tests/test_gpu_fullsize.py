@@ -232,7 +232,11 @@ def test_vgg19_objective_bf16_at_2048_and_one_lbfgs_step():
     lo, go = cpu.opfunc(cpu.input)
     ld, gd = dev.opfunc()
     eng = dev.engine
+    # the lean flow keeps style-only blobs as bf16 copies: take the fp32 blobs from the bit-identical full flow of the same input
+    eng.set_precision('bf16-full')
+    dev.opfunc()
     ferr = {n: rel_l2(eng.get_blob(n)[0], net._blobs[n]) for n in WEIGHTED}
+    eng.set_precision('bf16')
     cos = float(np.vdot(gd.astype(np.float64), go.astype(np.float64)) / (np.linalg.norm(gd.astype(np.float64)) * np.linalg.norm(go.astype(np.float64))))
     vals = {'forward_rel_l2': ferr, 'loss_rel': float(abs(ld - lo) / abs(lo)), 'grad_rel_l2': rel_l2(gd, go), 'grad_cosine': cos}
     report('bf16 vgg19 2048 objective', vals)

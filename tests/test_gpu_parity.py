@@ -61,6 +61,30 @@ def test_pool_ceil_mode_and_first_max():
         assert rel_l2(gpu.backward(d), cpu.backward(d)) <= 2e-5, (h, w)
 
 
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+@pytest.mark.parametrize('kernel', ['1', '0'])
+@pytest.mark.parametrize('cout,h,w', [(64, 64, 96), (64, 75, 100), (16, 9, 33), (32, 40, 31), (64, 8, 32), (48, 21, 70), (24, 12, 20)])
+def test_first_conv_data_gradient_on_the_matrix_cores(precision, kernel, cout, h, w, monkeypatch):
+    """conv1_1's data gradient (3 output channels): Z = A @ dy as one 32-row MFMA tile + 27 shifted adds
+    (conv3x3_dgrad_first.hip; ST2_DGRAD_FIRST=0 keeps the VALU kernel) against the oracle fed with the GPU's own forward state,
+    with a diff injected at the data blob too; tiles cut by the right / bottom edge, widths that are not multiples of 4, channel
+    counts the bf16 variant cannot take (24: falls back)."""
+    monkeypatch.setenv('ST2_DGRAD_FIRST', kernel)
+    topo = (('conv', 'conv1_1', 3, cout),)
+    params = oracle.he_init_weights(topo, seed=cout + h, bias_std=0.2)
+    gpu = st2.HipModel(params, topology=topo, precision=precision)
+    cpu = oracle.NetOracle(topo, params, operands='bf16' if precision == 'bf16' else 'fp32')
+    rng = np.random.RandomState(h * w + cout)
+    x = (rng.randn(1, 3, h, w) * 40).astype(F32)
+    f = gpu.forward(x, ['conv1_1'])
+    cpu.forward(x)
+    cpu.adopt_forward_state(f)
+    for names in (['conv1_1'], ['conv1_1', 'data']):
+        diffs = {n: rng.randn(*(f[n].shape if n != 'data' else x.shape)).astype(F32) for n in names}
+        err = rel_l2(gpu.backward(diffs), cpu.backward(diffs))
+        assert err <= (5e-5 if precision == 'bf16' else 2e-6), (names, err)
+
+
 def test_ranged_backward_injection_rules():
     """worker.py:88-106: unmasked at the start blob, masked from above, pool and data blobs too."""
     topo = oracle.tiny_topology((8, 16), (2, 2), final_pool=True)
