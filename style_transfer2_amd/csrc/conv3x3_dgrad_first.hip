@@ -84,25 +84,34 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_first_f32(const float* __re
     }
     const int r = l31, m_r = r / 9, tap_r = r - 9 * m_r;     // this lane's row of A
     for (int c0 = 0; c0 < Cout; c0 += 2 * KC) {
+        // every B operand of this pass first (96 loads in flight per lane): their latency covers the staging of A
+        float b[3][KC];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int kp = 0; kp < KC; ++kp) {
+                const int c = c0 + 2 * kp + khalf;
+                b[t][kp] = (off[t] >= 0 && c < Cout) ? dy[(size_t)c * plane + off[t]] : 0.f;
+            }
+        // A: the weights of these 64 channels, coalesced into LDS (the Z rows are not there yet), then one gather per lane
+        if (c0) __syncthreads();
+        const int nw = min(2 * KC, Cout - c0) * M * 9;
+        for (int i = tid; i < nw; i += 256) z_s[i] = w[(size_t)c0 * M * 9 + i];
+        __syncthreads();
         float a[KC];
 #pragma unroll
         for (int kp = 0; kp < KC; ++kp) {
-            const int c = c0 + 2 * kp + khalf;
-            a[kp] = (r < 9 * M && c < Cout) ? w[((size_t)c * M + m_r) * 9 + tap_r] : 0.f;
+            const int cl = 2 * kp + khalf;
+            a[kp] = (r < 9 * M && c0 + cl < Cout) ? z_s[(cl * M + m_r) * 9 + tap_r] : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             if (wave + 4 * t >= DF_NG) continue;             // wave-uniform
-            float b[KC];
 #pragma unroll
-            for (int kp = 0; kp < KC; ++kp) {
-                const int c = c0 + 2 * kp + khalf;
-                b[kp] = (off[t] >= 0 && c < Cout) ? dy[(size_t)c * plane + off[t]] : 0.f;
-            }
-#pragma unroll
-            for (int kp = 0; kp < KC; ++kp) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], b[kp], acc[t], 0, 0, 0);
+            for (int kp = 0; kp < KC; ++kp) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], b[t][kp], acc[t], 0, 0, 0);
         }
     }
+    __syncthreads();                                         // every wave has taken its A operands out of LDS
 #pragma unroll
     for (int t = 0; t < 3; ++t)
         if (wave + 4 * t < DF_NG) dgrad_first_park(z_s, acc[t], wave + 4 * t, lane);
@@ -137,26 +146,33 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_first_bf16(const uint4* __r
     const int r = l31, m_r = r / 9, tap_r = r - 9 * m_r;
     const int nks = Cout / 16;
     for (int k0 = 0; k0 < nks; k0 += KC) {
+        uint4 b[3][KC];                                      // every B operand of this pass first
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KC; ++ks)
+                b[t][ks] = (off[t] >= 0 && k0 + ks < nks) ? dy16[(size_t)(2 * (k0 + ks) + khalf) * plane + off[t]] : make_uint4(0, 0, 0, 0);
+        if (k0) __syncthreads();
+        const int nw = min(16 * KC, Cout - 16 * k0) * M * 9;
+        for (int i = tid; i < nw; i += 256) z_s[i] = w[(size_t)16 * k0 * M * 9 + i];
+        __syncthreads();
         df_bf16x8 a[KC];
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int c = 16 * (k0 + ks) + 8 * khalf + j;
-                a[ks][j] = (__bf16)((r < 9 * M && k0 + ks < nks) ? w[((size_t)c * M + m_r) * 9 + tap_r] : 0.f);     // exact: w is bf16-representable
+                const int cl = 16 * ks + 8 * khalf + j;
+                a[ks][j] = (__bf16)((r < 9 * M && k0 + ks < nks) ? z_s[(cl * M + m_r) * 9 + tap_r] : 0.f);     // exact: w is bf16-representable
             }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             if (wave + 4 * t >= DF_NG) continue;
-            uint4 b[KC];
 #pragma unroll
             for (int ks = 0; ks < KC; ++ks)
-                b[ks] = (off[t] >= 0 && k0 + ks < nks) ? dy16[(size_t)(2 * (k0 + ks) + khalf) * plane + off[t]] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int ks = 0; ks < KC; ++ks)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(df_bf16x8, b[ks]), acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(df_bf16x8, b[t][ks]), acc[t], 0, 0, 0);
         }
     }
+    __syncthreads();                                         // every wave has taken its A operands out of LDS
 #pragma unroll
     for (int t = 0; t < 3; ++t)
         if (wave + 4 * t < DF_NG) dgrad_first_park(z_s, acc[t], wave + 4 * t, lane);
@@ -164,12 +180,14 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_first_bf16(const uint4* __r
     dgrad_first_gather<M>(z_s, dx, inject, x0, y0, H, W);
 }
 
-// ST2_DGRAD_FIRST=0 keeps the VALU kernels (conv3x3_dgrad_smallM*); read per launch (the tests run both)
-static bool dgrad_first_enabled() { const char* e = getenv("ST2_DGRAD_FIRST"); return !(e && *e == '0'); }
-
+// Measured (profiles/r03_a_*): the bf16 variant beats the VALU kernel (2048^2: 303 -> 265 us), the fp32 variant does not (1024^2:
+// 122 -> 200 us: 96 four-byte operand loads per lane against 12 sixteen-byte ones) -- so by default only the bf16 path uses this file.
+// ST2_DGRAD_FIRST=1 routes fp32 here too, =0 neither; read per launch (the tests run every combination).
 bool conv_dgrad_first_ok(int Cout, int Cin, int H, int W, bool bf16)
 {
-    return dgrad_first_enabled() && Cin >= 1 && Cin <= 3 && Cout >= 2 && Cout % (bf16 ? 16 : 2) == 0 && H >= 1 && W >= 1 &&
+    const char* e = getenv("ST2_DGRAD_FIRST");
+    const bool enabled = e && *e ? (*e == '1') : bf16;
+    return enabled && Cin >= 1 && Cin <= 3 && Cout >= 2 && Cout % (bf16 ? 16 : 2) == 0 && H >= 1 && W >= 1 &&
            (unsigned long long)H * W < 0x7fffffffull;
 }
 
