@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_first_bf16(const uint4* __r
     dgrad_first_gather<M>(z_s, dx, inject, x0, y0, H, W);
 }
 
-// Measured (profiles/r03_a_*): the bf16 variant beats the VALU kernel (2048^2: 303 -> 265 us), the fp32 variant does not (1024^2:
+// Measured (profiles/r02_zb_dgrad_first_ab.txt): the bf16 variant beats the VALU kernel (2048^2: 303 -> 265 us), the fp32 variant does not (1024^2:
 // 122 -> 200 us: 96 four-byte operand loads per lane against 12 sixteen-byte ones) -- so by default only the bf16 path uses this file.
 // ST2_DGRAD_FIRST=1 routes fp32 here too, =0 neither; read per launch (the tests run every combination).
 bool conv_dgrad_first_ok(int Cout, int Cin, int H, int W, bool bf16)
