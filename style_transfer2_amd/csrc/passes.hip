@@ -262,75 +262,110 @@ __device__ __forceinline__ float tv_k(float q, float half_beta, int beta_is_2)
     return beta_is_2 ? 1.0f : half_beta * powf(q, half_beta - 1.0f);
 }
 
+// One workgroup walks tiles of IP_TY rows x IP_TX columns of one channel.  The tile and its 1-pixel circular neighbourhood are
+// staged once in LDS as u = x / 255 (one IEEE division per staged value instead of seven per output, all index arithmetic per
+// tile instead of per element); a thread owns one column of the tile.  Per-element arithmetic is the reference's, operation by
+// operation (utils.py / worker.py:283-301); only the order of the partial sums differs from a flat sweep.
+constexpr int IP_TY = 4, IP_TX = 256;
+constexpr int IP_LW = IP_TX + 2;                         // staged row length
+
 __global__ __launch_bounds__(256) void image_pass_k(const ImagePassArgs a)
 {
     __shared__ float scratch[32];
-    const int H = a.H, W = a.W;
+    __shared__ float u_s[(IP_TY + 2) * IP_LW];
+    const int H = a.H, W = a.W, tid = threadIdx.x;
     const size_t plane = (size_t)H * W;
-    const size_t total = plane * a.C;
     const float half_beta = a.tv_beta * 0.5f;
     const int beta_is_2 = a.tv_beta == 2.0f;
-    const int do_tv = a.tv_w != 0.0f || true;   // value is traced even when the weight is zero
-    (void)do_tv;
     // per-step Adam scalars: by value, or (graph replay: the launch arguments are frozen) from device memory
     const float corr1 = a.dyn ? a.dyn[0] : a.corr1, corr2 = a.dyn ? a.dyn[1] : a.corr2, step = a.dyn ? a.dyn[2] : a.step;
+    const int p_round = (int)a.p_pow;
+    const int p_int = ((float)p_round == a.p_pow && p_round >= 1 && p_round <= 16) ? p_round : 0;      // uniform
+    const int tiles_x = (W + IP_TX - 1) / IP_TX, tiles_y = (H + IP_TY - 1) / IP_TY;
+    const int n_tiles = a.C * tiles_y * tiles_x;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int x = (int)(idx % W);
-        const int y = (int)((idx / W) % H);
-        const float* p = a.x + (idx / plane) * plane;
-        const int xr = x + 1 == W ? 0 : x + 1, xl = x == 0 ? W - 1 : x - 1;
-        const int yd = y + 1 == H ? 0 : y + 1, yu = y == 0 ? H - 1 : y - 1;
-        const float xv = p[(size_t)y * W + x];
-        const float u = xv / 255.0f;
-        const float u_r = p[(size_t)y * W + xr] / 255.0f;
-        const float u_d = p[(size_t)yd * W + x] / 255.0f;
-        const float u_l = p[(size_t)y * W + xl] / 255.0f;
-        const float u_u = p[(size_t)yu * W + x] / 255.0f;
-        const float u_dl = p[(size_t)yd * W + xl] / 255.0f;
-        const float u_ur = p[(size_t)yu * W + xr] / 255.0f;
-        // this pixel
-        const float a0 = u - u_r, b0 = u - u_d;
-        const float q0 = (a0 * a0 + b0 * b0) + 1e-8f;
-        const float k0 = tv_k(q0, half_beta, beta_is_2);
-        const float da0 = (2.0f * a0) * k0, db0 = (2.0f * b0) * k0;
-        // left neighbour's x-difference, upper neighbour's y-difference
-        const float aL = u_l - u, bL = u_l - u_dl;
-        const float qL = (aL * aL + bL * bL) + 1e-8f;
-        const float daL = (2.0f * aL) * tv_k(qL, half_beta, beta_is_2);
-        const float aU = u_u - u_ur, bU = u_u - u;
-        const float qU = (aU * aU + bU * bU) + 1e-8f;
-        const float dbU = (2.0f * bU) * tv_k(qU, half_beta, beta_is_2);
-        float g_tv = da0 + db0;
-        g_tv -= daL;
-        g_tv -= dbU;
-        acc[0] += beta_is_2 ? q0 : powf(q0, half_beta);
-        // p-norm
-        const float mag = fabsf(u);
-        const float sgn = u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);
-        acc[1] += powf(mag, a.p_pow);
-        const float g_p = sgn * powf(mag, a.p_pow - 1.0f);
-        // combine
-        const float scd = a.scd ? a.scd[idx] : 0.f;
-        const float tg = a.tv_w * g_tv;
-        const float pg = a.p_w * g_p;
-        float g = scd + tg;
-        g += pg;
-        acc[2] += scd * scd;
-        acc[3] += tg * tg;
-        acc[4] += pg * pg;
-        acc[5] += g * g;
-        if (a.grad) a.grad[idx] = g;
-        if (a.x_out) {
-            const float m_old = a.m_is_zero ? 0.f : a.m[idx];
-            const float v_old = a.v_is_zero ? 0.f : a.v[idx];
-            const float m_new = a.d1 * m_old + a.c1 * g;
-            const float v_new = a.d2 * v_old + a.c2 * (g * g);
-            a.m[idx] = m_new;
-            a.v[idx] = v_new;
-            const float m_hat = m_new / corr1;
-            const float v_hat = v_new / corr2;
-            a.x_out[idx] = xv - (step * m_hat) / (sqrtf(v_hat) + 1e-8f);
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, rest = tile / tiles_x;
+        const int ty = rest % tiles_y, ch = rest / tiles_y;
+        const int x0 = tx * IP_TX, y0 = ty * IP_TY;
+        const float* p = a.x + (size_t)ch * plane;
+        __syncthreads();                                 // the previous tile is consumed
+        for (int e = tid; e < (IP_TY + 2) * IP_LW; e += 256) {
+            const int r = e / IP_LW, c = e - r * IP_LW;
+            int gy = y0 - 1 + r, gx = x0 - 1 + c;        // circular neighbourhood (np.roll)
+            gy = gy < 0 ? H - 1 : (gy >= H ? gy - H : gy);
+            gx = gx < 0 ? W - 1 : (gx >= W ? gx - W : gx);
+            u_s[e] = (gy < H && gx < W) ? p[(size_t)gy * W + gx] / 255.0f : 0.f;      // (beyond the wrap: slots no output reads)
+        }
+        __syncthreads();
+        const int x = x0 + tid;
+        if (x < W) {
+#pragma unroll
+            for (int ry = 0; ry < IP_TY; ++ry) {
+                const int y = y0 + ry;
+                if (y >= H) break;
+                const float* us = u_s + (ry + 1) * IP_LW + tid + 1;      // (y, x)
+                const size_t idx = (size_t)ch * plane + (size_t)y * W + x;
+                const float xv = a.x[idx];
+                const float u = us[0];
+                const float u_r = us[1], u_l = us[-1];
+                const float u_d = us[IP_LW], u_u = us[-IP_LW];
+                const float u_dl = us[IP_LW - 1], u_ur = us[-IP_LW + 1];
+                // this pixel
+                const float a0 = u - u_r, b0 = u - u_d;
+                const float q0 = (a0 * a0 + b0 * b0) + 1e-8f;
+                const float k0 = tv_k(q0, half_beta, beta_is_2);
+                const float da0 = (2.0f * a0) * k0, db0 = (2.0f * b0) * k0;
+                // left neighbour's x-difference, upper neighbour's y-difference
+                const float aL = u_l - u, bL = u_l - u_dl;
+                const float qL = (aL * aL + bL * bL) + 1e-8f;
+                const float daL = (2.0f * aL) * tv_k(qL, half_beta, beta_is_2);
+                const float aU = u_u - u_ur, bU = u_u - u;
+                const float qU = (aU * aU + bU * bU) + 1e-8f;
+                const float dbU = (2.0f * bU) * tv_k(qU, half_beta, beta_is_2);
+                float g_tv = da0 + db0;
+                g_tv -= daL;
+                g_tv -= dbU;
+                acc[0] += beta_is_2 ? q0 : powf(q0, half_beta);
+                // p-norm
+                const float mag = fabsf(u);
+                const float sgn = u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);
+                float pw, pw1;                           // |u|^p, |u|^(p-1)
+                if (p_int) {
+                    // integral exponent (the default p = 6): repeated multiplication, within 3 ulp of powf -- two powf calls per
+                    // element were 60 % of this kernel's time (it is VALU-bound, not HBM-bound, with them)
+                    pw1 = p_int > 1 ? mag : 1.0f;
+                    for (int k = 2; k < p_int; ++k) pw1 *= mag;
+                    pw = pw1 * mag;
+                } else {
+                    pw = powf(mag, a.p_pow);
+                    pw1 = powf(mag, a.p_pow - 1.0f);
+                }
+                acc[1] += pw;
+                const float g_p = sgn * pw1;
+                // combine
+                const float scd = a.scd ? a.scd[idx] : 0.f;
+                const float tg = a.tv_w * g_tv;
+                const float pg = a.p_w * g_p;
+                float g = scd + tg;
+                g += pg;
+                acc[2] += scd * scd;
+                acc[3] += tg * tg;
+                acc[4] += pg * pg;
+                acc[5] += g * g;
+                if (a.grad) a.grad[idx] = g;
+                if (a.x_out) {
+                    const float m_old = a.m_is_zero ? 0.f : a.m[idx];
+                    const float v_old = a.v_is_zero ? 0.f : a.v[idx];
+                    const float m_new = a.d1 * m_old + a.c1 * g;
+                    const float v_new = a.d2 * v_old + a.c2 * (g * g);
+                    a.m[idx] = m_new;
+                    a.v[idx] = v_new;
+                    const float m_hat = m_new / corr1;
+                    const float v_hat = v_new / corr2;
+                    a.x_out[idx] = xv - (step * m_hat) / (sqrtf(v_hat) + 1e-8f);
+                }
+            }
         }
     }
     block_sum(acc, scratch);
@@ -349,8 +384,8 @@ hipError_t launch_set_scalars3(float* dst, float a, float b, float c, hipStream_
 
 hipError_t launch_image_pass(const ImagePassArgs& a, int* n_partial, hipStream_t s)
 {
-    const size_t total = (size_t)a.C * a.H * a.W;
-    const int grid = reduce_grid(total, 256 * 4, kMaxPartials);
+    const long long n_tiles = (long long)a.C * ((a.H + IP_TY - 1) / IP_TY) * ((a.W + IP_TX - 1) / IP_TX);
+    const int grid = (int)(n_tiles < kMaxPartials ? (n_tiles < 1 ? 1 : n_tiles) : kMaxPartials);
     *n_partial = grid;
     image_pass_k<<<grid, 256, 0, s>>>(a);
     return hipGetLastError();

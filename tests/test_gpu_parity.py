@@ -175,6 +175,33 @@ def test_engine_opfunc_two_evals_match_reference_vectors(tag):
     assert list(st.traces[-1].data)[-4:] == ['scd_loss', 't_loss', 'p_loss', 'loss']
 
 
+@pytest.mark.parametrize('p_power,tv_power', [(2.5, 1.7), (3, 2), (1, 2.2), (7.0, 1.0)])
+def test_image_terms_with_integral_and_fractional_exponents(p_power, tv_power):
+    """TV / p-norm pass (utils.py:285-304 behind worker.py:283-301): integral p-norm exponents run by repeated multiplication,
+    fractional ones (and every TV exponent but 2) through powf -- both against the CPU oracle's objective on the same state, two
+    evaluations (norm capture, then frozen norms), on an image whose size is no multiple of the pass's 4 x 256 tile."""
+    g = load('transfer_tiny.npz')
+    topo, net_params, weights, content, style, init = tiny_setup(g)
+    params = {'p': 7.0, 'p_power': p_power, 'tv': 3.0, 'tv_power': tv_power}
+    cpu = oracle.TransferOracle(oracle.NetOracle(topo, net_params))
+    dev = st2.StyleTransfer(st2.HipModel(net_params, topology=topo))
+    for st in (cpu, dev):
+        st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+        st.set_weights(weights, params)
+    cpu.set_optimizer('adam', 10)
+    dev.optimizer_cls = st2.AdamOptimizer; dev.set_step_size(10); dev.reset()
+    assert dev.start()
+    x = g['std_eval1_x'].copy()
+    for ev in (1, 2):
+        lo, go = cpu.opfunc(x.copy())
+        ld, gd = dev.opfunc(x.copy())
+        assert rel_l2(gd, go) <= 1e-4, (ev, rel_l2(gd, go))
+        assert np.isclose(ld, lo, rtol=1e-4)
+        for k in ('t_loss', 'p_loss', 't_grad', 'p_grad'):
+            assert np.isclose(dev.traces[-1].data[k], cpu.traces[-1].data[k], rtol=2e-4, atol=1e-12), (k, dev.traces[-1].data[k], cpu.traces[-1].data[k])
+        x = x + 3.0 * np.sign(go).astype(F32)
+
+
 def test_engine_adam_trajectory_matches_reference_vectors():
     """50 Adam steps.  Adam's first steps are sign-like (x -= 10 g/|g|), so pixels whose gradient is at
     fp32 noise level may flip: tight bar on the per-step loss, loose bar on the image (MSE in 0-255
