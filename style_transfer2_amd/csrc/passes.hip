@@ -182,6 +182,40 @@ __global__ __launch_bounds__(256) void layer_elem_k(const LayerElemArgs a)
         if (a.content) inv_c = *a.norm_c;
         if (a.deepdream) inv_d = *a.norm_d;
     }
+    // whole blobs (not tile-sharded) with n % 4 == 0: 16 bytes per lane and access -- the scalar loop below keeps too few bytes
+    // in flight to reach the HBM rate (measured 2.3 TB/s at 33 M elements)
+    const bool vec = !a.w && (a.n & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.feat) | reinterpret_cast<uintptr_t>(a.inject) |
+                                                 reinterpret_cast<uintptr_t>(a.target)) & 15) == 0;
+    if (vec) {
+        const size_t n4 = a.n >> 2;
+        for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) {
+            const float4 f4 = reinterpret_cast<const float4*>(a.feat)[q];
+            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.content) t4 = reinterpret_cast<const float4*>(a.target)[q];
+            const float fv[4] = {f4.x, f4.y, f4.z, f4.w}, tv[4] = {t4.x, t4.y, t4.z, t4.w};
+            float ov[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                 // same per-element arithmetic as the scalar loop
+                const float f = fv[j];
+                float out = 0.f;
+                if (a.content) {
+                    const float d = f - tv[j];
+                    const float gc = a.cn_coef * d;
+                    acc[0] += d * d;
+                    acc[1] += gc * gc;
+                    if (a.write) out += (a.cw * gc) / inv_c;
+                }
+                if (a.deepdream) {
+                    const float gd = a.dn_coef * f;
+                    acc[2] += f * f;
+                    acc[3] += gd * gd;
+                    if (a.write) out += (a.dw * gd) / inv_d;
+                }
+                ov[j] = out;
+            }
+            if (a.write) reinterpret_cast<float4*>(a.inject)[q] = make_float4(ov[0], ov[1], ov[2], ov[3]);
+        }
+    } else
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
         if (a.w) {                                        // tile-sharded: only the region of interest counts
             const int x = (int)(i % a.w), y = (int)((i / a.w) % a.h);

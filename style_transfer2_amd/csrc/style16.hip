@@ -90,13 +90,20 @@ __global__ __launch_bounds__(64) void style_s2_trace_k(const float* __restrict__
     s16_f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-    for (int k = 0; k < C; k += 4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(drow + k);
-        const float4 d4 = *reinterpret_cast<const float4*>(grow_d + k);
-        const float4 t4 = *reinterpret_cast<const float4*>(grow_a + k);
-        const float b0 = h ? d4.y + t4.y : d4.x + t4.x, b1 = h ? d4.w + t4.w : d4.z + t4.z;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4.y : a4.x, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4.w : a4.z, b1, acc, 0, 0, 0);
+    for (int k0 = 0; k0 < C; k0 += 32) {               // C % 32 == 0; 24 loads in flight, then 16 MFMAs
+        float4 a4[8], d4[8], t4[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a4[u] = *reinterpret_cast<const float4*>(drow + k0 + 4 * u);
+            d4[u] = *reinterpret_cast<const float4*>(grow_d + k0 + 4 * u);
+            t4[u] = *reinterpret_cast<const float4*>(grow_a + k0 + 4 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float b0 = h ? d4[u].y + t4[u].y : d4[u].x + t4[u].x, b1 = h ? d4[u].w + t4[u].w : d4[u].z + t4[u].z;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4[u].y : a4[u].x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? a4[u].w : a4[u].z, b1, acc, 0, 0, 0);
+        }
     }
     float ss = 0.0f;
 #pragma unroll
