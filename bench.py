@@ -246,8 +246,29 @@ def worker_level(job, steps):
         dt = time.perf_counter() - t0
         out[mode + '_iterate_it_s'] = steps / dt
         out['iterate_MB'] = sink.bytes / steps / 1e6
+    # the worker's default loop: iteration k + 1 is begun before iterate k is collected (st_step_begin / st_step_end), sender thread on
+    if hasattr(job, 'step_begin'):
+        for _ in range(2):                       # (the first begin allocates the rotating pinned buffers)
+            job.step_begin()
+        while job.steps_pending:
+            job.step_end(copy=False)
+        job.engine.sync()
+        sink = PickleSink()
+        send = worker_mod.AsyncSender(sink)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            job.step_begin()
+            if job.steps_pending > 1:
+                image, trace, index = job.step_end(copy=False)       # as worker.py does: the sender pickles the pinned view
+                send.send_pyobj(messages.Iterate(image, index, trace))
+        while job.steps_pending:
+            image, trace, index = job.step_end(copy=False)
+            send.send_pyobj(messages.Iterate(image, index, trace))
+        send.close()
+        out['pipelined_iterate_it_s'] = steps / (time.perf_counter() - t0)
     out['steps'] = steps
-    out['note'] = 'one Iterate (D2H + pickle) per step on one host thread / with the sender thread; never `value`'
+    out['note'] = ('one Iterate (D2H + pickle) per step: on one host thread / with the sender thread / with the sender thread and the next '
+                   'iteration begun before the iterate is collected (the worker default); never `value`')
     return out
 
 

@@ -104,6 +104,16 @@ int st_adam_set_state(st_ctx* ctx, const float* m, const float* v, int items1, i
  * out_hwc (H,W,3 float32) and trace may be NULL: then nothing is copied back and the call does not
  * synchronise (device-resident loop). */
 int st_step(st_ctx* ctx, float* out_hwc, double* trace, float* out_loss);
+/* The same iteration in two halves, for the worker loop (worker.py:380-395: step, send Iterate, poll the socket, step ...).
+ * st_step_begin queues one StyleTransfer.step and the asynchronous copy of its iterate and trace into pinned host memory (own
+ * stream) and returns at once; st_step_end waits for the OLDEST queued iteration and hands it over: *out_hwc points at a
+ * (H,W,3) float32 array owned by the context, valid for the next FIVE calls of st_step_begin (six buffers rotate; a sender that
+ * is at most four iterates behind can serialise it in place).  At most two iterations may
+ * be in flight; while any is, st_step refuses.  Calling begin(k+1) before end(k) lets the GPU compute iteration k+1 while
+ * iterate k crosses PCIe and is pickled -- the results are those of st_step, bit for bit. */
+int st_step_begin(st_ctx* ctx);
+int st_step_end(st_ctx* ctx, const float** out_hwc, int* out_h, int* out_w, double* trace, float* out_loss);
+int st_step_pending(st_ctx* ctx);      /* iterations begun and not yet ended (0..2) */
 /* Steps so far that ran as a hipGraph replay.  Opt-in (environment ST2_GRAPH=1; ST2_GRAPH_MAX_PX=<edge>, default 768):
  * steady-state Adam steps are captured once per ping-pong parity and replayed, bit-identical to plain launches.  Measured
  * on MI355X it is no faster (the step is bound by the dependent kernels' execution latency), hence off by default. */

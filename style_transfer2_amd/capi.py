@@ -61,6 +61,9 @@ PROTOTYPES = {
     'st_adam_get_state': (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_int), POINTER(c_int)]),
     'st_adam_set_state': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int]),
     'st_step': (c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_float)]),
+    'st_step_begin': (c_int, [c_void_p]),
+    'st_step_end': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_void_p, POINTER(c_float)]),
+    'st_step_pending': (c_int, [c_void_p]),
     'st_graph_replays': (c_int, [c_void_p, POINTER(c_longlong)]),
     'st_lbfgs_inv_hv': (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p]),
     'st_sync': (c_int, [c_void_p]),

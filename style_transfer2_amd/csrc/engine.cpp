@@ -147,6 +147,17 @@ struct st_ctx {
     float* trace_host = nullptr;                   // pinned
     int trace_len_last = 8;
     float* hwc_dev = nullptr;
+    // pipelined iterations (st_step_begin / st_step_end): up to two in flight; the iterate of step k travels to pinned host memory
+    // on its own stream while step k + 1 computes
+    struct Pipe {
+        // kSlots buffers although only two iterations are ever in flight: an iterate handed out by st_step_end stays valid for
+        // kSlots - 1 further begins, which is what lets the worker's sender thread pickle it without a host-side copy
+        static constexpr int kSlots = 6;
+        hipStream_t copy = nullptr;
+        float* hwc[kSlots] = {}; float* img_pin[kSlots] = {}; float* trace_pin[kSlots] = {};
+        hipEvent_t ready[kSlots] = {}, done[kSlots] = {};
+        size_t cap = 0; long long head = 0; int count = 0, tlen[kSlots] = {}, H[kSlots] = {}, W[kSlots] = {};
+    } pipe;
     void* stage_dev = nullptr; size_t stage_cap = 0;
     // optimizer
     int opt_kind = ST_OPT_NONE;
@@ -990,6 +1001,17 @@ int st_destroy(st_ctx* c)
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     if (c->trace_sums) (void)hipFree(c->trace_sums);
     if (c->trace_host) (void)hipHostFree(c->trace_host);
+    if (c->pipe.copy) {
+        (void)hipStreamSynchronize(c->pipe.copy);
+        for (int i = 0; i < st_ctx::Pipe::kSlots; ++i) {
+            dfree(c->pipe.hwc[i]);
+            if (c->pipe.img_pin[i]) (void)hipHostFree(c->pipe.img_pin[i]);
+            if (c->pipe.trace_pin[i]) (void)hipHostFree(c->pipe.trace_pin[i]);
+            if (c->pipe.ready[i]) (void)hipEventDestroy(c->pipe.ready[i]);
+            if (c->pipe.done[i]) (void)hipEventDestroy(c->pipe.done[i]);
+        }
+        (void)hipStreamDestroy(c->pipe.copy);
+    }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1373,11 +1395,9 @@ int st_adam_set_state(st_ctx* c, const float* m, const float* v, int items1, int
     return ST_OK;
 }
 
-int st_step(st_ctx* c, float* out_hwc, double* trace, float* out_loss)
+// the optimizer step itself: everything st_step launches before the iterate is read back
+static int step_enqueue(st_ctx* c)
 {
-    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
-    if (!c->x[0]) return fail(ST_ERR_STATE, "no input image");
-    HIP_TRY(hipSetDevice(c->device));
     if (c->opt_kind == ST_OPT_ADAM) {
         c->items1 += 1; c->items2 += 1;          // DecayingMean.__call__(item), utils.py:58-61
         bool replayed = false;
@@ -1405,11 +1425,84 @@ int st_step(st_ctx* c, float* out_hwc, double* trace, float* out_loss)
     } else {
         return fail(ST_ERR_STATE, "no optimizer: call st_optimizer_reset first");
     }
+    return ST_OK;
+}
+
+int st_step(st_ctx* c, float* out_hwc, double* trace, float* out_loss)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    if (!c->x[0]) return fail(ST_ERR_STATE, "no input image");
+    if (c->pipe.count) return fail(ST_ERR_STATE, "%d pipelined iteration(s) in flight: st_step_end first", c->pipe.count);
+    HIP_TRY(hipSetDevice(c->device));
+    ST_TRY(step_enqueue(c));
     if (out_hwc) {
         { ProfScope ps(c, P_MISC, 0, 0); HIP_TRY(launch_deprocess(c->x[c->cur], c->hwc_dev, c->H, c->W, c->stream)); }
         HIP_TRY(hipMemcpyAsync(out_hwc, c->hwc_dev, (size_t)3 * c->H * c->W * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     }
     if (out_hwc || trace || out_loss) return read_trace(c, trace, out_loss);
+    return ST_OK;
+}
+
+// Pipelined form of st_step for the worker loop (worker.py:380-395: step, send Iterate, poll, step ...): begin() queues the
+// iteration and the asynchronous copy of its iterate / trace, end() hands the OLDEST queued iteration's results over.  With one
+// begin() ahead of every end() the GPU starts iteration k + 1 while iterate k crosses PCIe and is pickled.
+int st_step_begin(st_ctx* c)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    if (!c->x[0]) return fail(ST_ERR_STATE, "no input image");
+    st_ctx::Pipe& p = c->pipe;
+    if (p.count >= 2) return fail(ST_ERR_STATE, "two iterations are already in flight: st_step_end first");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n3 = (size_t)3 * c->H * c->W;
+    if (!p.copy) {
+        HIP_TRY(hipStreamCreateWithFlags(&p.copy, hipStreamNonBlocking));
+        for (int i = 0; i < st_ctx::Pipe::kSlots; ++i) {
+            HIP_TRY(hipEventCreateWithFlags(&p.ready[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p.done[i], hipEventDisableTiming));
+            HIP_TRY(hipHostMalloc((void**)&p.trace_pin[i], (kMaxTraceLayers * 6 + 8) * sizeof(float), 0));
+        }
+    }
+    if (n3 > p.cap) {
+        if (p.count) return fail(ST_ERR_STATE, "the input grew while an iteration is in flight: st_step_end first");
+        for (int i = 0; i < st_ctx::Pipe::kSlots; ++i) {
+            dfree(p.hwc[i]);
+            if (p.img_pin[i]) { (void)hipHostFree(p.img_pin[i]); p.img_pin[i] = nullptr; }
+            ST_TRY(dmalloc(&p.hwc[i], n3));
+            HIP_TRY(hipHostMalloc((void**)&p.img_pin[i], n3 * sizeof(float), 0));
+        }
+        p.cap = n3;
+    }
+    ST_TRY(step_enqueue(c));
+    const int slot = (int)((p.head + p.count) % st_ctx::Pipe::kSlots);
+    { ProfScope ps(c, P_MISC, 0, 0); HIP_TRY(launch_deprocess(c->x[c->cur], p.hwc[slot], c->H, c->W, c->stream)); }
+    p.tlen[slot] = c->trace_len_last; p.H[slot] = c->H; p.W[slot] = c->W;
+    HIP_TRY(hipMemcpyAsync(p.trace_pin[slot], c->trace_dev, p.tlen[slot] * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipEventRecord(p.ready[slot], c->stream));
+    HIP_TRY(hipStreamWaitEvent(p.copy, p.ready[slot], 0));
+    HIP_TRY(hipMemcpyAsync(p.img_pin[slot], p.hwc[slot], n3 * sizeof(float), hipMemcpyDeviceToHost, p.copy));
+    HIP_TRY(hipEventRecord(p.done[slot], p.copy));
+    p.count += 1;
+    return ST_OK;
+}
+
+int st_step_pending(st_ctx* c) { return c ? c->pipe.count : 0; }
+
+int st_step_end(st_ctx* c, const float** out_hwc, int* out_h, int* out_w, double* trace, float* out_loss)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    st_ctx::Pipe& p = c->pipe;
+    if (!p.count) return fail(ST_ERR_STATE, "no iteration in flight: st_step_begin first");
+    HIP_TRY(hipSetDevice(c->device));
+    const int slot = (int)(p.head % st_ctx::Pipe::kSlots);
+    HIP_TRY(hipEventSynchronize(p.done[slot]));          // (the trace copy precedes `ready`, which precedes `done`)
+    const int n = p.tlen[slot];
+    if (trace) for (int i = 0; i < n; ++i) trace[i] = p.trace_pin[slot][i];
+    c->last_loss = p.trace_pin[slot][n - 2];
+    if (out_loss) *out_loss = c->last_loss;
+    if (out_hwc) *out_hwc = p.img_pin[slot];             // valid for the next kSlots - 1 calls of st_step_begin
+    if (out_h) *out_h = p.H[slot];
+    if (out_w) *out_w = p.W[slot];
+    p.head += 1; p.count -= 1;
     return ST_OK;
 }
 

@@ -2,7 +2,7 @@
 model + objective + optimizer, resident on one MI355X."""
 
 import ctypes
-from ctypes import byref, c_double, c_float, c_int, c_longlong, c_void_p
+from ctypes import POINTER, byref, c_double, c_float, c_int, c_longlong, c_void_p
 
 import numpy as np
 
@@ -282,6 +282,28 @@ class Engine:
         check(self.lib.st_step(self._ctx, _ptr(img), _ptr(trace),
                                byref(loss) if (want_image or want_trace) else None))
         return img, trace, F32(loss.value)
+
+    def step_begin(self):
+        """Queue one iteration and the copy of its iterate / trace to the host (st_step_begin); at most two may be in flight."""
+        check(self.lib.st_step_begin(self._ctx))
+
+    STEP_VIEW_LIFETIME = 5      # st2.h: a view returned by step_end(copy=False) survives this many further step_begin calls
+
+    def step_end(self, copy=True):
+        """Results of the OLDEST queued iteration, as step() returns them.  copy=False returns a read-only view of the context's
+        pinned buffer instead of an owned array: valid for the next STEP_VIEW_LIFETIME calls of step_begin (the worker's bounded
+        sender queue stays inside that; a 12.6 MB host copy per iterate is what it saves)."""
+        ptr, h, w, loss = c_void_p(), c_int(), c_int(), c_float()
+        trace = np.zeros(self.trace_len(), np.float64)
+        check(self.lib.st_step_end(self._ctx, byref(ptr), byref(h), byref(w), _ptr(trace), byref(loss)))
+        view = np.ctypeslib.as_array(ctypes.cast(ptr, POINTER(c_float)), shape=(h.value, w.value, 3))
+        if copy:
+            return view.copy(), trace, F32(loss.value)
+        view.flags.writeable = False
+        return view, trace, F32(loss.value)
+
+    def steps_pending(self):
+        return int(self.lib.st_step_pending(self._ctx))
 
     def lbfgs_inv_hv(self, pairs, g):
         """Test hook: H g of optimizers.py:89-108 for the given [(s, y), ...] history (oldest first) on the device."""

@@ -74,6 +74,7 @@ class StyleTransfer:
         self.optimizer_cls = LBFGSOptimizer                    # reference worker.py:135
         self.step_size = 1                                      # SetOptimizer.step_sizes['lbfgs']
         self.traces = []
+        self._inflight = []
 
     # ------------------------------------------------------------------ views of device state
     @property
@@ -233,6 +234,27 @@ class StyleTransfer:
         t('fevals', self.t)
         self.traces.append(t)
         return image, t.data
+
+    # The same iteration in two halves (st_step_begin / st_step_end): the worker loop begins iteration k + 1 before it collects
+    # iterate k, so the GPU never waits for the copy to the host and the pickling.  Results are those of step(), bit for bit.
+    def step_begin(self):
+        self.t += 1
+        self.engine.step_begin()
+        self._inflight.append(self.t)
+
+    def step_end(self, copy=True):
+        """(image, trace, iteration index) of the oldest iteration begun and not yet collected.  copy=False: the image is a
+        read-only view that stays valid for the next Engine.STEP_VIEW_LIFETIME calls of step_begin."""
+        image, values, _ = self.engine.step_end(copy)
+        index = self._inflight.pop(0)
+        t = self._make_trace(values, True)
+        t('fevals', index)
+        self.traces.append(t)
+        return image, t.data, index
+
+    @property
+    def steps_pending(self):
+        return len(self._inflight)
 
     def step_async(self):
         """Device-resident iteration: nothing is read back, the call does not wait for the GPU."""

@@ -150,6 +150,62 @@ def test_worker_protocol_order_and_iterates():
     assert 'set_weights' in tr.calls and 'set_step_size' in tr.calls and tr.calls[-1] == 'start'
 
 
+class FakePipelinedTransfer(FakeTransfer):
+    """A backend with the two-half iteration (st_step_begin / st_step_end): at most two in flight, results in begin order."""
+    def __init__(self, max_steps=5, on_begin=None):
+        super().__init__(max_steps)
+        self.inflight, self.on_begin = [], on_begin
+
+    def step(self):
+        raise AssertionError('the pipelined loop never calls step()')
+
+    def step_begin(self):
+        assert len(self.inflight) < 2, 'more than two iterations in flight'
+        self.t += 1
+        self.inflight.append(self.t)
+        self.calls.append('begin%d' % self.t)
+        if self.t >= self.max_steps:
+            self.is_running = False
+        if self.on_begin:
+            self.on_begin(self.t)
+
+    def step_end(self):
+        i = self.inflight.pop(0)
+        self.calls.append('end%d' % i)
+        return np.full((2, 2, 3), i, F32), OrderedDict(loss=float(i), fevals=i), i
+
+    @property
+    def steps_pending(self):
+        return len(self.inflight)
+
+
+@pytest.mark.parametrize('async_iterate', ['0', '1'])
+def test_worker_pipelined_iterations_keep_the_wire_and_the_message_order(async_iterate):
+    """Pipelined loop (worker.py: iteration k + 1 is begun before iterate k is collected): the wire carries what the plain loop
+    sends -- one Iterate per step, in order, Shutdown last -- and a message that arrives mid-run is acted on only after every
+    iteration begun before it has been collected and sent (reference worker.py:380-395 polls between steps)."""
+    img = np.zeros((4, 4, 3), np.uint8)
+    socks = FakeSockets([messages.SetImages(None, img, img, img, True), messages.StartIteration()])
+    tr = FakePipelinedTransfer(5, on_begin=lambda t: socks.inbound.append(messages.SetWeights({'content': {}, 'style': {}, 'deepdream': {}}, {}))
+                               if t == 3 else None)
+    wk = worker_mod.Worker({'async_iterate': async_iterate}, sock_in=socks, sock_out=socks, transfer=tr)
+    assert wk.pipelined
+    wk.run()
+    kinds = [type(m).__name__ for m in socks.sent]
+    assert kinds == ['WorkerReady'] + ['Iterate'] * 5 + ['Shutdown']
+    its = [m for m in socks.sent if isinstance(m, messages.Iterate)]
+    assert [m.i for m in its] == [1, 2, 3, 4, 5] and [m.trace['fevals'] for m in its] == [1, 2, 3, 4, 5]
+    assert [float(m.image[0, 0, 0]) for m in its] == [1, 2, 3, 4, 5]
+    steps = [c for c in tr.calls if c.startswith(('begin', 'end', 'set_weights'))]
+    # one iteration ahead in steady state; everything begun before the message is collected before the message is handled
+    assert steps == ['begin1', 'begin2', 'end1', 'begin3', 'end2', 'end3', 'set_weights', 'begin4', 'begin5', 'end4', 'end5']
+    # the plain loop on a backend without the two halves, or when switched off
+    plain = worker_mod.Worker({'pipeline_iterate': '0'}, sock_in=FakeSockets([]), sock_out=FakeSockets([]), transfer=FakePipelinedTransfer())
+    assert not plain.pipelined
+    plain.close()
+    assert not worker_mod.Worker({}, sock_in=FakeSockets([]), sock_out=FakeSockets([]), transfer=FakeTransfer()).pipelined
+
+
 def test_worker_asks_for_images_when_it_cannot_start_and_survives_garbage():
     sent, tr = run_worker([messages.StartIteration(), 'not a message', messages.PauseIteration()], FakeTransfer())
     assert [type(m).__name__ for m in sent] == ['WorkerReady', 'GetImages', 'Shutdown']

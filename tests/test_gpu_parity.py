@@ -562,11 +562,14 @@ def test_vgg19_odd_default_size_225x300_unaligned_paths():
 
 
 # ------------------------------------------------------------------- the worker loop on the real engine
-@pytest.mark.parametrize('precision,cfg16', [('fp32', None), ('bf16', None), ('bf16', '0')])
-def test_worker_end_to_end_on_gpu_with_resample_and_optimizer_switch(precision, cfg16, monkeypatch):
+@pytest.mark.parametrize('precision,cfg16,pipeline', [('fp32', None, '0'), ('fp32', None, '1'), ('bf16', None, '1'), ('bf16', '0', '0')])
+def test_worker_end_to_end_on_gpu_with_resample_and_optimizer_switch(precision, cfg16, pipeline, monkeypatch):
     """The drop-in worker.py driven through its message protocol (in-process sockets) on the HIP engine:
     SetImages / SetWeights / SetOptimizer / Start, iterates, a RESAMPLE of input+content to a new size with a live
-    Adam optimizer (host Pillow path, optimizers.py:29-40), an optimizer switch, pause, shutdown."""
+    Adam optimizer (host Pillow path, optimizers.py:29-40), an optimizer switch, pause, shutdown.  The script injects a message
+    the moment the N-th Iterate is on the wire.  Plain loop: the message is polled before the next iteration.  Pipelined loop
+    (the default): iteration N + 1 has been begun by then, so its iterate goes out first and the message acts one iteration
+    later -- as any message does that arrives while an iteration is running."""
     import sys, os, pickle
     from collections import deque
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -609,20 +612,25 @@ def test_worker_end_to_end_on_gpu_with_resample_and_optimizer_switch(precision, 
                           messages.SetWeights({'content': {'conv2_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1}, 'deepdream': {}},
                                               {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}),
                           messages.SetOptimizer('adam', 10), messages.StartIteration()])
-    wk = worker_mod.Worker({'async_iterate': '0'}, sock_in=socks, sock_out=socks, transfer=tr)
+    wk = worker_mod.Worker({'async_iterate': '0', 'pipeline_iterate': pipeline}, sock_in=socks, sock_out=socks, transfer=tr)
+    assert wk.pipelined == (pipeline == '1')
     wk.run()
     kinds = [type(m).__name__ for m in socks.sent]
-    assert kinds[0] == 'WorkerReady' and kinds[-1] == 'Shutdown' and kinds.count('Iterate') == 9
+    late = 1 if pipeline == '1' else 0                          # iterations already begun when a message arrives
+    assert kinds[0] == 'WorkerReady' and kinds[-1] == 'Shutdown' and kinds.count('Iterate') == 9 + late
+    assert kinds == ['WorkerReady'] + ['Iterate'] * (9 + late) + ['Shutdown']
     its = [m for m in socks.sent if isinstance(m, messages.Iterate)]
-    assert [m.i for m in its] == [1, 2, 3, 4, 5, 6, 1, 2, 3]     # SetOptimizer with a new class resets t (worker.py:387-391)
-    assert its[2].image.shape == (32, 40, 3) and its[3].image.shape == (48, 64, 3)       # resampled after iterate 3
+    # SetOptimizer with a new class resets t (worker.py:387-391)
+    assert [m.i for m in its] == list(range(1, 7 + late)) + [1, 2, 3]
+    assert its[2 + late].image.shape == (32, 40, 3) and its[3 + late].image.shape == (48, 64, 3)       # resampled after iterate 3 (+ 1)
     assert all(np.isfinite(m.trace['loss']) and m.image.dtype == F32 for m in its)
-    assert its[5].trace['loss'] != its[4].trace['loss']        # still iterating after the resample
+    assert its[5 + late].trace['loss'] != its[4 + late].trace['loss']        # still iterating after the resample
     assert 'conv1_1_s_grad' in its[-1].trace and its[-1].trace['fevals'] == 3
     assert isinstance(tr.optimizer, st2.LBFGSOptimizer)
 
 
-def test_worker_async_iterate_on_gpu_keeps_order_one_iterate_per_step_shutdown_last():
+@pytest.mark.parametrize('pipeline', ['1', '0'])
+def test_worker_async_iterate_on_gpu_keeps_order_one_iterate_per_step_shutdown_last(pipeline):
     """SURVEY 8f item 3 on the real engine: with the sender thread (async_iterate = 1, the default) the wire still
     carries WorkerReady first, exactly one Iterate per step in step order, Shutdown last (reference worker.py:333,
     351-353, 362-363), and the iterates are the ones a synchronous run of the same job produces, bit for bit."""
@@ -665,9 +673,9 @@ def test_worker_async_iterate_on_gpu_keeps_order_one_iterate_per_step_shutdown_l
 
     socks = Socks()
     socks.inbound.extend(script())
-    wk = worker_mod.Worker({'async_iterate': '1'}, sock_in=socks, sock_out=socks,
+    wk = worker_mod.Worker({'async_iterate': '1', 'pipeline_iterate': pipeline}, sock_in=socks, sock_out=socks,
                            transfer=st2.StyleTransfer(st2.HipModel(params, topology=topo)))
-    assert isinstance(wk.sock_out, worker_mod.AsyncSender)
+    assert isinstance(wk.sock_out, worker_mod.AsyncSender) and wk.pipelined == (pipeline == '1')
     wk.run()
     kinds = [type(m).__name__ for m in socks.sent]
     assert kinds[0] == 'WorkerReady' and kinds[-1] == 'Shutdown' and kinds.count('Shutdown') == 1
@@ -685,6 +693,34 @@ def test_worker_async_iterate_on_gpu_keeps_order_one_iterate_per_step_shutdown_l
     for m in its:
         img, tr = ref.step()
         assert np.array_equal(m.image, img) and m.trace['loss'] == tr['loss'], m.i
+
+
+@pytest.mark.parametrize('kind,step', [('adam', 10), ('lbfgs', 1)])
+def test_two_half_iteration_is_the_plain_one_bit_for_bit(kind, step):
+    """st_step_begin / st_step_end (iteration k + 1 queued before iterate k is collected) against st_step on a twin job: same
+    images, same traces; at most two in flight, st_step refuses while any is, end without begin is an error."""
+    g = load('transfer_tiny.npz')
+    params = json.loads(str(g['params_json']))
+    a, b = engine_transfer(g, kind, step, params), engine_transfer(g, kind, step, params)
+    got = []
+    a.step_begin()
+    for _ in range(6):
+        a.step_begin()
+        assert a.steps_pending == 2 and a.engine.steps_pending() == 2
+        got.append(a.step_end())
+    with pytest.raises(st2.StError, match='already in flight'):
+        a.engine.step_begin(); a.engine.step_begin()
+    with pytest.raises(st2.StError, match='in flight'):
+        a.engine.step()
+    got.append(a.step_end())                               # the oldest first
+    a.engine.step_end()                                    # (the extra begin above; not tracked by the StyleTransfer)
+    assert a.engine.steps_pending() == 0
+    with pytest.raises(st2.StError, match='no iteration in flight'):
+        a.engine.step_end()
+    for i, (img, trace, index) in enumerate(got):
+        ref_img, ref_trace = b.step()
+        assert index == i + 1 and np.array_equal(img, ref_img)
+        assert {k: v for k, v in trace.items() if k != 'time'} == {k: v for k, v in ref_trace.items() if k != 'time'}
 
 
 def test_engine_error_paths_are_loud():

@@ -159,6 +159,16 @@ class Worker:
             async_send = str(config.get('async_iterate', '1')).lower() not in ('0', 'false', 'no')
             if async_send:
                 self.sock_out = AsyncSender(sock_out)
+            # pipelined iterations (backends that offer step_begin / step_end): iteration k + 1 is queued on the GPU before
+            # iterate k is collected and sent.  What goes out, and in which order, is unchanged: every pending iterate is sent
+            # before a received message is acted on.
+            self.pipelined = (hasattr(self.transfer, 'step_begin') and
+                              str(config.get('pipeline_iterate', '1')).lower() not in ('0', 'false', 'no'))
+            # An iterate may be sent straight out of the engine's rotating pinned buffers (no 12.6 MB host copy on this thread)
+            # when nothing can hold it for long: a direct send pickles it at once, the sender thread is at most
+            # queue depth + 1 = 3 iterates behind, plus the one being handed over -- inside the five further begins a view survives.
+            lifetime = getattr(getattr(self.transfer, 'engine', None), 'STEP_VIEW_LIFETIME', 0)
+            self._end_kwargs = {'copy': False} if self.pipelined and lifetime >= 5 else {}
             self.sock_out.send_pyobj(WorkerReady(layers=self.transfer.model.layers()))
         except BaseException:
             self.close()            # the reference always reaches ctx.destroy(0) (worker.py:429-431)
@@ -171,16 +181,29 @@ class Worker:
         if self._ctx is not None:
             self._ctx.destroy(0)
 
+    def _flush_pending(self):
+        """Collect and send every iteration that was begun (pipelined mode), oldest first."""
+        tr = self.transfer
+        while getattr(tr, 'steps_pending', 0):
+            image, trace, index = tr.step_end(**self._end_kwargs)
+            self.sock_out.send_pyobj(Iterate(image, index, trace))
+
     def run(self):
         try:
             while not self.run_should_stop:
                 if self.transfer.is_running:
                     self._drain_then_step()
-                elif self.process_message(self.sock_in.recv_pyobj()):
-                    break
+                else:
+                    self._flush_pending()
+                    if self.process_message(self.sock_in.recv_pyobj()):
+                        break
         except KeyboardInterrupt:
             pass
         finally:
+            try:
+                self._flush_pending()
+            except Exception:                 # the reference always reaches Shutdown (worker.py:396-398)
+                logger.exception('could not collect the iterations in flight')
             self.sock_out.send_pyobj(Shutdown())
             if isinstance(self.sock_out, AsyncSender):       # Shutdown is the last thing on the wire
                 sender, self.sock_out = self.sock_out, self._raw_out
@@ -190,18 +213,26 @@ class Worker:
         """Handle everything queued without blocking, then do exactly one iteration."""
         try:
             while True:
-                if self.process_message(self.sock_in.recv_pyobj(self._noblock)):
+                msg = self.sock_in.recv_pyobj(self._noblock)
+                self._flush_pending()             # whatever was computed before the message arrived goes out first
+                if self.process_message(msg):
                     self.run_should_stop = True
                     return
         except self._again:
             pass
         if not self.transfer.is_running:
             return
-        if self.transfer.check_consistency():
+        if not self.transfer.check_consistency():
+            self._flush_pending()
+            self.sock_out.send_pyobj(GetImages())
+        elif self.pipelined:
+            self.transfer.step_begin()            # queue iteration k + 1 ...
+            if self.transfer.steps_pending > 1:   # ... then collect and send iterate k while the GPU works on it
+                image, trace, index = self.transfer.step_end(**self._end_kwargs)
+                self.sock_out.send_pyobj(Iterate(image, index, trace))
+        else:
             image, trace = self.transfer.step()
             self.sock_out.send_pyobj(Iterate(image, self.transfer.t, trace))
-        else:
-            self.sock_out.send_pyobj(GetImages())
 
     def process_message(self, msg):
         """Returns True when the worker should shut down."""
