@@ -162,7 +162,15 @@ int st_tile_style_raw(st_ctx* ctx);
 int st_tile_losses_finish(st_ctx* ctx);
 int st_tile_backward(st_ctx* ctx, float** dev_grad);
 int st_tile_update(st_ctx* ctx, const float* ring_dev, float** dev_ptr, int* n_floats);
-/* which: 0 current x (3,wh,ww), 1 next x, 2 local sum D^2 per style layer, 3 norms [blob][c,s,d] */
+/* st_tile_update without the optimizer: the combined gradient (network + TV + p-norm) of the tile's pixels is written to the
+ * window-sized gradient buffer (st_tile_buffer 4), the six partial sums (+ style-gradient sums) come back as from st_tile_update.
+ * The tile-sharded L-BFGS (optimizers.py:62-108 with all-reduced dot products) evaluates its objective through this. */
+int st_tile_gradient(st_ctx* ctx, const float* ring_dev, float** dev_ptr, int* n_floats);
+/* utils.dot / utils.axpy (utils.py:29-47) on vectors the caller keeps on this device: out_dev[0] = sum a b (this rank's partial
+ * sum, to be all-reduced); y = alpha x + y.  Both return when the result is in place. */
+int st_vec_dot(st_ctx* ctx, const float* a_dev, const float* b_dev, long long n, float* out_dev);
+int st_vec_axpy(st_ctx* ctx, float alpha, const float* x_dev, float* y_dev, long long n);
+/* which: 0 current x (3,wh,ww), 1 next x, 2 local sum D^2 per style layer, 3 norms [blob][c,s,d], 4 gradient (3,wh,ww) */
 int st_tile_buffer(st_ctx* ctx, int which, float** dev_ptr);
 int st_tile_swap(st_ctx* ctx);
 /* strips exchanged with ONE neighbour: rects [n][4] = {y0, x0, h, w} (window coordinates, n <= 12) of the (C, wh, ww) device

@@ -84,6 +84,9 @@ PROTOTYPES = {
     'st_tile_update': (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_int)]),
     'st_tile_buffer': (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
     'st_tile_swap': (c_int, [c_void_p]),
+    'st_tile_gradient': (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_int)]),
+    'st_vec_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
+    'st_vec_axpy': (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_longlong]),
     'st_tile_strips': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), c_void_p, c_int]),
 }
 

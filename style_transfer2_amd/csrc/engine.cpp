@@ -1952,6 +1952,53 @@ int st_tile_update(st_ctx* c, const float* ring_dev, float** dev_ptr, int* n_flo
     return ST_OK;
 }
 
+// The same image-space pass without an optimizer update: the combined gradient of the tile's pixels goes to the window-sized
+// gradient buffer (st_tile_buffer 4), the partial sums come back as from st_tile_update.  The tile-sharded L-BFGS
+// (style_transfer2_amd/tiled.py) evaluates the objective with it and owns the update itself.
+int st_tile_gradient(st_ctx* c, const float* ring_dev, float** dev_ptr, int* n_floats)
+{
+    if (c) c->epoch++;
+    if (!c || !c->tile.on || !ring_dev) return fail(ST_ERR_STATE, "st_tile_configure first");
+    HIP_TRY(hipSetDevice(c->device));
+    const st_ctx::Tile& t = c->tile;
+    ST_TRY(tile_ensure(&c->tile.p3, &c->tile.p3_n, 6 + kMaxTraceLayers));
+    ImageTileArgs ta{};
+    ImagePassArgs& ip = ta.base;
+    ip.x = c->x[c->cur]; ip.scd = c->tile.wgrad; ip.grad = c->grad; ip.C = 3; ip.H = c->H; ip.W = c->W;
+    ip.tv_w = c->tv_w; ip.tv_beta = c->tv_pow; ip.p_w = c->p_w; ip.p_pow = c->p_pow; ip.partial = c->image_part;
+    ip.x_out = nullptr;
+    ta.ring = ring_dev; ta.ty = t.ty0 - t.wy0; ta.tx = t.tx0 - t.wx0; ta.th = t.ty1 - t.ty0; ta.tw = t.tx1 - t.tx0;
+    int np = 0;
+    HIP_TRY(launch_image_pass_tile(ta, &np, c->stream));
+    for (int k = 0; k < 6; ++k) HIP_TRY(launch_sum_partials(c->image_part + k * kMaxPartials, np, c->tile.p3 + k, c->stream));
+    int n_style = 0;
+    for (const ActiveLayer& al : c->active) n_style += al.s;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (dev_ptr) *dev_ptr = c->tile.p3;
+    if (n_floats) *n_floats = 6 + (c->tile.s2_in_p2 ? 0 : n_style);
+    return ST_OK;
+}
+
+// BLAS-1 pieces for a caller that keeps its own vectors on this device (the tile-sharded L-BFGS): out_dev[0] = sum a b over n
+// elements (this rank's partial sum; fixed summation order), y = alpha x + y.  Synchronous with respect to the host.
+int st_vec_dot(st_ctx* c, const float* a_dev, const float* b_dev, long long n, float* out_dev)
+{
+    if (!c || !a_dev || !b_dev || !out_dev || n < 0) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_vec_dot(a_dev, b_dev, (size_t)n, c->image_part, out_dev, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
+int st_vec_axpy(st_ctx* c, float alpha, const float* x_dev, float* y_dev, long long n)
+{
+    if (!c || !x_dev || !y_dev || n < 0) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_vec_axpy(alpha, x_dev, y_dev, (size_t)n, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
 // device pointers of the buffers the caller exchanges: which = 0 current x, 1 next x, 2 local sum D^2 per style layer
 int st_tile_buffer(st_ctx* c, int which, float** dev_ptr)
 {
@@ -1962,6 +2009,7 @@ int st_tile_buffer(st_ctx* c, int which, float** dev_ptr)
     else if (which == 1) *dev_ptr = c->x[c->cur ^ 1];
     else if (which == 2) *dev_ptr = c->tile.pd;
     else if (which == 3) *dev_ptr = c->norms;
+    else if (which == 4) *dev_ptr = c->grad;
     else return fail(ST_ERR_ARG, "unknown buffer %d", which);
     return ST_OK;
 }

@@ -727,6 +727,37 @@ hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------- BLAS-1 pieces of the tile-sharded L-BFGS
+// (optimizers.py:89-108 with utils.dot / utils.axpy = sdot / saxpy): every rank holds its tile of each vector, the dot products
+// are per-rank partial sums that the caller all-reduces.  HBM-bound, 4 or 8 bytes read per element.
+__global__ __launch_bounds__(256) void vec_dot_k(const float* __restrict__ a, const float* __restrict__ b, size_t n, float* __restrict__ part)
+{
+    __shared__ float scratch[8];
+    float acc[1] = {0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc[0] += a[i] * b[i];
+    block_sum(acc, scratch);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc[0];
+}
+
+hipError_t launch_vec_dot(const float* a, const float* b, size_t n, float* part, float* out, hipStream_t s)
+{
+    const int grid = reduce_grid(n, 256 * 8, kMaxPartials);
+    vec_dot_k<<<grid, 256, 0, s>>>(a, b, n, part);
+    dot_final_k<<<1, 256, 0, s>>>(part, grid, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void vec_axpy_k(float alpha, const float* __restrict__ x, float* __restrict__ y, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = alpha * x[i] + y[i];
+}
+
+hipError_t launch_vec_axpy(float alpha, const float* x, float* y, size_t n, hipStream_t s)
+{
+    vec_axpy_k<<<reduce_grid(n, 256 * 4, 8192), 256, 0, s>>>(alpha, x, y, n);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void lincomb_k(float a, const float* x, float b, const float* y, float* z, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {

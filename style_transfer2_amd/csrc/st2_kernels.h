@@ -290,5 +290,8 @@ hipError_t launch_lbfgs_two_loop(const LbfgsArgs& a, hipStream_t s);
 hipError_t launch_lbfgs_pair(const LbfgsArgs& a, const float* g_new, int mode, hipStream_t s);
 // z = a*x + b*y  (host scalars; y may be nullptr)
 hipError_t launch_lincomb(float a, const float* x, float b, const float* y, float* z, size_t n, hipStream_t s);
+// tile-sharded L-BFGS: *out = sum a[i] b[i] over this rank's n elements (part: kMaxPartials floats of scratch); y = alpha x + y
+hipError_t launch_vec_dot(const float* a, const float* b, size_t n, float* part, float* out, hipStream_t s);
+hipError_t launch_vec_axpy(float alpha, const float* x, float* y, size_t n, hipStream_t s);
 
 }  // namespace st2

@@ -125,6 +125,66 @@ class HipTileBackend:
         self.p3 = dev_tensor(p.value, (n.value,), self.device)
         return self.p3
 
+    # ---- L-BFGS pieces (tiled.TiledTransfer, optimizer='lbfgs'): vectors are compact (3, th, tw) tile tensors ----------------
+    def _tile_rect(self):
+        t, w = self.grid.tiles[self.rank], self.grid.windows[self.rank]
+        return [(t.y0 - w.y0, t.x0 - w.x0, t.y1 - t.y0, t.x1 - t.x0)]
+
+    def gradient(self, ring):
+        """The image-space pass without an optimizer (st_tile_gradient): partial sums as update() returns them; the combined
+        gradient of the tile is then available from grad_tile()."""
+        ring = ring.contiguous()
+        torch.cuda.synchronize(self.device)
+        self._ring = ring
+        p, n = c_void_p(), c_int()
+        check(self.lib.st_tile_gradient(self.ctx, c_void_p(ring.data_ptr()), byref(p), byref(n)))
+        self.p3 = dev_tensor(p.value, (n.value,), self.device)
+        return self.p3
+
+    def vnew(self):
+        t = self.grid.tiles[self.rank]
+        return torch.empty((3, t.y1 - t.y0, t.x1 - t.x0), dtype=torch.float32, device=self.device)
+
+    def grad_tile(self):
+        out = self.vnew()
+        self.strips(self._buf(4, (3, self.wh, self.ww)), self._tile_rect(), out.reshape(-1), 0)
+        return out
+
+    def vcopy(self, v):
+        out = self.vnew()
+        out.copy_(v)                                    # (device-to-device copy: memory plumbing)
+        torch.cuda.synchronize(self.device)
+        return out
+
+    def vdot(self, a, b):
+        """This rank's partial sum of <a, b> as a 1-element device tensor (utils.dot, utils.py:29-36)."""
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        check(self.lib.st_vec_dot(self.ctx, c_void_p(a.data_ptr()), c_void_p(b.data_ptr()), a.numel(), c_void_p(out.data_ptr())))
+        return out
+
+    def vaxpy(self, alpha, x, y):
+        """y += alpha x (utils.axpy, utils.py:38-47)."""
+        torch.cuda.synchronize(self.device)
+        check(self.lib.st_vec_axpy(self.ctx, float(F32(alpha)), c_void_p(x.data_ptr()), c_void_p(y.data_ptr()), x.numel()))
+
+    def vscale(self, alpha, y):
+        """y *= alpha, as y = (alpha - 1) y + y would not round the same way: axpy onto a zeroed vector."""
+        src = self.vcopy(y)
+        y.zero_()
+        self.vaxpy(alpha, src, y)
+
+    def apply_step(self, s):
+        """x_next[tile] = x_cur[tile] + s; the rest of x_next starts as a copy of x_cur (its apron is refreshed by the caller)."""
+        xt = self.vnew()
+        rect = self._tile_rect()
+        self.strips(self.x_cur(), rect, xt.reshape(-1), 0)
+        self.vaxpy(1.0, s, xt)
+        nxt = self.x_next()
+        nxt.copy_(self.x_cur())
+        torch.cuda.synchronize(self.device)
+        self.strips(nxt, rect, xt.reshape(-1), 1)
+
     def finish_trace(self):
         """Trace scalars from the reduced sums, in the reference's fp32 order (worker.py:249-301); same layout
         as the single-GPU engine: 6 per active layer + 8."""

@@ -69,9 +69,22 @@ def _local(rect, origin):
 
 
 class TiledTransfer:
-    def __init__(self, grid, rank, backend, comm):
+    """optimizer='adam': the backend's fused image pass + Adam update (one evaluation per step).
+    optimizer='lbfgs': LBFGSOptimizer (optimizers.py:49-125) over the tile-sharded image: every rank keeps its tile of x, of the
+    gradient and of the <= 10 curvature pairs; each utils.dot of the two-loop recursion is a per-rank partial sum + one scalar
+    all-reduce, every axpy is local.  The backend supplies gradient / grad_tile / vdot / vaxpy / vscale / vcopy / apply_step."""
+
+    N_CORR = 10                                     # optimizers.py:52
+
+    def __init__(self, grid, rank, backend, comm, optimizer='adam', step_size=None):
         self.grid, self.rank, self.backend, self.comm = grid, rank, backend, comm
         self.window, self.tile = grid.windows[rank], grid.tiles[rank]
+        if optimizer not in ('adam', 'lbfgs'):
+            raise ValueError('optimizer must be adam or lbfgs')
+        self.optimizer = optimizer
+        self.step_size = np.float32(1 if step_size is None else step_size)      # L-BFGS only; Adam's lives in the backend
+        self.sk, self.yk, self.syk = [], [], []
+        self.lb_grad = None
         self.t = 0
         self._refresh = grid.apron_refresh_plan()
         self._overlap = grid.grad_overlap_plan()
@@ -156,10 +169,74 @@ class TiledTransfer:
         self._exchange(x, sends, ring, recvs, add=False)
         return ring
 
+    # -- L-BFGS over the sharded image ----------------------------------------------------------------------
+    def _evaluate(self):
+        """opfunc at the current image: the trace values; the backend's grad_tile() then holds this rank's part of the gradient."""
+        b = self.backend
+        self.comm.all_reduce(b.forward_partials())
+        extra = b.losses_need_style_norm()
+        if extra is not None:
+            self.comm.all_reduce(extra)
+        b.finish_losses()
+        g = b.backward()
+        self.overlap_add(g)
+        ring = self.gather_ring(b.x_cur())
+        self.comm.all_reduce(b.gradient(ring))
+        return b.finish_trace()
+
+    def _dot(self, a, c):
+        """utils.dot over the whole image: partial sums of the ranks, all-reduced; float32 like sdot's result."""
+        t = self.backend.vdot(a, c)
+        self.comm.all_reduce(t)
+        return np.float32(t.reshape(-1)[0].item())
+
+    def _inv_hv(self, grad):
+        """optimizers.py:89-108, statement by statement; scalars are float32 as the reference's sdot results are."""
+        b = self.backend
+        p = b.vcopy(grad)
+        alphas = []
+        for s, y, sy in zip(reversed(self.sk), reversed(self.yk), reversed(self.syk)):
+            alphas.append(self._dot(s, p) / sy)
+            b.vaxpy(-alphas[-1], y, p)
+        if self.sk:
+            sy, y = self.syk[-1], self.yk[-1]
+            b.vscale(sy / self._dot(y, y), p)
+        else:       # no curvature information: a unit-RMS direction (p.size is the WHOLE image's)
+            n = np.float32(3 * self.grid.gH * self.grid.gW)
+            b.vscale(np.float32(1) / np.sqrt(self._dot(p, p) / n), p)
+        for s, y, sy, alpha in zip(self.sk, self.yk, self.syk, reversed(alphas)):
+            beta = self._dot(y, p) / sy
+            b.vaxpy(alpha - beta, s, p)
+        return p
+
+    def _lbfgs_step(self):
+        b = self.backend
+        if self.lb_grad is None:                    # optimizers.py:64-65
+            self._evaluate()
+            self.lb_grad = b.grad_tile()
+        s = self._inv_hv(self.lb_grad)              # s = -step_size * inv_hv(grad)            :68
+        b.vscale(-self.step_size, s)
+        b.apply_step(s)                             # x += s                                   :69
+        self.refresh_aprons(b.x_next())
+        b.swap()
+        values = self._evaluate()                   # loss, grad = opfunc(x)                   :72
+        g1 = b.grad_tile()
+        y = b.vcopy(g1)
+        b.vaxpy(-1.0, self.lb_grad, y)              # y = grad - self.grad                     :73
+        sy = self._dot(s, y)                        # store_curvature_pair                     :79-87
+        if sy > 1e-10:
+            self.sk.append(s); self.yk.append(y); self.syk.append(sy)
+        if len(self.sk) > self.N_CORR:
+            self.sk, self.yk, self.syk = self.sk[1:], self.yk[1:], self.syk[1:]
+        self.lb_grad = g1
+        return values
+
     # -- one iteration ----------------------------------------------------------------------------------------
     def step(self):
         b = self.backend
         self.t += 1
+        if self.optimizer == 'lbfgs':
+            return self._lbfgs_step()
         self.comm.all_reduce(b.forward_partials())
         extra = b.losses_need_style_norm()
         if extra is not None:

@@ -392,7 +392,32 @@ def test_tiled_single_rank_equals_plain_engine():
         assert np.allclose(tt.tile_image(), img, rtol=0, atol=2e-3), i
 
 
-def _tiled_gpu_rank(rank, world, rows, cols, port, steps, h, w, q):
+@pytest.mark.parametrize('h,w', [(32, 48), (75, 100)])
+def test_tiled_lbfgs_single_rank_equals_plain_engine(h, w):
+    """optimizer='lbfgs' on a 1x1 grid (every all-reduce a no-op) against the engine's device-resident L-BFGS: the same
+    optimizers.py:62-108 recursion, once as host-sequenced st_vec_dot / st_vec_axpy calls on tile vectors, once as the fused
+    device state machine (lbfgs.hip).  12 steps: the pair memory (10) rolls over."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    content, style, init = _tiled_images(h, w)
+    params = oracle.he_init_weights(TILED_TOPO, 0, 0.1)
+    grid = tiling.TileGrid(h, w, 1, 1, TILED_TOPO, 5)
+    tt = tiled.TiledTransfer(grid, 0, HipTileBackend(params, grid, 0, content, style, init, TILED_WEIGHTS, TILED_PARAMS,
+                                                     step_size=1, topology=TILED_TOPO), tiled.Comm(), optimizer='lbfgs', step_size=1)
+    ref = st2.StyleTransfer(st2.HipModel(params, topology=TILED_TOPO))
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(TILED_WEIGHTS, TILED_PARAMS)
+    ref.optimizer_cls = st2.LBFGSOptimizer; ref.set_step_size(1); ref.reset()
+    assert ref.start()
+    for i in range(12):
+        vals = tt.step()
+        img, tr = ref.step()
+        # two fp32 implementations of a quasi-Newton path: tight while the history is short, then they drift apart slowly
+        assert np.isclose(vals[-2], tr['loss'], rtol=1e-5 if i < 3 else 5e-3), (i, vals[-2], tr['loss'])
+        assert np.mean((tt.tile_image() - img) ** 2) <= (1e-4 if i < 3 else 0.1), i
+
+
+def _tiled_gpu_rank(rank, world, rows, cols, port, steps, h, w, q, optimizer='adam'):
     import os, sys
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -403,7 +428,8 @@ def _tiled_gpu_rank(rank, world, rows, cols, port, steps, h, w, q):
     grid = tiling.TileGrid(h, w, rows, cols, TILED_TOPO, 5)
     backend = HipTileBackend(oracle.he_init_weights(TILED_TOPO, 0, 0.1), grid, rank, content, style, init,
                              TILED_WEIGHTS, TILED_PARAMS, step_size=10, topology=TILED_TOPO)
-    tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world))
+    tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world), optimizer=optimizer,
+                             step_size={'adam': 10, 'lbfgs': 1}[optimizer])
     res = []
     for _ in range(steps):
         vals = tt.step()
@@ -411,6 +437,38 @@ def _tiled_gpu_rank(rank, world, rows, cols, port, steps, h, w, q):
     q.put((rank, tuple(grid.tiles[rank]), res))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_tiled_lbfgs_two_ranks_on_one_gpu_match_oracle():
+    """Two processes share the GPU, each with its tile of x, of the gradient and of the curvature pairs; the dot products of the
+    two-loop recursion cross ranks as scalar all-reduces (gloo here, RCCL on a node).  Against the single-process CPU oracle."""
+    import torch.multiprocessing as mp
+    h, w, steps, world = 32, 48, 6, 2
+    content, style, init = _tiled_images(h, w)
+    cpu = oracle.TransferOracle(oracle.NetOracle(TILED_TOPO, oracle.he_init_weights(TILED_TOPO, 0, 0.1)))
+    cpu.set_input(init); cpu.set_content(content); cpu.set_style(style); cpu.reset()
+    cpu.set_weights(TILED_WEIGHTS, TILED_PARAMS); cpu.set_optimizer('lbfgs', 1)
+    assert cpu.start()
+    ref = []
+    for _ in range(steps):
+        img, tr = cpu.step()
+        ref.append((np.asarray(img, F32).copy(), dict(tr)))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29100 + __import__('os').getpid() % 150
+    procs = [ctx.Process(target=_tiled_gpu_rank, args=(r, world, 1, 2, port, steps, h, w, q, 'lbfgs')) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for step in range(steps):
+        full = np.zeros_like(ref[step][0])
+        for rank, (y0, x0, y1, x1), res in got:
+            full[y0:y1, x0:x1] = res[step][0]
+            assert np.isclose(res[step][1][-2], ref[step][1]['loss'], rtol=1e-4 if step < 3 else 1e-2), (step, rank)
+        assert np.mean((full - ref[step][0]) ** 2) <= (1e-3 if step < 3 else 1.0), step
 
 
 @pytest.mark.parametrize('rows,cols', [(1, 2), (2, 2)])

@@ -156,6 +156,40 @@ class OracleTileBackend:
         return torch.from_numpy(self.g)
 
     # ---- phase 4 ---------------------------------------------------------------------------------------
+    def _tile_slices(self):
+        t, w = self.tile, self.win
+        return slice(t.y0 - w.y0, t.y1 - w.y0), slice(t.x0 - w.x0, t.x1 - w.x0)
+
+    # ---- L-BFGS pieces (tiled.TiledTransfer, optimizer='lbfgs'): plain fp32 numpy on the tile ------------------------------
+    def gradient(self, ring):
+        self._no_update = True
+        try:
+            return self.update(ring)
+        finally:
+            self._no_update = False
+
+    def grad_tile(self):
+        return torch.from_numpy(self._grad_tile.copy())
+
+    def vcopy(self, v):
+        return v.clone()
+
+    def vdot(self, a, b):
+        from scipy.linalg import blas
+        return torch.from_numpy(np.asarray([blas.sdot(a.numpy().ravel(), b.numpy().ravel())], F32))      # utils.dot on this rank's part
+
+    def vaxpy(self, alpha, x, y):
+        y.numpy()[...] = F32(alpha) * x.numpy() + y.numpy()
+
+    def vscale(self, alpha, y):
+        y.numpy()[...] = F32(alpha) * y.numpy()
+
+    def apply_step(self, s):
+        ys, xs = self._tile_slices()
+        nxt = self.x[self.cur ^ 1]
+        nxt[...] = self.x[self.cur]
+        nxt[0][:, ys, xs] = self.x[self.cur][0][:, ys, xs] + s.numpy()
+
     def update(self, ring):
         t, w = self.tile, self.win
         ys, xs = slice(t.y0 - w.y0, t.y1 - w.y0), slice(t.x0 - w.x0, t.x1 - w.x0)
@@ -182,6 +216,13 @@ class OracleTileBackend:
         pg = self.params['p'] * g_p
         grad = scd + tg
         grad = grad + pg
+        self._grad_tile = np.ascontiguousarray(grad, F32)
+        if getattr(self, '_no_update', False):
+            sq = lambda z: np.sum(z.astype(np.float64)**2)
+            img = [tv_val, p_val, sq(scd), sq(tg), sq(pg), sq(grad)]
+            s2 = [] if self._s2_reduced else list(self._s2)
+            self._p3 = np.asarray(img + s2, F32)
+            return torch.from_numpy(self._p3)
         self.items1 += 1
         self.items2 += 1
         self.m = F32(0.9) * self.m + F32(1 - 0.9) * grad

@@ -25,6 +25,7 @@ ap.add_argument('--style-size', type=int, default=1024)
 ap.add_argument('--grid', default='2x4')
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--warmup', type=int, default=2)
+ap.add_argument('--optimizer', default='adam', choices=('adam', 'lbfgs'))
 args = ap.parse_args()
 rows, cols = (int(v) for v in args.grid.split('x'))
 gH, gW = (int(v) for v in args.size.split('x')) if 'x' in args.size else (int(args.size), int(args.size))
@@ -70,7 +71,8 @@ class WindowView:
 style = np.random.RandomState(2).randint(0, 256, (args.style_size, args.style_size, 3)).astype(np.uint8)
 backend = HipTileBackend(st2_weights.he_normal(topo, seed=0), grid, rank, WindowView(window_image(1)), style,
                          WindowView(window_image(3)), WEIGHTS, PARAMS, step_size=10, device=local)
-tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world))
+tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world), optimizer=args.optimizer,
+                         step_size={'adam': 10, 'lbfgs': 1}[args.optimizer])
 for _ in range(args.warmup):
     tt.step()
 backend.engine.sync()
@@ -87,7 +89,7 @@ if rank == 0:
     print(json.dumps({'metric': 'tile-sharded style-transfer iters/sec @%sx%s VGG19' % (gH, gW), 'value': args.steps / dt,
                       'unit': 'it/s', 'n_gpus': world, 'grid': args.grid, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
                       'higher_is_better': True, 'vs_baseline': None,
-                      'config': {'workload': 'configs[4]: ONE %dx%d image tile-sharded %s (apron design, RCCL all-reduces + strip exchange), adam fp32' % (gH, gW, args.grid),
+                      'config': {'workload': 'configs[4]: ONE %dx%d image tile-sharded %s (apron design, RCCL all-reduces + strip exchange), %s fp32' % (gH, gW, args.grid, args.optimizer),
                                  'measured_on_hardware': 'by the driver only; the builder has one GPU'},
                       'apron_px': grid.apron, 'window': [win.y1 - win.y0, win.x1 - win.x0], 'loss': float(vals[-2]),
                       'dtype': 'f32', 'scaling': 'strong', 'data': 'synthetic'}))
