@@ -328,7 +328,7 @@ def main(argv=None):
     if args.tiled:
         import runpy
         sys.argv = [os.path.join(HERE, 'tools', 'bench_tiled.py'), '--size', str(args.size), '--grid', args.tiled,
-                    '--steps', str(args.steps), '--warmup', str(args.warmup)]
+                    '--steps', str(args.steps), '--warmup', str(args.warmup), '--optimizer', args.optimizer]
         runpy.run_path(sys.argv[0], run_name='__main__')
         return 0
 
