@@ -85,6 +85,8 @@ struct WinoKArgs {
     int K, M, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
     unsigned in_bytes, u_bytes;
     float* pool_out; int pool_h, pool_w;   // optional fused 2x2/2 max-pool of the (post-ReLU) output: [M][pool_h][pool_w]
+    unsigned char* pool_amap;              // optional, with pool_out: [M][pool_h][pool_w] bytes, bits 0-1 = slot of the FIRST maximum
+                                           // (row-major in the window), bit 2 = maximum > 0 after bias: all the pool backward needs
     int splits; float* scratch;   // split-K (few workgroups, deep K): split s accumulates chunks [s, s+1) * nch / splits into scratch[s]
     unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
 };
@@ -131,6 +133,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     static_assert(!W8 || (WM == 4 && TG == 1 && QUAD && !PS), "eight waves: 4 channel slices x 2 position halves, aligned widths");
     static_assert(!H4 || (WM == 2 && TG == 1 && QUAD && !PS && !W8), "half tile: 2 channel slices x 2 position halves, aligned widths");
     constexpr bool RS = W8 || H4;                        // accumulator ROWS of a channel slice are finished by two partner waves
+    constexpr bool AMAP = QUAD && TG == 1;               // builds whose fused pool also writes the arg-max map (register budget)
     constexpr int NW = W8 ? 8 : 4;                       // waves per workgroup
     constexpr int PARTNER = W8 ? 4 : 2;                  // RS: wave ^ PARTNER holds the other position half of the same channel slice
     constexpr bool SPLIT = PS || RS;                     // the 16 positions are split over two waves
@@ -554,11 +557,23 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
                 // even); bias and ReLU commute with max.  A window clipped by the bottom edge keeps its first row only.
                 const int ty2 = y0 + 4 * wave_g + 2 * (t31 >> 4), tx2 = x0 + 2 * (t31 & 15);
                 if (tx2 < a.W && ty2 < a.H && mb + ee < a.M) {
+                    const size_t po = ((size_t)(mb + ee) * a.pool_h + (ty2 >> 1)) * a.pool_w + (tx2 >> 1);
                     float pm = y00 > y01 ? y00 : y01;
                     if (ty2 + 1 < a.H) { const float p1 = y10 > y11 ? y10 : y11; pm = pm > p1 ? pm : p1; }
+                    if constexpr (AMAP) {
+                        // also record WHERE the maximum is (first one of a row-major scan; W % 4 == 0: the window has both columns) and
+                        // whether it is positive after the bias: the pool's backward then reads this byte instead of both blobs
+                        // (compared AFTER the bias, as the stored blob the reference's pooling layer scans is: two sums that round to the
+                        // same float tie there, and the first one wins)
+                        if (a.pool_amap) {
+                            const float qb = pm + bs[ee];
+                            const unsigned slot = y00 + bs[ee] == qb ? 0u : (y01 + bs[ee] == qb ? 1u : (y10 + bs[ee] == qb ? 2u : 3u));
+                            a.pool_amap[po] = (unsigned char)(slot | (qb > 0.f ? 4u : 0u));
+                        }
+                    }
                     pm += bs[ee];
                     if (relu) pm = pm > 0.f ? pm : 0.f;
-                    a.pool_out[((size_t)(mb + ee) * a.pool_h + (ty2 >> 1)) * a.pool_w + (tx2 >> 1)] = pm;
+                    a.pool_out[po] = pm;
                 }
             }
             // give away the row this lane does not keep, receive the partner's part of the row it keeps (quad_perm 1,0,3,2)
@@ -657,6 +672,14 @@ bool conv_wino_can_pool(int K, int M, int H, int W)
     return !off && conv_wino_ok(K, M, H, W) && conv_wino_splits(K, M, H, W) == 1;
 }
 
+// does a fused-pool launch of this shape also write the arg-max map (ConvProblem::pool_amap)?  The one-tile-group builds of aligned widths do.
+bool conv_wino_pool_amap_ok(int K, int M, int H, int W)
+{
+    if (!conv_wino_can_pool(K, M, H, W) || W % 4 != 0 || H % 2 != 0) return false;
+    const int v = wino_default_variant(M, W);
+    return v == 0 || v == 6 || v == 8;
+}
+
 bool conv_wino_ok(int K, int M, int H, int W)
 {
     static const bool anyw = [] { const char* e = getenv("ST2_WINO_ANYW"); return !(e && *e == '0'); }();
@@ -713,6 +736,7 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     k.splits = 1; k.scratch = nullptr;
     k.pool_out = p.pool_out; k.pool_h = (p.H + 1) / 2; k.pool_w = (p.W + 1) / 2;
+    k.pool_amap = (p.pool_out && quad && (variant == 0 || variant == 6 || variant == 8)) ? p.pool_amap : nullptr;
     if (forced_auto && p.scratch) {
         const int sp = conv_wino_splits(p.K, p.M, p.H, p.W);
         if (sp > 1 && p.scratch_floats >= (size_t)sp * p.M * p.H * p.W) { k.splits = sp; k.scratch = p.scratch; }

@@ -401,7 +401,16 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool le
                   if (wino) {
                       p.wpack = L.u_fwd; ST_TRY(wino_scratch(c, p));
                       // the max-pool that follows rides on this launch's epilogue (the pooled blob is written beside the conv blob)
-                      if (i < last && !c->topo[i].is_conv && !c->bf16 && conv_wino_can_pool(p.K, p.M, p.H, p.W)) { p.pool_out = a.data[i + 1]; pooled_by_conv = i + 1; a.has32[i + 1] = 1; }
+                      if (i < last && !c->topo[i].is_conv && !c->bf16 && conv_wino_can_pool(p.K, p.M, p.H, p.W)) {
+                          p.pool_out = a.data[i + 1]; pooled_by_conv = i + 1; a.has32[i + 1] = 1;
+                          // ... and a one-byte arg-max map for the pool's backward (maxpool_bwd_amap_k: neither blob is read again)
+                          const char* ae = getenv("ST2_POOL_AMAP");          // =0: the classic pool backward (read per forward: the tests compare both)
+                          if (!(ae && *ae == '0') && conv_wino_pool_amap_ok(p.K, p.M, p.H, p.W)) {
+                              const size_t pn = (size_t)a.C[i + 1] * a.h[i + 1] * a.w[i + 1];
+                              if (!a.amap[i + 1]) HIP_TRY(hipMalloc((void**)&a.amap[i + 1], pn));
+                              p.pool_amap = a.amap[i + 1]; a.amap_ok[i + 1] = 2;      // 2: the fp32 layout [C][ph][pw]
+                          }
+                      }
                       HIP_TRY(launch_conv3x3_wino(p, c->stream));
                   }
                   else { if (next16 && L.cout % 8 == 0) { p.out16 = a.data16[i]; packed = true; }      // the epilogue writes the bf16 copy too
@@ -571,6 +580,11 @@ static int backward_chain(st_ctx* c, int top, const float* top_diff, const std::
             ProfScope ps(c, P_POOL_BWD, 0, (double)C * (hw_top * 3.0 + hw * 2.0));
             HIP_TRY(launch_maxpool_bwd_idx16(cur16, a.amap[i], dst16, C, a.h[below], a.w[below], c->stream));
             cur16 = dst16; cur = nullptr;
+        } else if (a.amap_ok[i] == 2 && !inject && mask_src && cur) {
+            // pool fused into its producing Winograd conv (fp32): route the diff through the arg-max map, ReLU mask included
+            ProfScope ps(c, P_POOL_BWD, 0, (double)a.C[below] * ((double)a.h[i] * a.w[i] * 5.0 + (double)a.h[below] * a.w[below] * 4.0));
+            HIP_TRY(launch_maxpool_bwd_amap(cur, a.amap[i], dst, a.C[below], a.h[below], a.w[below], c->stream));
+            cur16 = nullptr; cur = dst;
         } else {
             if (!cur) return fail(ST_ERR_STATE, "internal: fp32 diff missing above %s", L.name.c_str());
             if (!a.has32[below]) return fail(ST_ERR_STATE, "internal: pool input blob %d missing", below);

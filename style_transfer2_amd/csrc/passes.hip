@@ -106,6 +106,33 @@ __global__ __launch_bounds__(256) void maxpool_bwd_v4_k(const float* __restrict_
     }
 }
 
+// The same routing from the one-byte arg-max map written by the producing conv's epilogue (bits 0-1 slot, bit 2 maximum > 0):
+// a thread takes two pooled pixels = a 2 x 4 patch of dx.
+__global__ __launch_bounds__(256) void maxpool_bwd_amap_k(const float* __restrict__ dy, const unsigned char* __restrict__ amap,
+                                                          float* __restrict__ dx, size_t n_patches, int W4)
+{
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n_patches; idx += (size_t)gridDim.x * 256) {
+        const size_t q = idx % W4, pr = idx / W4;
+        const size_t o0 = (pr * 2) * (size_t)W4 * 4 + q * 4, o1 = o0 + (size_t)W4 * 4;
+        const size_t po = pr * (size_t)W4 * 2 + q * 2;
+        const float2 g = *reinterpret_cast<const float2*>(dy + po);
+        const unsigned short mm = *reinterpret_cast<const unsigned short*>(amap + po);
+        const unsigned m0 = mm & 0xffu, m1 = mm >> 8;
+        const float g0 = (m0 & 4u) ? g.x : 0.f, g1 = (m1 & 4u) ? g.y : 0.f;
+        const unsigned a0 = m0 & 3u, a1 = m1 & 3u;
+        *reinterpret_cast<float4*>(dx + o0) = make_float4(a0 == 0 ? g0 : 0.f, a0 == 1 ? g0 : 0.f, a1 == 0 ? g1 : 0.f, a1 == 1 ? g1 : 0.f);
+        *reinterpret_cast<float4*>(dx + o1) = make_float4(a0 == 2 ? g0 : 0.f, a0 == 3 ? g0 : 0.f, a1 == 2 ? g1 : 0.f, a1 == 3 ? g1 : 0.f);
+    }
+}
+
+hipError_t launch_maxpool_bwd_amap(const float* dy, const unsigned char* amap, float* dx, int C, int H, int W, hipStream_t s)
+{
+    if (H % 2 != 0 || W % 4 != 0 || (reinterpret_cast<uintptr_t>(amap) & 1) != 0) return hipErrorInvalidValue;
+    const size_t n_patches = (size_t)C * (H / 2) * (W / 4);
+    maxpool_bwd_amap_k<<<reduce_grid(n_patches, 256, 65536), 256, 0, s>>>(dy, amap, dx, n_patches, W / 4);
+    return hipGetLastError();
+}
+
 hipError_t launch_maxpool_fwd(const float* in, float* out, int C, int H, int W, hipStream_t s)
 {
     const int Ho = pooled_size(H), Wo = pooled_size(W);

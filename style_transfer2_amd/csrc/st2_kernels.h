@@ -31,6 +31,7 @@ struct ConvProblem {
     unsigned long long* stamps = nullptr;   // diagnostic configs only
     unsigned short* out16 = nullptr;        // optional (direct kernel): bf16 channel-blocked copy of `out`, [M/8][H][W][8], M % 8 == 0
     float* pool_out = nullptr;              // optional (Winograd forward, see conv_wino_can_pool): also write maxpool2x2/2 of `out`
+    unsigned char* pool_amap = nullptr;     // optional, with pool_out: [M][ph][pw] bytes = first-max slot | (max > 0) << 2 (launch_maxpool_bwd_amap)
     float* scratch = nullptr;               // optional: room for split-K partial sums (Winograd launches with few workgroups)
     size_t scratch_floats = 0;
 };
@@ -50,6 +51,10 @@ size_t wino_pack_floats(int K, int M);
 void pack_wino_weights_fwd(const float* w, int Cout, int Cin, float* dst);
 void pack_wino_weights_dgrad(const float* w, int Cout, int Cin, float* dst);
 bool conv_wino_ok(int K, int M, int H, int W);
+// dx = pool backward of dy through the arg-max map a Winograd forward wrote (ConvProblem::pool_amap), ReLU mask of the pooled-from conv
+// blob included (bit 2); H even, W % 4 == 0.  352 instead of 603 bytes moved per 64 outputs: neither the conv blob nor the pooled one is read.
+hipError_t launch_maxpool_bwd_amap(const float* dy, const unsigned char* amap, float* dx, int C, int H, int W, hipStream_t s);
+bool conv_wino_pool_amap_ok(int K, int M, int H, int W);   // ... and such a launch fills ConvProblem::pool_amap
 bool conv_wino_can_pool(int K, int M, int H, int W);   // launch_conv3x3_wino may fuse the following max-pool (ConvProblem::pool_out)
 int conv_wino_splits(int K, int M, int H, int W);   // split-K factor the automatic path would use (1 = none); needs splits*M*H*W floats of scratch
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);
