@@ -206,6 +206,45 @@ def test_worker_pipelined_iterations_keep_the_wire_and_the_message_order(async_i
     assert not worker_mod.Worker({}, sock_in=FakeSockets([]), sock_out=FakeSockets([]), transfer=FakeTransfer()).pipelined
 
 
+def test_worker_over_real_pyzmq_sockets_loopback():
+    """The transport the reference uses (worker.py:321-324: PULL bind / PUSH connect, send_pyobj / recv_pyobj) with the sender
+    thread on: WorkerReady -> Iterates in order -> Shutdown last.  pyzmq is not in the build image: skipped there, runs wherever
+    it is installed."""
+    zmq = pytest.importorskip('zmq')
+    import threading
+    ctx = zmq.Context()
+    app_in = ctx.socket(zmq.PULL)
+    port_app = app_in.bind_to_random_port('tcp://127.0.0.1')
+    probe = ctx.socket(zmq.PULL)
+    port_worker = probe.bind_to_random_port('tcp://127.0.0.1')
+    probe.close(0)
+    config = {'worker_socket': 'tcp://127.0.0.1:%d' % port_worker, 'app_socket': 'tcp://127.0.0.1:%d' % port_app, 'async_iterate': '1'}
+    img = np.zeros((4, 4, 3), np.uint8)
+    wk = worker_mod.Worker(config, transfer=FakePipelinedTransfer(4))
+    t = threading.Thread(target=wk.run, daemon=True)
+    t.start()
+    app_out = ctx.socket(zmq.PUSH)
+    app_out.connect(config['worker_socket'])
+    for m in (messages.SetImages(None, img, img, img, True), messages.StartIteration()):
+        app_out.send_pyobj(m)
+    got = []
+    poller = zmq.Poller()
+    poller.register(app_in, zmq.POLLIN)
+    while len(got) < 5 and poller.poll(10000):
+        got.append(app_in.recv_pyobj())
+    app_out.send_pyobj(messages.Shutdown())
+    while poller.poll(10000):
+        got.append(app_in.recv_pyobj())
+        if isinstance(got[-1], messages.Shutdown):
+            break
+    t.join(20)
+    wk.close()
+    app_out.close(0); app_in.close(0); ctx.destroy(0)
+    kinds = [type(m).__name__ for m in got]
+    assert kinds == ['WorkerReady'] + ['Iterate'] * 4 + ['Shutdown']
+    assert [m.i for m in got[1:5]] == [1, 2, 3, 4]
+
+
 def test_worker_asks_for_images_when_it_cannot_start_and_survives_garbage():
     sent, tr = run_worker([messages.StartIteration(), 'not a message', messages.PauseIteration()], FakeTransfer())
     assert [type(m).__name__ for m in sent] == ['WorkerReady', 'GetImages', 'Shutdown']
