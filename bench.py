@@ -230,42 +230,47 @@ def worker_level(job, steps):
             self.bytes += len(pickle.dumps(obj, protocol=pickle.DEFAULT_PROTOCOL))
 
     out = {}
-    for mode in ('sync', 'async'):
-        for _ in range(2):
-            job.step_async()
+    n = max(steps, 30)
+    sink = PickleSink()
+
+    def leg(mode):
+        if mode == 'pipelined':
+            for _ in range(2):                       # (the first begin allocates the rotating pinned buffers)
+                job.step_begin()
+            while job.steps_pending:
+                job.step_end(copy=False)
+        else:
+            for _ in range(2):
+                job.step_async()
         job.engine.sync()
-        sink = PickleSink()
-        send = worker_mod.AsyncSender(sink) if mode == 'async' else sink
+        send = sink if mode == 'sync' else worker_mod.AsyncSender(sink)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            image, trace = job.step()
-            send.send_pyobj(messages.Iterate(image, job.t, trace))
-        job.engine.sync()
-        if mode == 'async':
-            send.close()
-        dt = time.perf_counter() - t0
-        out[mode + '_iterate_it_s'] = steps / dt
-        out['iterate_MB'] = sink.bytes / steps / 1e6
-    # the worker's default loop: iteration k + 1 is begun before iterate k is collected (st_step_begin / st_step_end), sender thread on
-    if hasattr(job, 'step_begin'):
-        for _ in range(2):                       # (the first begin allocates the rotating pinned buffers)
-            job.step_begin()
-        while job.steps_pending:
-            job.step_end(copy=False)
-        job.engine.sync()
-        sink = PickleSink()
-        send = worker_mod.AsyncSender(sink)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            job.step_begin()
-            if job.steps_pending > 1:
-                image, trace, index = job.step_end(copy=False)       # as worker.py does: the sender pickles the pinned view
+        if mode == 'pipelined':
+            # the worker's default loop: iteration k + 1 is begun before iterate k is collected (st_step_begin / st_step_end)
+            for _ in range(n):
+                job.step_begin()
+                if job.steps_pending > 1:
+                    image, trace, index = job.step_end(copy=False)       # as worker.py does: the sender pickles the pinned view
+                    send.send_pyobj(messages.Iterate(image, index, trace))
+            while job.steps_pending:
+                image, trace, index = job.step_end(copy=False)
                 send.send_pyobj(messages.Iterate(image, index, trace))
-        while job.steps_pending:
-            image, trace, index = job.step_end(copy=False)
-            send.send_pyobj(messages.Iterate(image, index, trace))
-        send.close()
-        out['pipelined_iterate_it_s'] = steps / (time.perf_counter() - t0)
+        else:
+            for _ in range(n):
+                image, trace = job.step()
+                send.send_pyobj(messages.Iterate(image, job.t, trace))
+            job.engine.sync()
+        if mode != 'sync':
+            send.close()
+        return n / (time.perf_counter() - t0)
+
+    modes = ('sync', 'async') + (('pipelined',) if hasattr(job, 'step_begin') else ())
+    for mode in modes:
+        rates = sorted(leg(mode) for _ in range(3))
+        out[mode + '_iterate_it_s'] = rates[1]          # median of three legs of n iterations
+        out[mode + '_iterate_it_s_min_max'] = [rates[0], rates[2]]
+    out['iterate_MB'] = sink.bytes / (3 * len(modes) * n) / 1e6
+    steps = n
     out['steps'] = steps
     out['note'] = ('one Iterate (D2H + pickle) per step: on one host thread / with the sender thread / with the sender thread and the next '
                    'iteration begun before the iterate is collected (the worker default); never `value`')
