@@ -319,6 +319,9 @@ def main(argv=None):
     ap.add_argument('--no-worker-level', action='store_true')
     ap.add_argument('--cpu-size', type=int, default=0, help='image size of the CPU sample (default: --size)')
     ap.add_argument('--engine', default='hip', choices=['hip', 'stub'], help=argparse.SUPPRESS)
+    ap.add_argument('--rehearse-one-gpu', action='store_true',
+                    help='every rank uses device 0 and the ranks meet over gloo (RCCL refuses two ranks on one device): checks the '
+                         '--gpus fan-out on a one-GPU box; the ranks share the card, so the rate is NOT a measurement')
     args = ap.parse_args(argv)
     if args.gpus < 1 or args.steps < 1 or args.repeats < 1:
         ap.error('--gpus, --steps and --repeats must be positive')
@@ -343,8 +346,10 @@ def main(argv=None):
     os.dup2(2, 1)
 
     from style_transfer2_amd import distributed as st2_dist
-    group = st2_dist.Group(backend='gloo' if args.engine == 'stub' else None)
+    group = st2_dist.Group(backend='gloo' if (args.engine == 'stub' or args.rehearse_one_gpu) else None)
     rank, local_rank, world = group.rank, group.local_rank, group.world
+    if args.rehearse_one_gpu:
+        local_rank = 0
 
     if args.engine == 'stub':
         job, sync = StubJob(), StubJob().sync
@@ -387,6 +392,8 @@ def main(argv=None):
                        'parallelism': 'independent jobs, 1 per GPU, no collective (replicas)',
                        'scaling_curve': 'measured only by the driver (N = 1, 2, 4, 8); none has been measured by the builder'},
         }
+        if args.rehearse_one_gpu:
+            out['config']['rehearsal'] = 'all %d ranks shared ONE GPU (gloo rendezvous): plumbing check, the rate is not a measurement' % world
         if prof:
             # the dominant kernel class = every conv3x3 launch on the matrix cores (direct implicit GEMM + Winograd F(2x2,3x3)).
             # The engine records ALGORITHMIC flops per launch (direct convolution: 2*9*Cin*Cout*H*W); a Winograd

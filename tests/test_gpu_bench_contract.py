@@ -60,3 +60,13 @@ def test_bench_bf16_and_lbfgs_variants_run():
     d = run_bench('--precision', 'bf16', '--optimizer', 'lbfgs', '--no-cpu-baseline', '--repeats', '2')
     assert 'bf16' in d['dtype'] and 'cpu_baseline' not in d and d['timing']['blocks'] == 2
     assert d['roofline']['peak'] == pytest.approx(2516.6)
+
+
+def test_bench_gpus_fan_out_rehearsed_on_one_gpu():
+    """`--gpus 2` without a launcher starts two fresh rank processes before anything touches the GPU; rank 0 prints the one line
+    with n_gpus = 2 and the aggregate rate.  Here both ranks share the box's only card (`--rehearse-one-gpu`: device 0, gloo
+    rendezvous), so this checks the plumbing the driver's 2/4/8-GPU runs go through, not a rate."""
+    d = run_bench('--gpus', '2', '--rehearse-one-gpu', '--size', '128', '--no-cpu-baseline', '--no-worker-level', '--repeats', '2')
+    assert d['n_gpus'] == 2 and d['config']['jobs'] == 2 and d['scaling'] == 'weak'
+    assert 'rehearsal' in d['config'] and d['value'] > 0
+    assert d['value'] == pytest.approx(2 * d['steps'] / (d['ms_per_step'] * 1e-3), rel=1e-6)      # whole-job aggregate over both ranks
