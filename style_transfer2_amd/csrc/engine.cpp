@@ -406,7 +406,8 @@ static int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool le
                           // ... and a one-byte arg-max map for the pool's backward (maxpool_bwd_amap_k: neither blob is read again)
                           const char* ae = getenv("ST2_POOL_AMAP");          // =0: the classic pool backward (read per forward: the tests compare both)
                           if (!(ae && *ae == '0') && conv_wino_pool_amap_ok(p.K, p.M, p.H, p.W)) {
-                              const size_t pn = (size_t)a.C[i + 1] * a.h[i + 1] * a.w[i + 1];
+                              // (sized like the bf16 path's map of the same blob: the buffer is shared when the precision is switched)
+                              const size_t pn = act16_elems(a.C[i + 1], (size_t)a.h[i + 1] * a.w[i + 1]);
                               if (!a.amap[i + 1]) HIP_TRY(hipMalloc((void**)&a.amap[i + 1], pn));
                               p.pool_amap = a.amap[i + 1]; a.amap_ok[i + 1] = 2;      // 2: the fp32 layout [C][ph][pw]
                           }
