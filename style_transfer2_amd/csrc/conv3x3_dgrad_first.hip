@@ -180,6 +180,89 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_first_bf16(const uint4* __r
     dgrad_first_gather<M>(z_s, dx, inject, x0, y0, H, W);
 }
 
+// fp32, aligned widths (W % 4 == 0): every lane fetches 16-byte QUADS of the diff (four pixels of one channel) and feeds them to
+// FOUR accumulator tiles, one per pixel of the quad -- 32 loads in flight per lane instead of 96 four-byte ones.  One workgroup =
+// 5 x 64 output pixels; its halo tile is 7 rows x 72 columns (x0 - 4 .. x0 + 67) = 126 quads = one 32-lane group per wave.
+constexpr int DQ_TH = 5, DQ_TW = 64;
+constexpr int DQ_HH = DQ_TH + 2, DQ_HQ = (DQ_TW + 8) / 4;          // 7 rows x 18 quads
+constexpr int DQ_NQ = DQ_HH * DQ_HQ;                               // 126
+constexpr int DQ_ZS = DQ_HH * DQ_HQ * 4 + 1;                       // padded row stride of Z (505 floats)
+static_assert(DQ_NQ <= 128, "one quad per lane of the four waves");
+
+template <int M>
+__global__ __launch_bounds__(256, 2) void conv3x3_dgrad_first_f32q(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                   float* __restrict__ dx, const float* __restrict__ inject,
+                                                                   int Cout, int H, int W)
+{
+    __shared__ float z_s[DF_ROWS * DQ_ZS];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * DQ_TW, y0 = blockIdx.y * DQ_TH;
+    const size_t plane = (size_t)H * W;
+    constexpr int KC = 32;                                   // k-pairs per pass (64 channels)
+    const int qi = wave * 32 + l31;                          // this lane's quad of the halo tile
+    const int hy = qi / DQ_HQ, hq = qi - hy * DQ_HQ;
+    const int gy = y0 - 1 + hy, gx = x0 - 4 + 4 * hq;        // W % 4 == 0: a quad is inside the row or outside it
+    const int off = (qi < DQ_NQ && gy >= 0 && gy < H && gx >= 0 && gx < W) ? gy * W + gx : -1;
+    df_f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    const int r = l31, m_r = r / 9, tap_r = r - 9 * m_r;
+    for (int c0 = 0; c0 < Cout; c0 += 2 * KC) {
+        float4 b[KC];                                        // every operand of this pass first: 32 x 16 bytes in flight per lane
+#pragma unroll
+        for (int kp = 0; kp < KC; ++kp) {
+            const int c = c0 + 2 * kp + khalf;
+            b[kp] = (off >= 0 && c < Cout) ? *reinterpret_cast<const float4*>(dy + (size_t)c * plane + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (c0) __syncthreads();
+        const int nw = min(2 * KC, Cout - c0) * M * 9;
+        for (int i = tid; i < nw; i += 256) z_s[i] = w[(size_t)c0 * M * 9 + i];
+        __syncthreads();
+        const bool a_row = r < 9 * M;
+        const float* a_src = z_s + (khalf * M + m_r) * 9 + tap_r;            // + 2 kp * M * 9: this lane's row, channel 2 kp + khalf
+#pragma unroll
+        for (int kp = 0; kp < KC; ++kp) {
+            // (A straight from LDS, one value per four MFMAs: the 128 operand registers leave no room for a register copy of it)
+            const float a = (a_row && c0 + 2 * kp + khalf < Cout) ? a_src[2 * kp * M * 9] : 0.f;
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[kp].x, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[kp].y, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[kp].z, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[kp].w, acc[3], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                         // every wave has taken its A operands out of LDS
+    // park rows 0 .. 26: column l31 of accumulator j is pixel j of quad qi = halo pixel (hy, 4 hq + j)
+    if (qi < DQ_NQ) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (row < DF_ROWS) z_s[row * DQ_ZS + 4 * qi + j] = acc[j][e];
+            }
+    }
+    __syncthreads();
+    for (int o = tid; o < DQ_TH * DQ_TW; o += 256) {
+        const int py = o / DQ_TW, px = o - py * DQ_TW;
+        const int oy = y0 + py, ox = x0 + px;
+        if (oy >= H || ox >= W) continue;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float v = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)      // source pixel (y - ky + 1, x - kx + 1) = halo (py + 2 - ky, px + 5 - kx)
+                    v += z_s[(m * 9 + ky * 3 + kx) * DQ_ZS + (py + 2 - ky) * (DQ_HQ * 4) + (px + 5 - kx)];
+            const size_t idx = (size_t)m * plane + (size_t)oy * W + ox;
+            dx[idx] = v + (inject ? inject[idx] : 0.f);
+        }
+    }
+}
+
 // Measured (profiles/r02_zb_dgrad_first_ab.txt): the bf16 variant beats the VALU kernel (2048^2: 303 -> 265 us), the fp32 variant does not (1024^2:
 // 122 -> 200 us: 96 four-byte operand loads per lane against 12 sixteen-byte ones) -- so by default only the bf16 path uses this file.
 // ST2_DGRAD_FIRST=1 routes fp32 here too, =0 neither; read per launch (the tests run every combination).
@@ -189,6 +272,28 @@ bool conv_dgrad_first_ok(int Cout, int Cin, int H, int W, bool bf16)
     const bool enabled = e && *e ? (*e == '1') : bf16;
     return enabled && Cin >= 1 && Cin <= 3 && Cout >= 2 && Cout % (bf16 ? 16 : 2) == 0 && H >= 1 && W >= 1 &&
            (unsigned long long)H * W < 0x7fffffffull;
+}
+
+// the quad variant: aligned rows.  Measured at 1024^2: 126 us against 125 us for the VALU kernel (both read the 268 MB diff at
+// 2.2 TB/s: 64 channel planes x a few short row segments per workgroup is what bounds them, not the arithmetic) -- so it is OFF
+// unless ST2_DGRAD_FIRST_Q=1 (read per launch; the tests run it)
+bool conv_dgrad_first_quad_ok(int Cout, int Cin, int H, int W, const float* dy)
+{
+    const char* e = getenv("ST2_DGRAD_FIRST_Q");
+    return (e && *e == '1') && Cin >= 1 && Cin <= 3 && Cout >= 2 && Cout % 2 == 0 && W % 4 == 0 && H >= 1 &&
+           (unsigned long long)H * W < 0x7fffffffull && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+}
+
+hipError_t launch_conv3x3_dgrad_first_quad(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s)
+{
+    if (!conv_dgrad_first_quad_ok(Cout, Cin, H, W, dy)) return hipErrorInvalidValue;
+    const dim3 grid((W + DQ_TW - 1) / DQ_TW, (H + DQ_TH - 1) / DQ_TH);
+    switch (Cin) {
+    case 1: conv3x3_dgrad_first_f32q<1><<<grid, 256, 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    case 2: conv3x3_dgrad_first_f32q<2><<<grid, 256, 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    default: conv3x3_dgrad_first_f32q<3><<<grid, 256, 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
+    }
+    return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_dgrad_first(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s)

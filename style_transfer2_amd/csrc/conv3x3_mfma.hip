@@ -733,6 +733,7 @@ hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* d
                                        int Cout, int Cin, int H, int W, hipStream_t s)
 {
     if (!conv_dgrad_smallM_ok(Cout, Cin)) return hipErrorInvalidValue;
+    if (conv_dgrad_first_quad_ok(Cout, Cin, H, W, dy)) return launch_conv3x3_dgrad_first_quad(dy, w, dx, inject, Cout, Cin, H, W, s);        // matrix cores, quads
     if (conv_dgrad_first_ok(Cout, Cin, H, W, false)) return launch_conv3x3_dgrad_first(dy, w, dx, inject, Cout, Cin, H, W, s);              // matrix cores
     dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
     switch (Cin) {

@@ -62,14 +62,19 @@ def test_pool_ceil_mode_and_first_max():
 
 
 @pytest.mark.parametrize('precision', ['fp32', 'bf16'])
-@pytest.mark.parametrize('kernel', ['1', '0'])
-@pytest.mark.parametrize('cout,h,w', [(64, 64, 96), (64, 75, 100), (16, 9, 33), (32, 40, 31), (64, 8, 32), (48, 21, 70), (24, 12, 20)])
+@pytest.mark.parametrize('kernel', ['quad', '1', '0'])
+@pytest.mark.parametrize('cout,h,w', [(64, 64, 96), (64, 75, 100), (16, 9, 33), (32, 40, 31), (64, 8, 32), (48, 21, 70), (24, 12, 20), (64, 23, 132)])
 def test_first_conv_data_gradient_on_the_matrix_cores(precision, kernel, cout, h, w, monkeypatch):
     """conv1_1's data gradient (3 output channels): Z = A @ dy as one 32-row MFMA tile + 27 shifted adds
     (conv3x3_dgrad_first.hip; ST2_DGRAD_FIRST=0 keeps the VALU kernel) against the oracle fed with the GPU's own forward state,
     with a diff injected at the data blob too; tiles cut by the right / bottom edge, widths that are not multiples of 4, channel
     counts the bf16 variant cannot take (24: falls back)."""
-    monkeypatch.setenv('ST2_DGRAD_FIRST', kernel)
+    # 'quad': the fp32 kernel with 16-byte operand loads (aligned widths; other shapes fall through to the VALU kernel);
+    # '1' / '0': the four-byte-load matrix-core kernels forced on / everything on the VALU kernels
+    monkeypatch.setenv('ST2_DGRAD_FIRST_Q', '1' if kernel == 'quad' else '0')
+    monkeypatch.setenv('ST2_DGRAD_FIRST', '0' if kernel == 'quad' else kernel)
+    if kernel == 'quad' and precision == 'bf16':
+        pytest.skip('the quad kernel is the fp32 path')
     topo = (('conv', 'conv1_1', 3, cout),)
     params = oracle.he_init_weights(topo, seed=cout + h, bias_std=0.2)
     gpu = st2.HipModel(params, topology=topo, precision=precision)
