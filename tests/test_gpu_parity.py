@@ -207,6 +207,39 @@ def test_image_terms_with_integral_and_fractional_exponents(p_power, tv_power):
         x = x + 3.0 * np.sign(go).astype(F32)
 
 
+@pytest.mark.parametrize('weights', [
+    {'content': {}, 'style': {}, 'deepdream': {}},                                     # image terms only: no layer is visited
+    {'content': {}, 'style': {}, 'deepdream': {'conv1_1': 0.3}},                       # the shallowest blob only
+    {'content': {'conv2_2': 1.0}, 'style': {}, 'deepdream': {}},                       # one deep content layer, no style at all
+    {'content': {}, 'style': {'pool1': 2.0}, 'deepdream': {}},                         # a style term on a pool blob only
+])
+@pytest.mark.parametrize('precision', ['fp32', 'bf16'])
+def test_degenerate_weight_tables(weights, precision):
+    """SetWeights tables the web UI can produce by zeroing sliders (worker.py:231-247 skips layers whose three weights are all
+    below 1e-6; with none left only the TV / p-norm terms remain): loss, gradient, trace keys and one Adam step against the oracle."""
+    g = load('transfer_tiny.npz')
+    topo, net_params, _, content, style, init = tiny_setup(g)
+    params = json.loads(str(g['params_json']))
+    cpu = oracle.TransferOracle(oracle.NetOracle(topo, net_params, operands='bf16' if precision == 'bf16' else 'fp32'))
+    dev = st2.StyleTransfer(st2.HipModel(net_params, topology=topo, precision=precision))
+    for st in (cpu, dev):
+        st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
+        st.set_weights(weights, params)
+    cpu.set_optimizer('adam', 10)
+    dev.optimizer_cls = st2.AdamOptimizer; dev.set_step_size(10); dev.reset()
+    assert cpu.start() and dev.start()
+    x = g['std_eval1_x'].copy()
+    lo, go = cpu.opfunc(x.copy())
+    ld, gd = dev.opfunc(x.copy())
+    tol = 2e-3 if precision == 'bf16' else 1e-4
+    assert np.isclose(ld, lo, rtol=tol) and rel_l2(gd, go) <= tol, (ld, lo, rel_l2(gd, go))
+    assert list(dev.traces[-1].data) == list(cpu.traces[-1].data)
+    ic, tc = cpu.step()
+    idv, td = dev.step()
+    assert list(td) == list(tc) and np.isclose(td['loss'], tc['loss'], rtol=tol)
+    assert np.mean((idv - ic) ** 2) <= 1.0
+
+
 def test_engine_adam_trajectory_matches_reference_vectors():
     """50 Adam steps.  Adam's first steps are sign-like (x -= 10 g/|g|), so pixels whose gradient is at
     fp32 noise level may flip: tight bar on the per-step loss, loose bar on the image (MSE in 0-255
