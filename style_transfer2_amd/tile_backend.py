@@ -27,8 +27,10 @@ def dev_tensor(ptr, shape, device):
 
 class HipTileBackend:
     def __init__(self, net_params, grid, rank, content, style, init, weights, params, step_size=10,
-                 topology=None, device=0):
-        self.engine = Engine(topology, device)
+                 topology=None, device=0, precision='fp32'):
+        # precision='bf16': the convs of the window run on the bf16 matrix cores (fp32 accumulation); the Gram / style / loss kernels of
+        # the tile phases stay fp32 on the fp32 blobs (the region-of-interest forms exist for those only), i.e. the 'bf16-full' data flow
+        self.engine = Engine(topology, device, 'bf16-full' if precision == 'bf16' else precision)
         self.engine.load_weights(net_params)
         self.lib, self.ctx = self.engine.lib, self.engine._ctx
         self.device = torch.device('cuda', device)

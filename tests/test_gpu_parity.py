@@ -455,6 +455,40 @@ def test_tiled_lbfgs_single_rank_equals_plain_engine(h, w):
         assert np.mean((tt.tile_image() - img) ** 2) <= (1e-4 if i < 3 else 0.1), i
 
 
+def test_tiled_single_rank_with_bf16_convs_tracks_the_bf16_engine():
+    """precision='bf16' in the tile backend: the window's convs on the bf16 matrix cores, Gram / style / loss kernels in their fp32
+    region-of-interest forms.  Against the plain engine in its bf16 mode (whose Gram and style gradient read the bf16 copies instead):
+    the same objective to bf16 accuracy."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    h, w = 64, 96
+    content, style, init = _tiled_images(h, w)
+    topo = oracle.VGG19_TOPOLOGY[:7]
+    params = oracle.he_init_weights(topo, 0, 0.1)
+    weights = {'content': {'conv2_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1}, 'deepdream': {}}
+    grid = tiling.TileGrid(h, w, 1, 1, topo, 5)
+    tt = tiled.TiledTransfer(grid, 0, HipTileBackend(params, grid, 0, content, style, init, weights, TILED_PARAMS,
+                                                     step_size=10, topology=topo, precision='bf16'), tiled.Comm())
+    ref = st2.StyleTransfer(st2.HipModel(params, topology=topo, precision='bf16'))
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(weights, TILED_PARAMS)
+    ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
+    assert ref.start()
+    f32 = st2.StyleTransfer(st2.HipModel(params, topology=topo))
+    f32.set_input(init); f32.set_content(content); f32.set_style(style); f32.reset()
+    f32.set_weights(weights, TILED_PARAMS)
+    f32.optimizer_cls = st2.AdamOptimizer; f32.set_step_size(10); f32.reset()
+    assert f32.start()
+    for i in range(3):
+        vals = tt.step()
+        img, tr = ref.step()
+        _, tr32 = f32.step()
+        assert np.isclose(vals[-2], tr['loss'], rtol=2e-3), (i, vals[-2], tr['loss'])
+        assert np.mean((tt.tile_image() - img) ** 2) <= 1.0, i
+        if i == 0:
+            assert vals[-2] != tr32['loss'] and np.isclose(vals[-2], tr32['loss'], rtol=2e-2)      # bf16 operands really are in use
+
+
 def _tiled_gpu_rank(rank, world, rows, cols, port, steps, h, w, q, optimizer='adam'):
     import os, sys
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
