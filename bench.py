@@ -336,7 +336,8 @@ def main(argv=None):
     if args.tiled:
         import runpy
         sys.argv = [os.path.join(HERE, 'tools', 'bench_tiled.py'), '--size', str(args.size), '--grid', args.tiled,
-                    '--steps', str(args.steps), '--warmup', str(args.warmup), '--optimizer', args.optimizer]
+                    '--steps', str(args.steps), '--warmup', str(args.warmup), '--optimizer', args.optimizer,
+                    '--precision', args.precision]
         runpy.run_path(sys.argv[0], run_name='__main__')
         return 0
 
