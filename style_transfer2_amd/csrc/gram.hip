@@ -326,6 +326,43 @@ __global__ __launch_bounds__(256) void gram_fold_k(const float* __restrict__ sla
     folded[(size_t)g * cc + i] = sum;
 }
 
+// Both stages in one launch for many splits: 16 lanes share an element, lane j sums splits j, j + 16, ... (16 loads in flight
+// per lane pair of rounds), the 16 partial sums meet in LDS and are added in lane order -- a fixed order again, and a tenth of
+// the launches' latency (two ~10 us kernels per style layer become one).
+constexpr int GR_LANES = 16, GR_ELEMS = 256 / GR_LANES;
+__global__ __launch_bounds__(256) void gram_reduce_wide_k(const float* __restrict__ slabs, const float* __restrict__ target,
+                                                          float* __restrict__ out, float* __restrict__ partial,
+                                                          int cc, int splits, float n, int C, int out_ld, int bt)
+{
+    __shared__ float part_s[GR_LANES][GR_ELEMS + 1];
+    __shared__ float scratch[4];
+    const int el = threadIdx.x % GR_ELEMS, ln = threadIdx.x / GR_ELEMS;      // neighbouring threads: neighbouring elements of one slab
+    float acc[1] = {0.f};
+    for (int base = blockIdx.x * GR_ELEMS; base < cc; base += gridDim.x * GR_ELEMS) {
+        const int i = base + el;
+        const int r = i < cc ? i / C : 0, c = i < cc ? i - r * C : 0;
+        const bool live = i < cc && r / bt <= c / bt;        // lower-triangular tiles are produced by the mirror of (c, r)
+        float sum = 0.f;
+        if (live)
+            for (int s = ln; s < splits; s += GR_LANES) sum += slabs[(size_t)s * cc + i];
+        __syncthreads();                                     // the previous group's partial sums are consumed
+        part_s[ln][el] = sum;
+        __syncthreads();
+        if (ln == 0 && live) {
+            float tot = part_s[0][el];
+#pragma unroll
+            for (int j = 1; j < GR_LANES; ++j) tot += part_s[j][el];
+            float v = tot / n;                               // np.dot(x, x.T) / np.float32(x.size)
+            if (target) v -= target[i];
+            out[r * out_ld + c] = v;
+            acc[0] += v * v;
+            if (r / bt < c / bt) { out[c * out_ld + r] = v; acc[0] += v * v; }
+        }
+    }
+    block_sum(acc, scratch);
+    if (threadIdx.x == 0 && partial) partial[blockIdx.x] = acc[0];
+}
+
 int gram_fold_groups(const GramPlan& pl) { return pl.splits > 32 ? 32 : 0; }
 
 hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* target, float* out, int out_ld, float* partial,
@@ -333,6 +370,14 @@ hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* ta
 {
     const int cc = C * C;
     int splits = pl.splits;
+    // ST2_GRAM_REDUCE=2 keeps the two-stage reduction (read per launch)
+    const char* two = getenv("ST2_GRAM_REDUCE");
+    if (splits > 32 && !(two && *two == '2')) {
+        const int grid = reduce_grid((size_t)cc, GR_ELEMS, kMaxPartials);
+        if (n_partial) *n_partial = grid;
+        gram_reduce_wide_k<<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)divisor, C, out_ld, pl.bt);
+        return hipGetLastError();
+    }
     const int groups = gram_fold_groups(pl);
     if (groups) {
         const int per = (pl.splits + groups - 1) / groups;
