@@ -125,7 +125,7 @@ def source_hash():
     h = hashlib.sha256()
     csrc = os.path.join(HERE, 'style_transfer2_amd', 'csrc')
     for name in sorted(os.listdir(csrc)):
-        if name.endswith(('.hip', '.cpp', '.h', '.cuh')):
+        if name.endswith(('.hip', '.cpp', '.h')):
             h.update(name.encode())
             h.update(open(os.path.join(csrc, name), 'rb').read())
     return h.hexdigest()[:16]

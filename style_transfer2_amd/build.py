@@ -28,8 +28,12 @@ SOURCES = (
     ('gram16.hip', ()),
     ('conv3x3_dgrad_first.hip', ()),
     ('engine.cpp', ('-x', 'hip')),
+    ('engine_objective.cpp', ('-x', 'hip')),
+    ('engine_step.cpp', ('-x', 'hip')),
+    ('engine_resample.cpp', ('-x', 'hip')),
+    ('engine_tile.cpp', ('-x', 'hip')),
 )
-HEADERS = ('st2_kernels.h', 'reduce.cuh', os.path.join('..', '..', 'include', 'st2.h'))
+HEADERS = ('st2_kernels.h', 'wave_reduce.h', 'engine.h', os.path.join('..', '..', 'include', 'st2.h'))
 
 
 def _hipcc():

@@ -8,7 +8,7 @@
 // (up to 2^20), so it is split along K into slabs -> [splits][C][C] fp32 partials that a second
 // kernel sums in a fixed order (bitwise reproducible, no float atomics).
 #include "st2_kernels.h"
-#include "reduce.cuh"
+#include "wave_reduce.h"
 #include <stdint.h>
 #include <stdlib.h>
 

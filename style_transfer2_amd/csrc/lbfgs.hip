@@ -14,7 +14,7 @@
 // count return at once.  HBM-bound: (8 k + 3) N3 x 4 bytes per two-loop with k pairs; 4 N3 x 4 for the pair update.
 // Built with -ffp-contract=off (one rounding per operation, like the NumPy / BLAS-1 reference).
 #include <hip/hip_runtime.h>
-#include "reduce.cuh"
+#include "wave_reduce.h"
 #include "st2_kernels.h"
 
 namespace st2 {

@@ -9,7 +9,7 @@
 //   trace scalars               worker.py:236-301, utils.py:257-282
 //   BLAS-1 for L-BFGS           utils.py:29-46, optimizers.py:62-108
 #include "st2_kernels.h"
-#include "reduce.cuh"
+#include "wave_reduce.h"
 #include <float.h>
 #include <math.h>
 

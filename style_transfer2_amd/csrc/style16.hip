@@ -9,7 +9,7 @@
 // 128-channel output tile, D once per 128-pixel tile, both from L2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "reduce.cuh"
+#include "wave_reduce.h"
 #include "st2_kernels.h"
 
 namespace st2 {
