@@ -280,26 +280,50 @@ def worker_level(job, steps):
 # ------------------------------------------------------------------------------------------------ multi-rank plumbing
 def fan_out(args, argv):
     """--gpus N > 1 without a launcher: start N fresh processes, one per GPU, before anything here touches the GPU.
-    Rank 0's stdout (the one JSON line) is relayed; the exit code is the worst child's."""
+    Rank 0's stdout (the one JSON line) is relayed.  Every child is watched: when any rank exits non-zero (device out of
+    range, out of memory, a failed rendezvous) the others are terminated at once and that code is returned, instead of
+    rank 0 sitting in a barrier until the collective's own timeout."""
+    import tempfile
     n = args.gpus
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, out_file = [], tempfile.TemporaryFile()
     for rank in range(n):
         env = dict(os.environ)
         env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('ST2_RENDEZVOUS_TIMEOUT_S', '120')        # a rank that never arrives fails the others soon, not in 30 min
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+                                      stdout=out_file if rank == 0 else subprocess.DEVNULL))
+    codes = [None] * n
+    bad = None
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+                if codes[r] not in (None, 0) and bad is None:
+                    bad = (r, codes[r])
+        if bad is not None:
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.terminate()
+            deadline = time.time() + 10
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = p.wait(max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    out_file.seek(0)
+    sys.stdout.write(out_file.read().decode())
     sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        print('bench.py: ranks failed (rank, exit code): %s' % bad, file=sys.stderr)
-        return max(abs(c) for _, c in bad) or 1
+    if bad is not None:
+        print('bench.py: rank %d exited with code %d; the other ranks were stopped (exit codes %s)' % (bad[0], bad[1], codes), file=sys.stderr)
+        return abs(bad[1]) or 1
     return 0
 
 
@@ -341,6 +365,8 @@ def main(argv=None):
         runpy.run_path(sys.argv[0], run_name='__main__')
         return 0
 
+    if os.environ.get('ST2_BENCH_TEST_FAIL_RANK') == os.environ.get('RANK', '0') and args.engine == 'stub':
+        return 7                    # tests/test_bench_fanout_cpu.py: a rank that dies before the rendezvous
     # native libraries (gloo, RCCL, the HIP runtime) print to fd 1 at will: keep the real stdout for the ONE JSON line
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), 'w')

@@ -114,6 +114,12 @@ int st_step(st_ctx* ctx, float* out_hwc, double* trace, float* out_loss);
 int st_step_begin(st_ctx* ctx);
 int st_step_end(st_ctx* ctx, const float** out_hwc, int* out_h, int* out_w, double* trace, float* out_loss);
 int st_step_pending(st_ctx* ctx);      /* iterations begun and not yet ended (0..2) */
+/* Room for a message frame around the iterate (worker.py:351-353 sends messages.Iterate(image, i, trace) as ONE pickle, messages.py:64-74):
+ * from the next st_step_begin on, the caller may write `head_bytes` in front of and `tail_bytes` behind the image st_step_end hands out
+ * (same pinned allocation, same lifetime), so that the pickle's fixed header, the image the GPU copied in and the variable tail form one
+ * contiguous buffer the transport sends without a host-side copy.  At most 1 MiB each; the image stays page-aligned.  Buffers replaced
+ * by a re-allocation (a larger input, other rooms) stay valid for the views already handed out, for the same five further begins. */
+int st_step_frame_room(st_ctx* ctx, size_t head_bytes, size_t tail_bytes);
 /* Steps so far that ran as a hipGraph replay.  Opt-in (environment ST2_GRAPH=1; ST2_GRAPH_MAX_PX=<edge>, default 768):
  * steady-state Adam steps are captured once per ping-pong parity and replayed, bit-identical to plain launches.  Measured
  * on MI355X it is no faster (the step is bound by the dependent kernels' execution latency), hence off by default. */
@@ -170,6 +176,8 @@ int st_tile_gradient(st_ctx* ctx, const float* ring_dev, float** dev_ptr, int* n
  * sum, to be all-reduced); y = alpha x + y.  Both return when the result is in place. */
 int st_vec_dot(st_ctx* ctx, const float* a_dev, const float* b_dev, long long n, float* out_dev);
 int st_vec_axpy(st_ctx* ctx, float alpha, const float* x_dev, float* y_dev, long long n);
+/* y = float(double(y) / divisor): `p /= np.sqrt(dot(p, p) / p.size)` of optimizers.py:99 divides by a float64 scalar */
+int st_vec_div(st_ctx* ctx, double divisor, float* y_dev, long long n);
 /* which: 0 current x (3,wh,ww), 1 next x, 2 local sum D^2 per style layer, 3 norms [blob][c,s,d], 4 gradient (3,wh,ww) */
 int st_tile_buffer(st_ctx* ctx, int which, float** dev_ptr);
 int st_tile_swap(st_ctx* ctx);

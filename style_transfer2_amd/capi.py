@@ -2,7 +2,7 @@
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_longlong, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -64,6 +64,7 @@ PROTOTYPES = {
     'st_step_begin': (c_int, [c_void_p]),
     'st_step_end': (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), c_void_p, POINTER(c_float)]),
     'st_step_pending': (c_int, [c_void_p]),
+    'st_step_frame_room': (c_int, [c_void_p, c_size_t, c_size_t]),
     'st_graph_replays': (c_int, [c_void_p, POINTER(c_longlong)]),
     'st_lbfgs_inv_hv': (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p]),
     'st_sync': (c_int, [c_void_p]),
@@ -87,6 +88,7 @@ PROTOTYPES = {
     'st_tile_gradient': (c_int, [c_void_p, c_void_p, POINTER(c_void_p), POINTER(c_int)]),
     'st_vec_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p]),
     'st_vec_axpy': (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_longlong]),
+    'st_vec_div': (c_int, [c_void_p, c_double, c_void_p, c_longlong]),
     'st_tile_strips': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), c_void_p, c_int]),
 }
 

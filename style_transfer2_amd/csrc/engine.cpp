@@ -579,11 +579,12 @@ int st_destroy(st_ctx* c)
         (void)hipStreamSynchronize(c->pipe.copy);
         for (int i = 0; i < st_ctx::Pipe::kSlots; ++i) {
             dfree(c->pipe.hwc[i]);
-            if (c->pipe.img_pin[i]) (void)hipHostFree(c->pipe.img_pin[i]);
+            if (c->pipe.pin_base[i]) (void)hipHostFree(c->pipe.pin_base[i]);
             if (c->pipe.trace_pin[i]) (void)hipHostFree(c->pipe.trace_pin[i]);
             if (c->pipe.ready[i]) (void)hipEventDestroy(c->pipe.ready[i]);
             if (c->pipe.done[i]) (void)hipEventDestroy(c->pipe.done[i]);
         }
+        for (auto& r : c->pipe.retired) (void)hipHostFree(r.p);
         (void)hipStreamDestroy(c->pipe.copy);
     }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);

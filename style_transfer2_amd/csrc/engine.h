@@ -137,8 +137,17 @@ struct st_ctx {
         static constexpr int kSlots = 6;
         hipStream_t copy = nullptr;
         float* hwc[kSlots] = {}; float* img_pin[kSlots] = {}; float* trace_pin[kSlots] = {};
+        char* pin_base[kSlots] = {};               // the pinned allocation of a slot: [head room | image | tail room]; img_pin points at the image
         hipEvent_t ready[kSlots] = {}, done[kSlots] = {};
         size_t cap = 0; long long head = 0; int count = 0, tlen[kSlots] = {}, H[kSlots] = {}, W[kSlots] = {};
+        // bytes the caller may write in front of / behind an iterate handed out by st_step_end (a message frame around the image,
+        // st_step_frame_room): requested, and what the current buffers were allocated with
+        size_t want_head = 0, want_tail = 0, have_head = 0, have_tail = 0;
+        // Buffers replaced by a re-allocation (the input grew, the frame room changed) stay alive until kSlots further begins have
+        // passed: views handed out before it keep the documented lifetime.
+        struct Retired { void* p; long long at; };
+        std::vector<Retired> retired;
+        long long begins = 0;
     } pipe;
     void* stage_dev = nullptr; size_t stage_cap = 0;
     // optimizer

@@ -227,15 +227,23 @@ int st_step_begin(st_ctx* c)
             HIP_TRY(hipHostMalloc((void**)&p.trace_pin[i], (kMaxTraceLayers * 6 + 8) * sizeof(float), 0));
         }
     }
-    if (n3 > p.cap) {
-        if (p.count) return fail(ST_ERR_STATE, "the input grew while an iteration is in flight: st_step_end first");
+    p.begins += 1;
+    // buffers a re-allocation replaced: free them once no view handed out before it can still be in use (st2.h: five further begins)
+    for (size_t i = 0; i < p.retired.size();) {
+        if (p.begins - p.retired[i].at >= st_ctx::Pipe::kSlots) { (void)hipHostFree(p.retired[i].p); p.retired.erase(p.retired.begin() + i); }
+        else ++i;
+    }
+    if (n3 > p.cap || p.want_head != p.have_head || p.want_tail != p.have_tail) {
+        if (p.count) return fail(ST_ERR_STATE, "the input grew (or the frame room changed) while an iteration is in flight: st_step_end first");
+        const size_t cap = std::max(n3, p.cap);
         for (int i = 0; i < st_ctx::Pipe::kSlots; ++i) {
-            dfree(p.hwc[i]);
-            if (p.img_pin[i]) { (void)hipHostFree(p.img_pin[i]); p.img_pin[i] = nullptr; }
-            ST_TRY(dmalloc(&p.hwc[i], n3));
-            HIP_TRY(hipHostMalloc((void**)&p.img_pin[i], n3 * sizeof(float), 0));
+            // the iterates already handed out are views of these buffers: retire them instead of freeing them
+            if (p.pin_base[i]) { p.retired.push_back({p.pin_base[i], p.begins}); p.pin_base[i] = nullptr; p.img_pin[i] = nullptr; }
+            if (cap > p.cap) { dfree(p.hwc[i]); ST_TRY(dmalloc(&p.hwc[i], cap)); }
+            HIP_TRY(hipHostMalloc((void**)&p.pin_base[i], p.want_head + cap * sizeof(float) + p.want_tail, 0));
+            p.img_pin[i] = (float*)(p.pin_base[i] + p.want_head);
         }
-        p.cap = n3;
+        p.cap = cap; p.have_head = p.want_head; p.have_tail = p.want_tail;
     }
     ST_TRY(step_enqueue(c));
     const int slot = (int)((p.head + p.count) % st_ctx::Pipe::kSlots);
@@ -251,6 +259,16 @@ int st_step_begin(st_ctx* c)
 }
 
 int st_step_pending(st_ctx* c) { return c ? c->pipe.count : 0; }
+
+int st_step_frame_room(st_ctx* c, size_t head_bytes, size_t tail_bytes)
+{
+    if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    if (head_bytes > (1u << 20) || tail_bytes > (1u << 20)) return fail(ST_ERR_ARG, "frame room is limited to 1 MiB on either side");
+    // the image stays page-aligned inside the pinned allocation
+    c->pipe.want_head = (head_bytes + 4095) / 4096 * 4096;
+    c->pipe.want_tail = tail_bytes;
+    return ST_OK;
+}
 
 int st_step_end(st_ctx* c, const float** out_hwc, int* out_h, int* out_w, double* trace, float* out_loss)
 {

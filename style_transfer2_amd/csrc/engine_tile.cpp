@@ -334,6 +334,15 @@ int st_vec_axpy(st_ctx* c, float alpha, const float* x_dev, float* y_dev, long l
     return ST_OK;
 }
 
+int st_vec_div(st_ctx* c, double divisor, float* y_dev, long long n)
+{
+    if (!c || !y_dev || n < 0 || !(divisor != 0.0)) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_vec_div(divisor, y_dev, (size_t)n, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
 // device pointers of the buffers the caller exchanges: which = 0 current x, 1 next x, 2 local sum D^2 per style layer
 int st_tile_buffer(st_ctx* c, int which, float** dev_ptr)
 {

@@ -785,6 +785,17 @@ hipError_t launch_vec_axpy(float alpha, const float* x, float* y, size_t n, hipS
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void vec_div_k(double divisor, float* __restrict__ y, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = (float)((double)y[i] / divisor);
+}
+
+hipError_t launch_vec_div(double divisor, float* y, size_t n, hipStream_t s)
+{
+    vec_div_k<<<reduce_grid(n, 256 * 4, 8192), 256, 0, s>>>(divisor, y, n);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void lincomb_k(float a, const float* x, float b, const float* y, float* z, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {

@@ -300,5 +300,6 @@ hipError_t launch_lincomb(float a, const float* x, float b, const float* y, floa
 // tile-sharded L-BFGS: *out = sum a[i] b[i] over this rank's n elements (part: kMaxPartials floats of scratch); y = alpha x + y
 hipError_t launch_vec_dot(const float* a, const float* b, size_t n, float* part, float* out, hipStream_t s);
 hipError_t launch_vec_axpy(float alpha, const float* x, float* y, size_t n, hipStream_t s);
+hipError_t launch_vec_div(double divisor, float* y, size_t n, hipStream_t s);      // y = float(double(y) / divisor)
 
 }  // namespace st2

@@ -24,16 +24,19 @@ class Group:
         self.dist = None
         self.device = None
         if self.world > 1:
+            import datetime
             import torch
             import torch.distributed as dist
+            # a rank that dies before the rendezvous must fail the others within minutes (bench.py's fan-out sets 120 s)
+            timeout = datetime.timedelta(seconds=float(os.environ.get('ST2_RENDEZVOUS_TIMEOUT_S', '600')))
             backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
             if backend == 'nccl':
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device('cuda', self.local_rank)
-                dist.init_process_group('nccl', device_id=self.device)
+                dist.init_process_group('nccl', device_id=self.device, timeout=timeout)
             else:
                 self.device = torch.device('cpu')
-                dist.init_process_group(backend)
+                dist.init_process_group(backend, timeout=timeout)
             self.dist = dist
 
     def barrier(self):

@@ -289,10 +289,16 @@ class Engine:
 
     STEP_VIEW_LIFETIME = 5      # st2.h: a view returned by step_end(copy=False) survives this many further step_begin calls
 
-    def step_end(self, copy=True):
+    def set_frame_room(self, head_bytes, tail_bytes):
+        """Reserve room in front of / behind the iterates step_end hands out (st_step_frame_room), from the next step_begin on."""
+        check(self.lib.st_step_frame_room(self._ctx, int(head_bytes), int(tail_bytes)))
+        self._frame_room = ((int(head_bytes) + 4095) // 4096 * 4096, int(tail_bytes))
+
+    def step_end(self, copy=True, room=False):
         """Results of the OLDEST queued iteration, as step() returns them.  copy=False returns a read-only view of the context's
         pinned buffer instead of an owned array: valid for the next STEP_VIEW_LIFETIME calls of step_begin (the worker's bounded
-        sender queue stays inside that; a 12.6 MB host copy per iterate is what it saves)."""
+        sender queue stays inside that; a 12.6 MB host copy per iterate is what it saves).  room=True (with copy=False, after
+        set_frame_room): a fourth result, the writable buffer [head room | image | tail room] the view lies in (iterate_frame.py)."""
         ptr, h, w, loss = c_void_p(), c_int(), c_int(), c_float()
         trace = np.zeros(self.trace_len(), np.float64)
         check(self.lib.st_step_end(self._ctx, byref(ptr), byref(h), byref(w), _ptr(trace), byref(loss)))
@@ -300,6 +306,10 @@ class Engine:
         if copy:
             return view.copy(), trace, F32(loss.value)
         view.flags.writeable = False
+        if room:
+            head, tail = getattr(self, '_frame_room', (0, 0))
+            buf = (ctypes.c_char * (head + view.nbytes + tail)).from_address(ptr.value - head)
+            return view, trace, F32(loss.value), buf
         return view, trace, F32(loss.value)
 
     def steps_pending(self):

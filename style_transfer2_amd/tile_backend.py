@@ -176,6 +176,11 @@ class HipTileBackend:
         y.zero_()
         self.vaxpy(alpha, src, y)
 
+    def vdiv(self, divisor, y):
+        """y /= divisor with the quotient formed in double and rounded once (optimizers.py:99: p /= np.sqrt(...), a float64)."""
+        torch.cuda.synchronize(self.device)
+        check(self.lib.st_vec_div(self.ctx, float(divisor), c_void_p(y.data_ptr()), y.numel()))
+
     def apply_step(self, s):
         """x_next[tile] = x_cur[tile] + s; the rest of x_next starts as a copy of x_cur (its apron is refreshed by the caller)."""
         xt = self.vnew()

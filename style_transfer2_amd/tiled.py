@@ -185,25 +185,27 @@ class TiledTransfer:
         return b.finish_trace()
 
     def _dot(self, a, c):
-        """utils.dot over the whole image: partial sums of the ranks, all-reduced; float32 like sdot's result."""
+        """utils.dot over the whole image: partial sums of the ranks, all-reduced.  Returned as a python float holding the
+        float32 sum, as scipy's sdot returns it (utils.py:29-36): the scalar arithmetic below is then done in double and rounded
+        once where it meets an array, exactly as the reference's python floats are (and as lbfgs.hip does on one GPU)."""
         t = self.backend.vdot(a, c)
         self.comm.all_reduce(t)
-        return np.float32(t.reshape(-1)[0].item())
+        return float(np.float32(t.reshape(-1)[0].item()))
 
     def _inv_hv(self, grad):
-        """optimizers.py:89-108, statement by statement; scalars are float32 as the reference's sdot results are."""
+        """optimizers.py:89-108, statement by statement."""
         b = self.backend
         p = b.vcopy(grad)
         alphas = []
         for s, y, sy in zip(reversed(self.sk), reversed(self.yk), reversed(self.syk)):
-            alphas.append(self._dot(s, p) / sy)
-            b.vaxpy(-alphas[-1], y, p)
+            alphas.append(self._dot(s, p) / sy)                 # double / double
+            b.vaxpy(-alphas[-1], y, p)                          # saxpy: the coefficient is rounded to float32 here
         if self.sk:
             sy, y = self.syk[-1], self.yk[-1]
-            b.vscale(sy / self._dot(y, y), p)
+            b.vscale(sy / self._dot(y, y), p)                   # p *= python float: rounded to float32, one multiply
         else:       # no curvature information: a unit-RMS direction (p.size is the WHOLE image's)
-            n = np.float32(3 * self.grid.gH * self.grid.gW)
-            b.vscale(np.float32(1) / np.sqrt(self._dot(p, p) / n), p)
+            n = 3 * self.grid.gH * self.grid.gW
+            b.vdiv(float(np.sqrt(self._dot(p, p) / n)), p)      # p /= np.float64: divided in double, rounded once
         for s, y, sy, alpha in zip(self.sk, self.yk, self.syk, reversed(alphas)):
             beta = self._dot(y, p) / sy
             b.vaxpy(alpha - beta, s, p)
@@ -215,7 +217,7 @@ class TiledTransfer:
             self._evaluate()
             self.lb_grad = b.grad_tile()
         s = self._inv_hv(self.lb_grad)              # s = -step_size * inv_hv(grad)            :68
-        b.vscale(-self.step_size, s)
+        b.vscale(-float(self.step_size), s)
         b.apply_step(s)                             # x += s                                   :69
         self.refresh_aprons(b.x_next())
         b.swap()

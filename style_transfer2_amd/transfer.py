@@ -238,19 +238,33 @@ class StyleTransfer:
     # The same iteration in two halves (st_step_begin / st_step_end): the worker loop begins iteration k + 1 before it collects
     # iterate k, so the GPU never waits for the copy to the host and the pickling.  Results are those of step(), bit for bit.
     def step_begin(self):
+        self.engine.step_begin()                # (first: a refused begin must not advance the iteration count)
         self.t += 1
-        self.engine.step_begin()
         self._inflight.append(self.t)
 
-    def step_end(self, copy=True):
+    def step_end(self, copy=True, frame=False):
         """(image, trace, iteration index) of the oldest iteration begun and not yet collected.  copy=False: the image is a
-        read-only view that stays valid for the next Engine.STEP_VIEW_LIFETIME calls of step_begin."""
-        image, values, _ = self.engine.step_end(copy)
+        read-only view that stays valid for the next Engine.STEP_VIEW_LIFETIME calls of step_begin.  frame=True (after
+        enable_iterate_frames): a fourth result, the finished pickle of ``messages.Iterate(image, index, trace)`` as a memoryview
+        of the same pinned buffer (iterate_frame.py) -- what a transport sends without copying the image on the host."""
+        if frame:
+            image, values, _, room = self.engine.step_end(False, room=True)
+        else:
+            image, values, _ = self.engine.step_end(copy)
         index = self._inflight.pop(0)
         t = self._make_trace(values, True)
         t('fevals', index)
         self.traces.append(t)
+        if frame:
+            from . import iterate_frame
+            head_room = self.engine._frame_room[0]
+            return image, t.data, index, iterate_frame.assemble(room, head_room, image.nbytes, image.shape, index, t.data)
         return image, t.data, index
+
+    def enable_iterate_frames(self):
+        """From the next step_begin on, iterates come with room for the pickle of their ``messages.Iterate`` around them."""
+        from . import iterate_frame
+        self.engine.set_frame_room(iterate_frame.HEAD_ROOM, iterate_frame.TAIL_ROOM)
 
     @property
     def steps_pending(self):

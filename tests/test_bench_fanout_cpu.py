@@ -50,3 +50,14 @@ def test_under_a_launcher_every_rank_joins(tmp_path):
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     assert json.loads(lines[0])['n_gpus'] == 2
+
+
+def test_a_rank_that_dies_early_ends_the_run_at_once_with_its_code():
+    """One rank fails before the rendezvous (here: a test hook makes rank 1 exit with code 7): the launcher must not leave
+    rank 0 waiting in the barrier for the collective's timeout."""
+    import time
+    t0 = time.time()
+    out = _run(['--gpus', '2', '--steps', '5', '--engine', 'stub'], _env(ST2_BENCH_TEST_FAIL_RANK='1'))
+    assert out.returncode == 7, (out.returncode, out.stderr[-1000:])
+    assert 'rank 1 exited with code 7' in out.stderr
+    assert time.time() - t0 < 60

@@ -1,0 +1,149 @@
+"""The zero-copy ``Iterate`` frame (style_transfer2_amd/iterate_frame.py): a pickle assembled around an image that is already
+in (pinned) memory must unpickle to exactly what the reference's ``send_pyobj(Iterate(image, i, trace))`` would have produced
+(reference worker.py:351-353, messages.py:64-74), and the worker's zero-copy path must keep the wire order."""
+from collections import OrderedDict
+import pickle
+import pickletools
+
+import numpy as np
+import pytest
+
+import messages
+import worker as worker_mod
+from style_transfer2_amd import iterate_frame
+from helpers import load_json
+from test_boundary import FakePipelinedTransfer, FakeSockets
+
+F32 = np.float32
+
+
+def framed(image, i, trace, head_room=iterate_frame.HEAD_ROOM, tail_room=iterate_frame.TAIL_ROOM):
+    room = bytearray(head_room + image.nbytes + tail_room)
+    room[head_room:head_room + image.nbytes] = image.tobytes()
+    return iterate_frame.assemble(room, head_room, image.nbytes, image.shape, i, trace), room
+
+
+def trace_of(n_layers=6):
+    t = OrderedDict()
+    for k in range(n_layers):
+        for tag in ('c', 's', 'd'):
+            t['conv%d_1_%s_loss' % (k, tag)] = 0.25 * k
+            t['conv%d_1_%s_grad' % (k, tag)] = 1e-3 * k
+    for k in ('scd_loss', 't_loss', 'p_loss', 'scd_grad', 't_grad', 'p_grad', 'time', 'loss', 'grad'):
+        t[k] = float(len(t))
+    t['fevals'] = 17
+    return t
+
+
+@pytest.mark.parametrize('shape', [(1, 1, 3), (5, 7, 3), (192, 256, 3)])
+def test_frame_unpickles_to_what_send_pyobj_would_have_sent(shape):
+    image = np.random.RandomState(3).randn(*shape).astype(F32)
+    trace = trace_of()
+    frame, _ = framed(image, 17, trace)
+    got = pickle.loads(frame)
+    ref = pickle.loads(pickle.dumps(messages.Iterate(image, 17, trace), protocol=pickle.DEFAULT_PROTOCOL))
+    assert type(got) is messages.Iterate and sorted(vars(got)) == sorted(vars(ref)) == ['i', 'image', 'trace']
+    assert got.image.dtype == ref.image.dtype == F32 and got.image.shape == ref.image.shape
+    assert got.image.flags['C_CONTIGUOUS'] and got.image.flags['WRITEABLE'] == ref.image.flags['WRITEABLE']
+    assert np.array_equal(got.image, image)
+    assert type(got.i) is int and got.i == ref.i
+    assert type(got.trace) is OrderedDict and list(got.trace.items()) == list(ref.trace.items())
+    assert all(type(a) is type(b) for a, b in zip(got.trace.values(), ref.trace.values()))
+    # the image bytes are IN the frame (one operand of the pickle program), not copied around it
+    assert len(frame) - image.nbytes < 4096
+    assert sum(1 for _ in pickletools.genops(bytes(frame))) > 20                                     # a well-formed stream
+
+
+def test_frame_names_the_class_the_reference_pickles_name():
+    """tests/golden/message_pickles.json holds the reference's own pickles: the class is referenced as messages.Iterate."""
+    blob = bytes.fromhex(load_json('message_pickles.json')['Iterate'])
+    frame, _ = framed(np.zeros((2, 2, 3), F32), 1, OrderedDict(loss=1.0))
+
+    def globals_of(data):
+        strings = [arg for op, arg, _ in pickletools.genops(data) if op.name in ('SHORT_BINUNICODE', 'BINUNICODE', 'GLOBAL')]
+        return ' '.join(str(v) for v in strings)
+    for data in (bytes(frame), blob):
+        assert 'messages' in globals_of(data) and 'Iterate' in globals_of(data)
+    a, b = pickle.loads(bytes(frame)), pickle.loads(blob)
+    assert type(a) is type(b) and sorted(vars(a)) == sorted(vars(b))
+
+
+def test_frame_room_is_checked_and_large_images_use_an_8_byte_length():
+    image = np.zeros((2, 2, 3), F32)
+    with pytest.raises(ValueError):
+        framed(image, 1, trace_of(), tail_room=16)
+    with pytest.raises(ValueError):
+        framed(image, 1, trace_of(), head_room=64)
+    big = iterate_frame.head((40000, 40000, 3))                      # 19.2 GB: BINBYTES8, protocol 4
+    assert big[:2] == b'\x80\x04' and big[-9:-8] == b'\x8e' and int.from_bytes(big[-8:], 'little') == 40000 * 40000 * 12
+    small = iterate_frame.head((1024, 1024, 3))
+    assert small[:2] == b'\x80\x03' and small[-5:-4] == b'B' and int.from_bytes(small[-4:], 'little') == 1024 * 1024 * 12
+
+
+# ------------------------------------------------------------------------------------------ the worker's zero-copy path
+class FrameSockets(FakeSockets):
+    """An outbound socket with pyzmq's raw ``send(data, copy=False, track=True)`` beside send_pyobj.  Like libzmq, it reads the
+    buffer some time AFTER send returns unless the caller waits on the tracker: the bytes are captured in ``wait``."""
+    def __init__(self, inbound):
+        super().__init__(inbound)
+        self.raw_sends = 0
+
+    def send(self, data, copy=True, track=False):
+        assert copy is False and track is True, 'the zero-copy path sends with copy=False, track=True'
+        assert isinstance(data, memoryview)
+        self.raw_sends += 1
+        outer = self
+
+        class Tracker:
+            def wait(self_inner):
+                outer.sent.append(pickle.loads(bytes(data)))
+        return Tracker()
+
+
+class FakeFramedTransfer(FakePipelinedTransfer):
+    """A pipelined backend that also offers the finished pickle of each iterate in a rotating buffer (as the engine does)."""
+    def __init__(self, max_steps=5):
+        super().__init__(max_steps)
+        self.frames_on = False
+        self.rooms = [bytearray(iterate_frame.HEAD_ROOM + 48 + iterate_frame.TAIL_ROOM) for _ in range(6)]
+
+    def enable_iterate_frames(self):
+        self.frames_on = True
+
+    def step_end(self, copy=True, frame=False):
+        image, trace, i = super().step_end()
+        if not frame:
+            return image, trace, i
+        assert self.frames_on
+        room = self.rooms[i % 6]
+        room[iterate_frame.HEAD_ROOM:iterate_frame.HEAD_ROOM + 48] = image.tobytes()
+        return image, trace, i, iterate_frame.assemble(room, iterate_frame.HEAD_ROOM, 48, image.shape, i, trace)
+
+
+@pytest.mark.parametrize('async_iterate', ['0', '1'])
+def test_worker_zero_copy_iterates_keep_the_wire(async_iterate):
+    img = np.zeros((4, 4, 3), np.uint8)
+    socks = FrameSockets([messages.SetImages(None, img, img, img, True), messages.StartIteration()])
+    tr = FakeFramedTransfer(5)
+    wk = worker_mod.Worker({'async_iterate': async_iterate, 'zero_copy_iterate': '1'}, sock_in=socks, sock_out=socks, transfer=tr)
+    assert wk.pipelined and wk.zero_copy and tr.frames_on
+    wk.run()
+    kinds = [type(m).__name__ for m in socks.sent]
+    assert kinds == ['WorkerReady'] + ['Iterate'] * 5 + ['Shutdown']
+    its = socks.sent[1:6]
+    assert socks.raw_sends == 5
+    assert [m.i for m in its] == [1, 2, 3, 4, 5] and [m.trace['fevals'] for m in its] == [1, 2, 3, 4, 5]
+    assert [float(m.image[0, 0, 0]) for m in its] == [1, 2, 3, 4, 5] and its[0].image.shape == (2, 2, 3)
+
+
+def test_injected_sockets_get_owned_copies_by_default():
+    """Zero copy is for the pyzmq sockets the worker created itself (or an explicit config key): an injected socket that keeps
+    the message objects must never be handed views of buffers the engine rewrites."""
+    img = np.zeros((4, 4, 3), np.uint8)
+    socks = FrameSockets([messages.SetImages(None, img, img, img, True), messages.StartIteration()])
+    tr = FakeFramedTransfer(3)
+    wk = worker_mod.Worker({}, sock_in=socks, sock_out=socks, transfer=tr)
+    assert wk.pipelined and not wk.zero_copy and not tr.frames_on
+    wk.run()
+    assert socks.raw_sends == 0
+    assert [type(m).__name__ for m in socks.sent] == ['WorkerReady'] + ['Iterate'] * 3 + ['Shutdown']

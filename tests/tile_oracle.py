@@ -184,6 +184,9 @@ class OracleTileBackend:
     def vscale(self, alpha, y):
         y.numpy()[...] = F32(alpha) * y.numpy()
 
+    def vdiv(self, divisor, y):
+        y.numpy()[...] = (y.numpy().astype(np.float64) / float(divisor)).astype(F32)      # p /= np.float64 scalar
+
     def apply_step(self, s):
         ys, xs = self._tile_slices()
         nxt = self.x[self.cur ^ 1]

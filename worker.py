@@ -37,12 +37,11 @@ Build it with `python -c "import __graft_entry__ as g; g.build()"` and check `gp
 # config / logging / signals (reference utils.py:110-127, 172-190)
 # ---------------------------------------------------------------------------------------------------
 def parse_args(desc=''):
-    parser = argparse.ArgumentParser(description=desc)
-    parser.add_argument('config', nargs='?', help='the config file')
-    parser.add_argument('--debug', '-d', action='count', help='debug')
-    args = parser.parse_args()
-    args.debug = args.debug or 0
-    return args
+    """``worker.py [config] [-d ...]`` (reference utils.py:110-117): an optional config path and a repeatable debug flag."""
+    cli = argparse.ArgumentParser(description=desc)
+    cli.add_argument('config', nargs='?', default=None, help='the config file')
+    cli.add_argument('-d', '--debug', action='count', default=0, help='debug (repeat for message creation sites)')
+    return cli.parse_args()
 
 
 def read_config(args):
@@ -96,6 +95,22 @@ def build_transfer(config):
         sys.exit(2)
 
 
+class _Frame:
+    __slots__ = ('buf',)
+
+    def __init__(self, buf):
+        self.buf = buf
+
+
+def send_frame(sock, buf):
+    """One already-pickled message, straight from pinned memory: no copy on this side (pyzmq ``send(copy=False)``).  The
+    buffer belongs to the engine and is rewritten a few iterations later, so the call returns only once the transport no
+    longer needs it (``track=True`` + ``MessageTracker.wait``: libzmq has handed the bytes to the kernel)."""
+    tracker = sock.send(buf, copy=False, track=True)
+    if tracker is not None and hasattr(tracker, 'wait'):
+        tracker.wait()
+
+
 class AsyncSender:
     """Owns the outbound socket on its own thread: pickling + sending an ``Iterate`` (12.6 MB at 1024^2)
     overlaps the next iteration's GPU work instead of stalling it.  Order is
@@ -115,7 +130,10 @@ class AsyncSender:
             if msg is None:
                 return
             try:
-                self.sock.send_pyobj(msg)
+                if isinstance(msg, _Frame):
+                    send_frame(self.sock, msg.buf)
+                else:
+                    self.sock.send_pyobj(msg)
             except Exception as err:      # surfaced on the worker thread at the next send
                 self.error = err
 
@@ -123,6 +141,10 @@ class AsyncSender:
         if self.error is not None:
             raise self.error
         self.q.put(msg)
+
+    def send_frame(self, buf):
+        """A finished pickle (iterate_frame.py) that lives in the engine's rotating pinned buffers: sent as it is."""
+        self.send_pyobj(_Frame(buf))
 
     def close(self):
         """Flush everything queued, then stop the thread."""
@@ -164,11 +186,15 @@ class Worker:
             # before a received message is acted on.
             self.pipelined = (hasattr(self.transfer, 'step_begin') and
                               str(config.get('pipeline_iterate', '1')).lower() not in ('0', 'false', 'no'))
-            # An iterate may be sent straight out of the engine's rotating pinned buffers (no 12.6 MB host copy on this thread)
-            # when nothing can hold it for long: a direct send pickles it at once, the sender thread is at most
-            # queue depth + 1 = 3 iterates behind, plus the one being handed over -- inside the five further begins a view survives.
-            lifetime = getattr(getattr(self.transfer, 'engine', None), 'STEP_VIEW_LIFETIME', 0)
-            self._end_kwargs = {'copy': False} if self.pipelined and lifetime >= 5 else {}
+            # Zero-copy iterates: the GPU copies each iterate into the payload slot of a pre-formatted pickle in pinned memory
+            # (iterate_frame.py) and the transport sends that buffer as it is -- no 12.6 MB (50 MB at 2048^2) host copy or pickling.
+            # Only for the pyzmq sockets this worker created itself (their send(copy=False, track=True) is what bounds the
+            # buffer's use) or when the config asks for it; an injected socket gets owned copies through send_pyobj.
+            want = str(config.get('zero_copy_iterate', 'auto')).lower()
+            self.zero_copy = (self.pipelined and hasattr(self.transfer, 'enable_iterate_frames') and
+                              (want in ('1', 'true', 'yes') or (want == 'auto' and self._ctx is not None)))
+            if self.zero_copy:
+                self.transfer.enable_iterate_frames()
             self.sock_out.send_pyobj(WorkerReady(layers=self.transfer.model.layers()))
         except BaseException:
             self.close()            # the reference always reaches ctx.destroy(0) (worker.py:429-431)
@@ -181,12 +207,23 @@ class Worker:
         if self._ctx is not None:
             self._ctx.destroy(0)
 
+    def _collect_and_send(self):
+        """The oldest iteration in flight: wait for it, send its Iterate."""
+        tr = self.transfer
+        if self.zero_copy:
+            _, _, _, frame = tr.step_end(frame=True)
+            if isinstance(self.sock_out, AsyncSender):
+                self.sock_out.send_frame(frame)
+            else:
+                send_frame(self.sock_out, frame)
+        else:
+            image, trace, index = tr.step_end()
+            self.sock_out.send_pyobj(Iterate(image, index, trace))
+
     def _flush_pending(self):
         """Collect and send every iteration that was begun (pipelined mode), oldest first."""
-        tr = self.transfer
-        while getattr(tr, 'steps_pending', 0):
-            image, trace, index = tr.step_end(**self._end_kwargs)
-            self.sock_out.send_pyobj(Iterate(image, index, trace))
+        while getattr(self.transfer, 'steps_pending', 0):
+            self._collect_and_send()
 
     def run(self):
         try:
@@ -228,55 +265,62 @@ class Worker:
         elif self.pipelined:
             self.transfer.step_begin()            # queue iteration k + 1 ...
             if self.transfer.steps_pending > 1:   # ... then collect and send iterate k while the GPU works on it
-                image, trace, index = self.transfer.step_end(**self._end_kwargs)
-                self.sock_out.send_pyobj(Iterate(image, index, trace))
+                self._collect_and_send()
         else:
             image, trace = self.transfer.step()
             self.sock_out.send_pyobj(Iterate(image, self.transfer.t, trace))
 
+    # what each inbound message does (reference worker.py:366-409); Shutdown is the only one that ends the loop
+    def _on_set_images(self, msg):
+        tr = self.transfer
+        for value, assign, resample in ((msg.input_image, tr.set_input, tr.resample_input),
+                                        (msg.content_image, tr.set_content, tr.resample_content),
+                                        (msg.style_image, tr.set_style, None)):
+            if value is None:
+                continue
+            if not isinstance(value, int):                    # an image
+                assign(value)
+            elif value == SetImages.RESAMPLE and resample is not None:
+                resample(msg.size)
+        if msg.reset_state:
+            tr.reset()
+
+    def _on_set_optimizer(self, msg):
+        tr = self.transfer
+        tr.optimizer_cls = SetOptimizer.classes[msg.optimizer]
+        tr.set_step_size(msg.step_size)
+        if not isinstance(tr.optimizer, tr.optimizer_cls):
+            tr.reset()
+
+    def _on_set_weights(self, msg):
+        self.transfer.set_weights(msg.weights, msg.params)
+
+    def _on_start(self, msg):
+        if not self.transfer.start():
+            self.sock_out.send_pyobj(GetImages())
+
+    def _on_pause(self, msg):
+        self.transfer.pause()
+
+    HANDLERS = ((SetImages, _on_set_images), (SetOptimizer, _on_set_optimizer), (SetWeights, _on_set_weights),
+                (StartIteration, _on_start), (PauseIteration, _on_pause))
+
     def process_message(self, msg):
         """Returns True when the worker should shut down."""
-        tr = self.transfer
-
-        def is_image(obj):
-            return obj is not None and not isinstance(obj, int)
-
-        if isinstance(msg, SetImages):
-            if is_image(msg.input_image):
-                tr.set_input(msg.input_image)
-            elif msg.input_image == SetImages.RESAMPLE:
-                tr.resample_input(msg.size)
-            if is_image(msg.content_image):
-                tr.set_content(msg.content_image)
-            elif msg.content_image == SetImages.RESAMPLE:
-                tr.resample_content(msg.size)
-            if is_image(msg.style_image):
-                tr.set_style(msg.style_image)
-            if msg.reset_state:
-                tr.reset()
-        elif isinstance(msg, SetOptimizer):
-            tr.optimizer_cls = SetOptimizer.classes[msg.optimizer]
-            tr.set_step_size(msg.step_size)
-            if not isinstance(tr.optimizer, tr.optimizer_cls):
-                tr.reset()
-        elif isinstance(msg, SetWeights):
-            tr.set_weights(msg.weights, msg.params)
-        elif isinstance(msg, Shutdown):
+        if isinstance(msg, Shutdown):
             return True
-        elif isinstance(msg, StartIteration):
-            if not tr.start():
-                self.sock_out.send_pyobj(GetImages())
-        elif isinstance(msg, PauseIteration):
-            tr.pause()
-        else:
-            logger.error('Invalid message received over ZeroMQ.')
+        for kind, handler in self.HANDLERS:
+            if isinstance(msg, kind):
+                handler(self, msg)
+                return False
+        logger.error('Invalid message received over ZeroMQ.')
         return False
 
 
 def main():
     args = parse_args(__doc__)
     config = read_config(args)
-    debug = args.debug + config.getint('debug', 0)
+    debug = (args.debug or 0) + config.getint('debug', 0)
     setup_logging(debug)
     setup_signals()
     worker = None
