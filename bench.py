@@ -59,16 +59,44 @@ def images(size):
             rs(3).randint(0, 256, shape).astype(np.uint8))
 
 
-def make_job(size, optimizer, device, precision='fp32'):
+EXAMPLES_FIT = 256
+EXAMPLES_ITERS = 50
+
+
+def example_inputs():
+    """BASELINE configs[0]: the reference's example pair as app.py would have sent it (app.py:82,244-262): decoded pixels
+    (tests/golden/config1_sources.npz, written from the reference's examples/*.jpg by tests/golden/make_golden.py) ->
+    jobs.resize_to_fit(256) (reference utils.py:210-229; checked here against the reference's own output,
+    tests/golden/config1_inputs.npz) -> uniform-noise initial image."""
+    from PIL import Image
+    from style_transfer2_amd import jobs
+    gold = os.path.join(HERE, 'tests', 'golden')
+    src, ref = np.load(os.path.join(gold, 'config1_sources.npz')), np.load(os.path.join(gold, 'config1_inputs.npz'))
+    content = np.uint8(jobs.resize_to_fit(Image.fromarray(src['golden_gate']), EXAMPLES_FIT))
+    style = np.uint8(jobs.resize_to_fit(Image.fromarray(src['starry_night']), EXAMPLES_FIT))
+    same = bool(np.array_equal(content, ref['golden_gate']) and np.array_equal(style, ref['starry_night']))
+    return content, style, jobs.noise_image(content.shape[:2], seed=0), same
+
+
+def job_inputs(args):
+    """(content, style, init, weights, params) of the benched workload."""
+    if args.examples:
+        from style_transfer2_amd import jobs
+        content, style, init, _ = example_inputs()
+        return content, style, init, jobs.DEFAULT_WEIGHTS, jobs.DEFAULT_PARAMS
+    return images(args.size) + (WEIGHTS, PARAMS)
+
+
+def make_job(inputs, optimizer, device, precision='fp32'):
     import style_transfer2_amd as st2
     from style_transfer2_amd import weights as st2_weights
-    content, style, init = images(size)
+    content, style, init, weights, params = inputs
     model = st2.HipModel(st2_weights.he_normal(st2.VGG19_TOPOLOGY, seed=0), device=device, precision=precision)
     job = st2.StyleTransfer(model)
     job.set_input(init)
     job.set_content(content)
     job.set_style(style)
-    job.set_weights(WEIGHTS, PARAMS)
+    job.set_weights(weights, params)
     job.optimizer_cls = {'adam': st2.AdamOptimizer, 'lbfgs': st2.LBFGSOptimizer}[optimizer]
     job.set_step_size(STEP_SIZES[optimizer])
     job.reset()
@@ -89,6 +117,10 @@ class StubJob:
 
 
 def workload_label(args):
+    if args.examples:
+        return ('configs[0]: examples golden_gate + starry_night fitted to %d px (content 192x256, style 160x256) by jobs.resize_to_fit, '
+                'uniform-noise init, VGG19 (seeded weights), initial_weights.yaml losses, adam fp32, %d iterations per image'
+                % (EXAMPLES_FIT, EXAMPLES_ITERS))
     what = '%dx%d single image per GPU, VGG19 to conv5_1, content conv4_2 + 5 style layers, %s %s, %d iterations per image' % (
         args.size, args.size, args.optimizer, args.precision, ITERS_PER_IMAGE)
     if (args.size, args.optimizer, args.precision) == (1024, 'adam', 'fp32'):
@@ -110,7 +142,7 @@ def class_roofline(name, rec, conv_peak):
         executed = rec['flops'] * (4.0 / 9.0 if 'wino' in name else 1.0)
         tf = executed / sec / 1e12
         out['TFLOP/s'] = round(tf, 1)
-        out['frac_mfma'] = round(tf / (conv_peak if name.startswith('conv3x3') else PEAK_F32_MFMA_TFLOPS), 3)
+        out['frac_mfma'] = round(tf / (PEAK_BF16_MFMA_TFLOPS if name.endswith('bf16') else PEAK_F32_MFMA_TFLOPS), 3)
         if 'wino' in name:
             out['algorithmic_TFLOP/s'] = round(rec['flops'] / sec / 1e12, 1)
     if rec['bytes'] > 0:
@@ -152,12 +184,13 @@ def committed_pmc(name, args):
 
 
 # ------------------------------------------------------------------------------------------------ CPU oracle legs
-def cpu_baseline_and_parity(size, optimizer, precision, dev_eval):
+def cpu_baseline_and_parity(inputs, optimizer, precision, dev_eval, iterations=1):
     """The CPU oracle ("port") on this host: setup, one objective evaluation at the initial image (untimed; it captures
-    the norms and is what `parity` compares with the HIP path's evaluation of the same state), one timed step."""
+    the norms and is what `parity` compares with the HIP path's evaluation of the same state), then `iterations` timed steps
+    whose last iterate is compared with the HIP path's iterate after the same steps from the same state."""
     import oracle
     from threadpoolctl import threadpool_info
-    content, style, init = images(size)
+    content, style, init, weights, params = inputs
     topo = oracle.VGG19_TOPOLOGY
     net = oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False,
                            operands='bf16' if precision == 'bf16' else 'fp32')
@@ -166,13 +199,13 @@ def cpu_baseline_and_parity(size, optimizer, precision, dev_eval):
     job.set_content(content)
     job.set_style(style)
     job.reset()
-    job.set_weights(WEIGHTS, PARAMS)
+    job.set_weights(weights, params)
     job.set_optimizer(optimizer, STEP_SIZES[optimizer])
     job.start()
     loss0, grad0 = job.opfunc(job.input)
     parity = None
     if dev_eval is not None:
-        ld, gd, signs = dev_eval
+        ld, gd, signs = dev_eval[:3]
         g64, d64 = grad0.astype(np.float64), gd.astype(np.float64)
         flips = total = 0
         for name, packed in signs.items():
@@ -188,20 +221,30 @@ def cpu_baseline_and_parity(size, optimizer, precision, dev_eval):
                   'affected_pixel_frac': float(np.mean(pix > 1e-3 * np.abs(grad0).max())),
                   'note': 'ReLU / max-pool are discontinuous: each sign flip between two correct forwards changes the '
                           'gradient by O(1) inside one receptive field (DESIGN.md section 5)'}
-    if optimizer == 'lbfgs':
+    extra = 1 if (optimizer == 'lbfgs' and iterations == 1) else 0
+    if extra:
         job.step()                  # the first L-BFGS step costs two evaluations; time a steady-state one
     t0 = time.perf_counter()
-    job.step()
+    for _ in range(iterations):
+        image, trace = job.step()
     dt = time.perf_counter() - t0
+    if parity is not None and len(dev_eval) > 3 and dev_eval[3] is not None:
+        dev_image, dev_trace = dev_eval[3]
+        # the iterate itself (reference worker.py:303-310 returns deprocess(x)): 0..255 units
+        parity['image_mse'] = float(np.mean((np.asarray(dev_image, np.float64) - np.asarray(image, np.float64)) ** 2))
+        parity['image_max_abs'] = float(np.max(np.abs(np.asarray(dev_image, np.float64) - image)))
+        parity['image_after'] = '%d %s iteration(s) from the same initial state on both sides' % (iterations + extra, optimizer)
+        parity['step_loss_rel'] = float(abs(dev_trace['loss'] - trace['loss']) / abs(trace['loss']))
     threads = max([p.get('num_threads', 1) for p in threadpool_info()] + [1])
-    base = {'value': 1.0 / dt, 'unit': 'it/s', 'cores': threads, 'host_cpus': os.cpu_count(), 'kind': 'port',
-            'sample': '1 %s iteration at %dx%d (after 1 untimed objective evaluation), numpy+OpenBLAS oracle, forward stops at conv5_1'
-                      % (optimizer, size, size)}
+    base = {'value': iterations / dt, 'unit': 'it/s', 'cores': threads, 'host_cpus': os.cpu_count(), 'kind': 'port',
+            'sample': '%d %s iteration(s) at %dx%d (after 1 untimed objective evaluation), numpy+OpenBLAS oracle, forward stops at the deepest weighted layer'
+                      % (iterations, optimizer, init.shape[0], init.shape[1])}
     return base, parity
 
 
-def device_eval_for_parity(job):
-    """Objective at the initial image on the HIP path, plus the ReLU sign pattern (bit-packed) of every conv blob."""
+def device_eval_for_parity(job, iterations=1):
+    """Objective at the initial image on the HIP path, plus the ReLU sign pattern (bit-packed) of every conv blob; then the
+    iterate after `iterations` steps from that state (what the oracle leg does after its own evaluation)."""
     loss, grad = job.opfunc()
     eng = job.engine
     signs = {}
@@ -212,13 +255,21 @@ def device_eval_for_parity(job):
                 signs[layer[1]] = np.packbits(eng.get_blob(layer[1])[0] > 0)
             except StError:             # bf16 lean data flow: this blob exists only as a bf16 copy -- not part of the census
                 pass
-    return loss, grad, signs
+    stepped = None
+    for _ in range(iterations):
+        stepped = job.step()
+    return loss, grad, signs, stepped
 
 
 def worker_level(job, steps):
-    """Rate with one Iterate per step as worker.py sends it (image D2H over PCIe + pickle of the HxWx3 float32 image,
-    the sending side of pyzmq's send_pyobj), synchronous and with worker.AsyncSender (SURVEY 8d "report both")."""
+    """Rate with one Iterate per step as worker.py sends it (SURVEY 8d "report both"): image D2H over PCIe + the sending side of
+    pyzmq's send_pyobj (pickle of the HxWx3 float32 image) on one thread / with worker.AsyncSender / pipelined; and the worker's
+    zero-copy form, where the GPU copies the iterate into a pre-formatted pickle in pinned memory and the transport is handed
+    that buffer (no host-side copy).  The sinks stand where libzmq would: `handoff` takes the buffer and returns, `tcp` pushes
+    every byte through a loopback TCP socket drained by a reader thread (the app's side of the wire runs on this host too)."""
     import pickle
+    import socket as socket_mod
+    import threading
     import messages
     import worker as worker_mod
 
@@ -229,12 +280,43 @@ def worker_level(job, steps):
         def send_pyobj(self, obj):
             self.bytes += len(pickle.dumps(obj, protocol=pickle.DEFAULT_PROTOCOL))
 
+        def send(self, data, copy=True, track=False):          # zero-copy hand-off: libzmq would queue the buffer itself
+            self.bytes += len(data)
+
+    class TcpSink(PickleSink):
+        """Every frame crosses a loopback TCP connection; a reader thread drains it (kernel copies on both sides)."""
+        def __init__(self):
+            super().__init__()
+            srv = socket_mod.socket()
+            srv.bind(('127.0.0.1', 0))
+            srv.listen(1)
+            self.out = socket_mod.create_connection(srv.getsockname())
+            self.inp, _ = srv.accept()
+            srv.close()
+            self.reader = threading.Thread(target=self._drain, daemon=True)
+            self.reader.start()
+
+        def _drain(self):
+            buf = bytearray(8 << 20)
+            while self.inp.recv_into(buf):
+                pass
+
+        def send(self, data, copy=True, track=False):
+            self.out.sendall(data)
+            self.bytes += len(data)
+
+        def close(self):
+            self.out.close()
+            self.reader.join(10)
+            self.inp.close()
+
     out = {}
     n = max(steps, 30)
     sink = PickleSink()
 
-    def leg(mode):
-        if mode == 'pipelined':
+    def leg(mode, sink=sink):
+        framed = mode.startswith('zero_copy')
+        if mode == 'pipelined' or framed:
             for _ in range(2):                       # (the first begin allocates the rotating pinned buffers)
                 job.step_begin()
             while job.steps_pending:
@@ -244,17 +326,22 @@ def worker_level(job, steps):
                 job.step_async()
         job.engine.sync()
         send = sink if mode == 'sync' else worker_mod.AsyncSender(sink)
+
+        def collect():
+            if framed:
+                send.send_frame(job.step_end(frame=True)[3])
+            else:
+                image, trace, index = job.step_end(copy=False)       # the sender thread pickles the pinned view
+                send.send_pyobj(messages.Iterate(image, index, trace))
         t0 = time.perf_counter()
-        if mode == 'pipelined':
+        if mode == 'pipelined' or framed:
             # the worker's default loop: iteration k + 1 is begun before iterate k is collected (st_step_begin / st_step_end)
             for _ in range(n):
                 job.step_begin()
                 if job.steps_pending > 1:
-                    image, trace, index = job.step_end(copy=False)       # as worker.py does: the sender pickles the pinned view
-                    send.send_pyobj(messages.Iterate(image, index, trace))
+                    collect()
             while job.steps_pending:
-                image, trace, index = job.step_end(copy=False)
-                send.send_pyobj(messages.Iterate(image, index, trace))
+                collect()
         else:
             for _ in range(n):
                 image, trace = job.step()
@@ -270,10 +357,19 @@ def worker_level(job, steps):
         out[mode + '_iterate_it_s'] = rates[1]          # median of three legs of n iterations
         out[mode + '_iterate_it_s_min_max'] = [rates[0], rates[2]]
     out['iterate_MB'] = sink.bytes / (3 * len(modes) * n) / 1e6
-    steps = n
-    out['steps'] = steps
+    if hasattr(job, 'enable_iterate_frames'):
+        job.enable_iterate_frames()                      # from here on the pinned slots carry room for the pickle around the image
+        rates = sorted(leg('zero_copy') for _ in range(3))
+        out['zero_copy_iterate_it_s'] = rates[1]
+        out['zero_copy_iterate_it_s_min_max'] = [rates[0], rates[2]]
+        tcp = TcpSink()
+        out['zero_copy_tcp_loopback_it_s'] = leg('zero_copy_tcp', tcp)
+        tcp.close()
+    out['steps'] = n
     out['note'] = ('one Iterate (D2H + pickle) per step: on one host thread / with the sender thread / with the sender thread and the next '
-                   'iteration begun before the iterate is collected (the worker default); never `value`')
+                   'iteration begun before the iterate is collected; zero_copy = the worker default on its own pyzmq sockets: the GPU '
+                   'copies the iterate into a pre-formatted pickle in pinned memory and the transport is handed that buffer '
+                   '(tcp_loopback: every byte then crosses a loopback TCP socket to a reader thread on this host); never `value`')
     return out
 
 
@@ -338,6 +434,8 @@ def main(argv=None):
     ap.add_argument('--optimizer', default='adam', choices=['adam', 'lbfgs'])
     ap.add_argument('--precision', default='fp32', choices=['fp32', 'bf16'],
                     help="bf16 = BASELINE configs[2] 'bf16 features / fp32 Gram'; the headline metric is fp32")
+    ap.add_argument('--examples', action='store_true',
+                    help='BASELINE configs[0]: the example pair fitted to 256 px by jobs.resize_to_fit, noise init, 50 Adam iterations, CPU oracle beside it')
     ap.add_argument('--tiled', default='', help='RxC: ONE image of --size tile-sharded over R*C GPUs (BASELINE configs[4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-worker-level', action='store_true')
@@ -378,14 +476,20 @@ def main(argv=None):
     if args.rehearse_one_gpu:
         local_rank = 0
 
+    inputs = None
     if args.engine == 'stub':
         job, sync = StubJob(), StubJob().sync
     else:
-        job = make_job(args.size, args.optimizer, local_rank, args.precision)
+        if args.examples:
+            args.size, args.optimizer = EXAMPLES_FIT, 'adam'
+        inputs = job_inputs(args)
+        job = make_job(inputs, args.optimizer, local_rank, args.precision)
         sync = job.engine.sync
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.engine == 'hip'
     cpu_size = args.cpu_size or args.size
-    dev_eval = device_eval_for_parity(job) if want_cpu and cpu_size == args.size else None
+    cpu_iters = EXAMPLES_ITERS if args.examples else 1
+    dev_steps = cpu_iters + (1 if (args.optimizer == 'lbfgs' and cpu_iters == 1) else 0)      # (the oracle leg's untimed first L-BFGS step)
+    dev_eval = device_eval_for_parity(job, dev_steps) if want_cpu and cpu_size == args.size else None
 
     blocks = []
     for r in range(args.repeats):
@@ -426,7 +530,7 @@ def main(argv=None):
             # The engine records ALGORITHMIC flops per launch (direct convolution: 2*9*Cin*Cout*H*W); a Winograd
             # launch executes 4/9 of them on the MFMA pipe.
             peak = PEAK_F32_MFMA_TFLOPS if f32 else PEAK_BF16_MFMA_TFLOPS
-            direct = [prof[k] for k in ('conv3x3_fwd_mfma_f32', 'conv3x3_dgrad_mfma_f32') if k in prof]
+            direct = [prof[k] for k in ('conv3x3_fwd_mfma_f32', 'conv3x3_dgrad_mfma_f32', 'conv3x3_fwd_mfma_bf16', 'conv3x3_dgrad_mfma_bf16') if k in prof]
             wino = [prof[k] for k in ('conv3x3_fwd_wino_f32', 'conv3x3_dgrad_wino_f32') if k in prof]
             conv = direct + wino
             flops = sum(c['flops'] for c in conv)
@@ -462,8 +566,11 @@ def main(argv=None):
         if world == 1 and args.engine == 'hip' and not args.no_worker_level:
             out['worker_level'] = worker_level(job, max(3, min(20, args.steps)))
         if want_cpu:
-            out['cpu_baseline'], parity = cpu_baseline_and_parity(cpu_size, args.optimizer, args.precision, dev_eval)
+            cpu_inputs = inputs if cpu_size == args.size else images(cpu_size) + (WEIGHTS, PARAMS)
+            out['cpu_baseline'], parity = cpu_baseline_and_parity(cpu_inputs, args.optimizer, args.precision, dev_eval, cpu_iters)
             out['parity'] = parity
+            if args.examples:
+                out['config']['resize_to_fit_matches_reference_fixture'] = example_inputs()[3]
         json_out.write(json.dumps(out) + '\n')
         json_out.flush()
     group.close()

@@ -22,6 +22,16 @@ import numpy as np
 
 F32 = np.float32
 
+# Optional callable invoked after every layer of a forward / backward pass (the test session on a GPU box writes a progress
+# file from it: minutes-long full-size evaluations then show as progress, and only as long as they do progress).
+progress = None
+
+
+def _tick():
+    if progress is not None:
+        progress()
+
+
 # (kind, name, cin, cout) -- models/vgg19.prototxt
 VGG19_TOPOLOGY = (
     ('conv', 'conv1_1', 3, 64), ('conv', 'conv1_2', 64, 64), ('pool', 'pool1'),
@@ -227,6 +237,7 @@ class NetOracle:
             else:
                 x, self._slots[layer[1]] = maxpool_forward(x)
             self._blobs[layer[1]] = x
+            _tick()
         return OrderedDict((n, self._blobs[n][None]) for n in wanted)
 
     def style_operand(self, name, f2):
@@ -304,6 +315,7 @@ class NetOracle:
             else:
                 below = self.blob_names[i - 1]
                 g = maxpool_backward(g, self._slots[name], self._blobs[below].shape)
+            _tick()
         if 'data' in diffs:
             inj = np.asarray(diffs['data'], F32)[0]
             g = inj.copy() if g is None else g + inj

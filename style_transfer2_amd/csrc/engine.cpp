@@ -19,7 +19,8 @@ int fail(int code, const char* fmt, ...)
 }
 const char* const kProfNames[P_COUNT] = {"conv3x3_fwd_mfma_f32", "conv3x3_dgrad_mfma_f32", "maxpool_fwd", "maxpool_bwd",
                                           "gram_partial_mfma_f32", "gram_reduce", "style_grad_mfma_f32", "layer_elem",
-                                          "image_pass", "finalize", "vector_ops", "misc", "conv3x3_fwd_wino_f32", "conv3x3_dgrad_wino_f32"};
+                                          "image_pass", "finalize", "vector_ops", "misc", "conv3x3_fwd_wino_f32", "conv3x3_dgrad_wino_f32",
+                                          "conv3x3_fwd_mfma_bf16", "conv3x3_dgrad_mfma_bf16", "tile_comm"};
 
 static const struct { int kind; const char* name; int cin, cout; } kVgg19[] = {
     {0, "conv1_1", 3, 64}, {0, "conv1_2", 64, 64}, {1, "pool1", 0, 0},
@@ -193,7 +194,7 @@ int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
                         bytes = px * (2.0 * L.cin + 2.0 * L.cout);
                     }
                 }
-                ProfScope ps(c, P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, bytes);
+                ProfScope ps(c, P_CONV_FWD_BF16, 2.0 * 9 * L.cin * L.cout * px, bytes);
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
             } else {
                 ConvProblem p{};
@@ -354,7 +355,7 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
                 if (p.mask_src && !a.has32[below]) return fail(ST_ERR_STATE, "internal: mask blob %d missing", below);
                 if (lean && below16) p.out = nullptr;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
-                ProfScope ps(c, P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px + (fused ? 2.0 * L.cin * L.cin * px : 0.0),
+                ProfScope ps(c, P_CONV_DGRAD_BF16, 2.0 * 9 * L.cin * L.cout * px + (fused ? 2.0 * L.cin * L.cin * px : 0.0),
                              px * (2.0 * L.cout + (fused ? 2.0 : 0.0) * L.cin + (p.out ? 4.0 : 0.0) * L.cin + (p.out16 ? 2.0 : 0.0) * L.cin + (mask_src ? (p.mask16 ? 2.0 : 4.0) : 0.0) * L.cin));
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
                 cur16 = below16 ? dst16 : nullptr;

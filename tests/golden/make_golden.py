@@ -265,12 +265,14 @@ def golden_messages():
 # (8) config-1 inputs: resize_to_fit of the example images -----------------------------------------------
 def golden_config1_inputs():
     from PIL import Image
-    out = {}
+    out, src = {}, {}
     for name in ('golden_gate', 'starry_night'):
         im = Image.open(os.path.join(REF, 'examples', name + '.jpg')).convert('RGB')
+        src[name] = np.asarray(im)                  # the decoded pixels the app starts from (app.py:244-262): input of jobs.resize_to_fit
         out[name] = np.asarray(ref_utils.resize_to_fit(im, 256))
         print(name, im.size, '->', out[name].shape)
     save('config1_inputs.npz', **out)
+    save('config1_sources.npz', **src)
 
 
 if __name__ == '__main__':

@@ -94,3 +94,37 @@ def test_caffemodel_fixtures_are_what_protobuf_encodes_today(variant, golden_dir
     spec.loader.exec_module(gen)
     raw = gen.encode(weights.he_normal(TOPO, seed=4, bias_std=0.3), variant)
     assert raw == open(os.path.join(golden_dir, 'caffemodel_%s.bin' % variant), 'rb').read()
+
+
+# ---------------------------------------------------------------- network definition (config key `prototxt`)
+def test_prototxt_roundtrip_and_refusals():
+    """style_transfer2_amd/prototxt.py reads the subset of Caffe's text format that models/vgg19.prototxt uses (reference
+    config.ini:28, worker.py:58-61) and refuses everything the engine would not run exactly."""
+    from style_transfer2_amd import prototxt
+    assert prototxt.parse(prototxt.write(VGG19_TOPOLOGY)) == VGG19_TOPOLOGY
+    assert prototxt.parse(prototxt.write(TOPO)) == TOPO
+    text = prototxt.write(TOPO)
+    for bad, why in ((text.replace('kernel_size: 3', 'kernel_size: 5', 1), 'not a 3x3'),
+                     (text.replace('pool: MAX', 'pool: AVE'), 'MAX pool'),
+                     (text.replace('type: "ReLU"', 'type: "Sigmoid"', 1), 'in-place ReLU'),
+                     (text + 'layer { bottom: "conv2_1" top: "fc" name: "fc" type: "InnerProduct" }', 'not supported'),
+                     (text.replace('bottom: "conv1_1"\n    top: "conv1_2"', 'bottom: "data"\n    top: "conv1_2"'), 'linear chain'),
+                     (text.replace('dim: 3', 'dim: 1'), 'N x 3 x H x W'),
+                     (text + 'layer { name: "x" ', 'missing }')):
+        with pytest.raises(ValueError, match=why):
+            prototxt.parse(bad)
+    # a convolution without its ReLU
+    lines = text.split('layer {')
+    no_relu = 'layer {'.join(l for l in lines if 'relu2_1' not in l)
+    with pytest.raises(ValueError, match='in-place ReLU'):
+        prototxt.parse(no_relu)
+
+
+def test_prototxt_reader_on_the_reference_model_file():
+    """The reference's own models/vgg19.prototxt (present in the build container only) parses to the built-in VGG19."""
+    import os
+    from style_transfer2_amd import prototxt
+    path = '/root/reference/models/vgg19.prototxt'
+    if not os.path.exists(path):
+        pytest.skip('the reference tree is not on this machine')
+    assert prototxt.read(path) == VGG19_TOPOLOGY

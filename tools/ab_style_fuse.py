@@ -7,7 +7,7 @@ import bench
 out = {}
 for flag in ('1', '0'):
     os.environ['ST2_STYLE_FUSE'] = flag
-    job = bench.make_job(2048, 'lbfgs', 0, 'bf16')
+    job = bench.make_job(bench.images(2048) + (bench.WEIGHTS, bench.PARAMS), 'lbfgs', 0, 'bf16')
     job.opfunc()
     loss, grad = job.opfunc()
     out[flag] = (loss, grad.astype(np.float64).copy(), dict(job.traces[-1].data))

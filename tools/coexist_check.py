@@ -15,7 +15,7 @@ dist.barrier()
 print('RCCL group up', flush=True)
 import bench
 from style_transfer2_amd import distributed as st2_dist
-job = bench.make_job(512, 'adam', 0)
+job = bench.make_job(bench.images(512) + (bench.WEIGHTS, bench.PARAMS), 'adam', 0)
 t0 = time.perf_counter()
 for _ in range(10):
     job.step_async()

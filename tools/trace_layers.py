@@ -30,14 +30,18 @@ for r, n, s in zip(convs, names, specs):
         r['Accum_VGPR_Count'], r['LDS_Block_Size']))
 print('conv total %.1f us, %.1f TF/s' % (tot, totf / tot / 1e6))
 print('--- every kernel of the iteration (duration, gap to previous)')
-prev = None
-other = 0
+prev = int(rows[idx[which - 1]]['End_Timestamp'])      # end of the previous iteration's last kernel
+other = busy = gaps = 0.0
 for r in it:
-    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    gap = (s - prev) / 1e3 if prev else 0
-    prev = e
-    if 'conv3x3_mfma' not in r['Kernel_Name']:
-        other += (e - s) / 1e3
-        print('%-44s %9.1f us gap %6.1f' % (r['Kernel_Name'].split('(')[0].replace('void st2::', '')[:44], (e - s) / 1e3, gap))
-print('non-conv-mfma kernels %.1f us; iteration span %.1f us' % (
-    other, (int(it[-1]['End_Timestamp']) - int(it[0]['Start_Timestamp'])) / 1e3))
+    s_, e_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    gap = (s_ - prev) / 1e3                              # idle time on the stream in front of this kernel (negative: overlap)
+    prev = max(prev, e_)
+    busy += (e_ - s_) / 1e3
+    gaps += max(gap, 0.0)
+    kn = r['Kernel_Name']
+    if 'conv3x3' not in kn or 'dgrad_smallM' in kn or 'dgrad_first' in kn:
+        other += (e_ - s_) / 1e3
+        print('%-44s %9.1f us gap %6.2f' % (kn.split('(')[0].replace('void st2::', '')[:44], (e_ - s_) / 1e3, gap))
+span = (int(it[-1]['End_Timestamp']) - int(rows[idx[which - 1]]['End_Timestamp'])) / 1e3
+print('kernels other than the matrix-core convs %.1f us; all kernels %.1f us + gaps %.1f us = iteration span %.1f us (%d launches, %.2f us per gap)' % (
+    other, busy, gaps, span, len(it), gaps / max(1, len(it))))

@@ -18,7 +18,7 @@ class PickleSink:                       # what send_pyobj costs on the sending s
         self.bytes += len(pickle.dumps(obj, protocol=pickle.DEFAULT_PROTOCOL))
 
 
-job = bench.make_job(size, 'adam', 0)
+job = bench.make_job(bench.images(size) + (bench.WEIGHTS, bench.PARAMS), 'adam', 0)
 for mode in ('device-resident (no Iterate)', 'synchronous Iterate', 'asynchronous Iterate'):
     for _ in range(3):
         job.step_async()

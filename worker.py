@@ -75,20 +75,28 @@ def build_transfer(config):
         import style_transfer2_amd as st2
         from style_transfer2_amd import weights as st2_weights
         gpu = config.getint('gpu', fallback=0)
+        # the network definition (reference config.ini:28, worker.py:58-61): the stock VGG19 is built in, a prototxt that exists
+        # is read (and refused loudly if it asks for anything the engine does not run)
+        proto_path = MODULE_DIR / config.get('prototxt', 'models/vgg19.prototxt')
+        topology = st2.VGG19_TOPOLOGY
+        if proto_path.exists():
+            from style_transfer2_amd import prototxt
+            topology = prototxt.read(str(proto_path))
         weights_path = MODULE_DIR / config.get('caffemodel', 'models/vgg19.npz')
         if weights_path.suffix == '.npz' and weights_path.exists():
-            params = st2_weights.load_npz(str(weights_path), st2.VGG19_TOPOLOGY)
+            params = st2_weights.load_npz(str(weights_path), topology)
         elif weights_path.suffix == '.caffemodel' and weights_path.exists():
             from style_transfer2_amd import caffemodel
-            params = caffemodel.vgg_params(caffemodel.read_caffemodel(str(weights_path)), st2.VGG19_TOPOLOGY,
+            params = caffemodel.vgg_params(caffemodel.read_caffemodel(str(weights_path)), topology,
                                            bgr_to_rgb=config.getboolean('caffemodel_is_bgr', fallback=False))
         elif config.get('weights', '') == 'synthetic':
-            logger.warning('Using seeded synthetic VGG19 weights (config: weights = synthetic).')
-            params = st2_weights.he_normal(st2.VGG19_TOPOLOGY, seed=0)
+            logger.warning('Using seeded synthetic weights (config: weights = synthetic).')
+            params = st2_weights.he_normal(topology, seed=0)
         else:
             raise st2.HipUnavailable('weights file %s not found (.npz or .caffemodel; or set weights = synthetic)'
                                      % weights_path)
-        model = st2.HipModel(params, device=max(gpu, 0))
+        model = st2.HipModel(params, topology=None if topology == st2.VGG19_TOPOLOGY else topology, device=max(gpu, 0),
+                             precision=config.get('precision', 'fp32'))
         return st2.StyleTransfer(model)
     except Exception as err:  # HipUnavailable, StError, OSError ...
         print(BACKEND_MSG % err, file=sys.stderr)
