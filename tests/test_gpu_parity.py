@@ -604,10 +604,15 @@ def _tiled_vgg_rank(rank, world, port, steps, h, w, q):
     dist.destroy_process_group()
 
 
-def test_tiled_vgg19_two_ranks_match_single_gpu_engine():
-    """Full VGG19 to conv5_1 (receptive-field apron 80 px): 2 ranks on a 176 x 416 image vs the plain engine."""
+@pytest.mark.parametrize('h,w,loss_rtol', [(176, 416, 1e-4), (1024, 4096, 2e-5)])
+def test_tiled_vgg19_two_ranks_match_single_gpu_engine(h, w, loss_rtol):
+    """Full VGG19 to conv5_1 (receptive-field apron 80 px): 2 ranks (1 x 2 grid) vs the plain engine on the whole image.
+    176 x 416 is the quick case; 1024 x 4096 is BASELINE configs[4]'s per-rank GEOMETRY on the one GPU there is: windows of
+    1024 x 2128 whose levels are 2128, 1064, 532, 266 and 133 wide (the any-width Winograd kernels, ceil-mode pools, 0.9 GB blobs),
+    aprons, overlap-add, the torus ring of the TV term -- two ranks sharing the card over host-staged gloo, so still unmeasured on
+    xGMI / RCCL hardware."""
     import torch.multiprocessing as mp
-    h, w, steps = 176, 416, 2
+    steps = 2
     rs = np.random.RandomState
     content, style, init = (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (96, 80, 3)).astype(np.uint8),
                             rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
@@ -626,19 +631,22 @@ def test_tiled_vgg19_two_ranks_match_single_gpu_engine():
     procs = [ctx.Process(target=_tiled_vgg_rank, args=(r, 2, port, steps, h, w, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=300) for _ in procs]
+    got = [q.get(timeout=400) for _ in procs]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     for rank, tile, window, res in got:
-        assert window[3] - window[1] == 208 + 80          # tile 208 px + the 80-px apron on its inner side
+        assert window[3] - window[1] == w // 2 + 80       # tile + the 80-px apron on its inner side
     for step in range(steps):
         full = np.zeros_like(want[step][0])
         for rank, (y0, x0, y1, x1), window, res in got:
             full[y0:y1, x0:x1] = res[step][0]
-            assert np.isclose(res[step][1][-2], want[step][1]['loss'], rtol=1e-4), (step, rank)
+            assert np.isclose(res[step][1][-2], want[step][1]['loss'], rtol=loss_rtol), (step, rank, res[step][1][-2], want[step][1]['loss'])
             assert np.isclose(res[step][1][-1], want[step][1]['grad'], rtol=1e-3), (step, rank)
-        assert np.mean((full - want[step][0]) ** 2) <= 1.0, step
+        mse = float(np.mean((full.astype(np.float64) - want[step][0]) ** 2))
+        print('[tiled %dx%d] step %d: loss %.9g vs %.9g, image MSE %.3g, pixels off by > 1: %.2e' % (
+            h, w, step, got[0][3][step][1][-2], want[step][1]['loss'], mse, float(np.mean(np.abs(full - want[step][0]) > 1.0))))
+        assert mse <= (1.0 if h < 1024 else 0.25), (step, mse)   # 0..255 units; Adam's first steps are sign-like (a flipped tiny gradient = 20 levels)
 
 
 def test_vgg19_odd_default_size_225x300_unaligned_paths():

@@ -26,12 +26,20 @@ ap.add_argument('--grid', default='2x4')
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--optimizer', default='adam', choices=('adam', 'lbfgs'))
+ap.add_argument('--solo-rank', type=int, default=-1,
+                help='run ONE rank of the grid alone on this GPU (its window, its pack / unpack kernels; nothing is exchanged, what a\n'
+                     'neighbour would send arrives as zeros): the per-rank compute of a multi-GPU run, e.g. --size 8192 --grid 2x4 --solo-rank 1\n'
+                     '= an interior column (window 4176 x 2208)')
 ap.add_argument('--precision', default='fp32', choices=('fp32', 'bf16'), help='bf16: conv operands bf16, everything else fp32')
 args = ap.parse_args()
 rows, cols = (int(v) for v in args.grid.split('x'))
 gH, gW = (int(v) for v in args.size.split('x')) if 'x' in args.size else (int(args.size), int(args.size))
 rank, local, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
-assert world == rows * cols, 'world size %d != grid %s' % (world, args.grid)
+solo = args.solo_rank >= 0
+assert solo or world == rows * cols, 'world size %d != grid %s' % (world, args.grid)
+if solo:
+    assert world == 1 and args.solo_rank < rows * cols
+    rank = args.solo_rank
 dist = None
 if world > 1:
     import torch
@@ -72,7 +80,16 @@ class WindowView:
 style = np.random.RandomState(2).randint(0, 256, (args.style_size, args.style_size, 3)).astype(np.uint8)
 backend = HipTileBackend(st2_weights.he_normal(topo, seed=0), grid, rank, WindowView(window_image(1)), style,
                          WindowView(window_image(3)), WEIGHTS, PARAMS, step_size=10, device=local, precision=args.precision)
-tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world), optimizer=args.optimizer,
+
+
+class SoloComm(tiled.Comm):
+    """One rank of the grid on its own: reductions see one rank, a neighbour's strips arrive as zeros."""
+    def exchange(self, sends, recvs):
+        for _, t in recvs:
+            t.zero_()
+
+
+tt = tiled.TiledTransfer(grid, rank, backend, SoloComm() if solo else tiled.Comm(dist, rank, world), optimizer=args.optimizer,
                          step_size={'adam': 10, 'lbfgs': 1}[args.optimizer])
 for _ in range(args.warmup):
     tt.step()
@@ -86,13 +103,13 @@ backend.engine.sync()
 if dist is not None:
     dist.barrier()
 dt = time.perf_counter() - t0
-if rank == 0:
+if rank == 0 or solo:
     print(json.dumps({'metric': 'tile-sharded style-transfer iters/sec @%sx%s VGG19' % (gH, gW), 'value': args.steps / dt,
                       'unit': 'it/s', 'n_gpus': world, 'grid': args.grid, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
                       'higher_is_better': True, 'vs_baseline': None,
                       'config': {'workload': 'configs[4]: ONE %dx%d image tile-sharded %s (apron design, RCCL all-reduces + strip exchange), %s %s' % (gH, gW, args.grid, args.optimizer, args.precision),
                                  'measured_on_hardware': 'by the driver only; the builder has one GPU'},
-                      'apron_px': grid.apron, 'window': [win.y1 - win.y0, win.x1 - win.x0], 'loss': float(vals[-2]),
+                      'solo_rank': (args.solo_rank if solo else None), 'apron_px': grid.apron, 'window': [win.y1 - win.y0, win.x1 - win.x0], 'loss': float(vals[-2]),
                       'dtype': 'f32' if args.precision == 'fp32' else 'bf16 conv operands, f32 accumulate/Gram/optimizer', 'scaling': 'strong', 'data': 'synthetic'}))
 if dist is not None:
     dist.destroy_process_group()
