@@ -185,6 +185,40 @@ int st_tile_swap(st_ctx* ctx);
  * tensor <-> one contiguous device buffer (rect r stored as (C, h_r, w_r), in order).  mode 0 pack, 1 unpack, 2 unpack-add. */
 int st_tile_strips(st_ctx* ctx, void* tensor_dev, int C, int wh, int ww, int n, const int* rects, void* buf_dev, int mode);
 
+
+/* ---- the tile-sharded iteration with its communication inside the engine (BASELINE config 5: "RCCL halo exchange over xGMI") -----
+ * The phases above leave the collectives to the caller.  Here the engine owns them: one RCCL communicator per context, the two
+ * all-reduces and the three strip exchanges of an Adam iteration are enqueued on the engine's own stream between the compute phases
+ * (ncclAllReduce in place on the phase buffers; one grouped ncclSend / ncclRecv per neighbour and phase on packed strip buffers), and
+ * the host synchronises once per iteration, to read the trace.  No reference counterpart (the reference runs one image per worker);
+ * what must cross ranks is fixed by worker.py:114 (global Gram normalisation), :254,266,275 (global RMS norms) and utils.py:232-254
+ * (periodic TV).  The geometry and the exchange plan come from the caller (style_transfer2_amd/tiling.py). */
+#define ST_COMM_ID_BYTES 128
+int st_comm_unique_id(char out_id[ST_COMM_ID_BYTES]);                       /* ncclGetUniqueId: on rank 0, then handed to every rank */
+int st_comm_init(st_ctx* ctx, const char id[ST_COMM_ID_BYTES], int rank, int world);      /* ncclCommInitRank on the context's device */
+/* A caller-supplied transport in place of RCCL (the tests run several ranks on ONE GPU, which RCCL refuses): allreduce sums `n` floats
+ * in place over the ranks; exchange sends send_buf[i] (send_count[i] floats) to send_peer[i] and fills recv_buf[j] from recv_peer[j].
+ * All buffers are device memory; the engine has synchronised its stream before the call and the data must be in place on return. */
+typedef int (*st_allreduce_fn)(void* user, float* dev_buf, int n);
+typedef int (*st_exchange_fn)(void* user, int n_send, const int* send_peer, float* const* send_buf, const int* send_count,
+                              int n_recv, const int* recv_peer, float* const* recv_buf, const int* recv_count);
+int st_comm_callbacks(st_ctx* ctx, int rank, int world, st_allreduce_fn allreduce, st_exchange_fn exchange, void* user);
+int st_comm_destroy(st_ctx* ctx);
+int st_comm_barrier(st_ctx* ctx);                                            /* all-reduce of one float + stream synchronisation */
+/* The strips this rank exchanges in one phase.  rects are [n][4] = {y0, x0, h, w}: send rects in the coordinates of the tensor packed
+ * (the window), recv rects in those of the tensor unpacked into (the window; the (3, th + 2, tw + 2) ring for ST_TILE_PLAN_RING).
+ * A peer equal to the own rank (ring phase only: the image's periodic wrap may land on this rank's own tile) is a local copy;
+ * its send and recv rects pair up one to one. */
+enum { ST_TILE_PLAN_OVERLAP = 0, ST_TILE_PLAN_RING = 1, ST_TILE_PLAN_REFRESH = 2 };
+typedef struct st_tile_peer { int peer; int n_send; const int* send_rects; int n_recv; const int* recv_rects; } st_tile_peer;
+int st_tile_plan(st_ctx* ctx, int phase, int n_peers, const st_tile_peer* peers);
+/* One Adam iteration of the tile-sharded image (after st_tile_configure, st_comm_init / st_comm_callbacks and the three st_tile_plan
+ * calls): forward -> all-reduce -> losses (first evaluation: style gradients raw -> all-reduce) -> backward -> overlap-add exchange ->
+ * ring exchange -> TV / p-norm / Adam on the tile -> all-reduce -> apron refresh exchange -> swap.  trace: st_trace_len(ctx) values,
+ * the layout of st_step's. */
+int st_tile_step(st_ctx* ctx, double* trace);
+int st_tile_get_tile(st_ctx* ctx, float* out_hwc);                           /* this rank's tile of the current iterate, (th, tw, 3) deprocessed */
+
 #ifdef __cplusplus
 }
 #endif

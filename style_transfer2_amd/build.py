@@ -32,6 +32,7 @@ SOURCES = (
     ('engine_step.cpp', ('-x', 'hip')),
     ('engine_resample.cpp', ('-x', 'hip')),
     ('engine_tile.cpp', ('-x', 'hip')),
+    ('engine_comm.cpp', ('-x', 'hip')),
 )
 HEADERS = ('st2_kernels.h', 'wave_reduce.h', 'engine.h', os.path.join('..', '..', 'include', 'st2.h'))
 
@@ -81,7 +82,7 @@ def build_lib(force=False, verbose=False):
     if jobs or force or _stale(LIB, objs):
         # -z defs: an unresolved symbol (e.g. a kernel host stub the compiler dropped) fails the LINK, here,
         # instead of the first dlopen on the GPU box
-        run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-Wl,-z,defs', '-o', LIB] + objs)
+        run([hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-Wl,-z,defs', '-o', LIB] + objs + ['-ldl'])
     return LIB
 
 

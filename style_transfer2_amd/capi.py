@@ -19,6 +19,17 @@ class ResampleTable(ctypes.Structure):
     _fields_ = [('lo', POINTER(c_int)), ('n', POINTER(c_int)), ('k', POINTER(c_double)), ('kmax', c_int), ('out_size', c_int)]
 
 
+class TilePeer(ctypes.Structure):
+    _fields_ = [('peer', c_int), ('n_send', c_int), ('send_rects', POINTER(c_int)), ('n_recv', c_int), ('recv_rects', POINTER(c_int))]
+
+
+# transport callbacks of st_comm_callbacks (device pointers arrive as integers)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int)
+EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_int, POINTER(c_int), POINTER(c_void_p), POINTER(c_int),
+                               c_int, POINTER(c_int), POINTER(c_void_p), POINTER(c_int))
+COMM_ID_BYTES = 128
+
+
 class LayerDesc(ctypes.Structure):
     _fields_ = [('kind', c_int), ('name', c_char_p), ('cin', c_int), ('cout', c_int)]
 
@@ -90,6 +101,14 @@ PROTOTYPES = {
     'st_vec_axpy': (c_int, [c_void_p, c_float, c_void_p, c_void_p, c_longlong]),
     'st_vec_div': (c_int, [c_void_p, c_double, c_void_p, c_longlong]),
     'st_tile_strips': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), c_void_p, c_int]),
+    'st_comm_unique_id': (c_int, [c_char_p]),
+    'st_comm_init': (c_int, [c_void_p, c_char_p, c_int, c_int]),
+    'st_comm_callbacks': (c_int, [c_void_p, c_int, c_int, ALLREDUCE_FN, EXCHANGE_FN, c_void_p]),
+    'st_comm_destroy': (c_int, [c_void_p]),
+    'st_comm_barrier': (c_int, [c_void_p]),
+    'st_tile_plan': (c_int, [c_void_p, c_int, c_int, POINTER(TilePeer)]),
+    'st_tile_step': (c_int, [c_void_p, c_void_p]),
+    'st_tile_get_tile': (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -175,7 +175,21 @@ struct st_ctx {
         size_t p1_n = 0, p2_n = 0, p3_n = 0, pd_n = 0;
         bool s2_in_p2 = false;
         float* wgrad = nullptr;                    // window gradient (3, wh, ww)
+        bool fused = false;                        // inside st_tile_step: the phases do not synchronise the stream on their own
     } tile;
+    // communicator of the tile-sharded mode (engine_comm.cpp): RCCL over xGMI, or caller-supplied transport functions (tests)
+    struct Comm {
+        void* lib = nullptr;                       // librccl.so, loaded on first use
+        void* comm = nullptr;                      // ncclComm_t
+        int rank = 0, world = 1;
+        st_allreduce_fn ar = nullptr; st_exchange_fn ex = nullptr; void* user = nullptr;
+        struct Peer { int peer = 0; std::vector<int> send, recv; float *sbuf = nullptr, *rbuf = nullptr; size_t sn = 0, rn = 0; };
+        std::vector<Peer> plan[3];                 // per phase (ST_TILE_PLAN_*): the peers this rank exchanges strips with
+        bool planned[3] = {false, false, false};
+        bool self_via_rccl = false;                // test hook (ST2_COMM_SELF_VIA_RCCL=1): copies to the own rank travel through RCCL too
+        float* ring = nullptr; size_t ring_cap = 0;
+        long long steps = 0;
+    } comm;
     // profiling
     bool prof_on = false;
     std::vector<ProfRec> prof;
@@ -241,4 +255,6 @@ int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad_out, b
 int read_trace(st_ctx* c, double* trace, float* loss);
 // ---------------------------------------------------------------------------------------- engine_step.cpp
 int lbfgs_alloc(st_ctx* c);
+// ---------------------------------------------------------------------------------------- engine_comm.cpp
+void comm_free(st_ctx* c);
 }  // namespace st2e

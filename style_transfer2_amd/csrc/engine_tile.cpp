@@ -248,7 +248,7 @@ int st_tile_backward(st_ctx* c, float** dev_grad)
         if (last > 0) ST_TRY(backward_chain(c, last, inj[last], inj, &g));
         HIP_TRY(hipMemcpyAsync(c->tile.wgrad, g, n3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->tile.fused) HIP_TRY(hipStreamSynchronize(c->stream));
     if (dev_grad) *dev_grad = c->tile.wgrad;
     return ST_OK;
 }
@@ -281,7 +281,7 @@ int st_tile_update(st_ctx* c, const float* ring_dev, float** dev_ptr, int* n_flo
     c->m_zero = c->v_zero = false;
     int n_style = 0;
     for (const ActiveLayer& al : c->active) n_style += al.s;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->tile.fused) HIP_TRY(hipStreamSynchronize(c->stream));
     if (dev_ptr) *dev_ptr = c->tile.p3;
     if (n_floats) *n_floats = 6 + (c->tile.s2_in_p2 ? 0 : n_style);
     return ST_OK;
@@ -308,7 +308,7 @@ int st_tile_gradient(st_ctx* c, const float* ring_dev, float** dev_ptr, int* n_f
     for (int k = 0; k < 6; ++k) HIP_TRY(launch_sum_partials(c->image_part + k * kMaxPartials, np, c->tile.p3 + k, c->stream));
     int n_style = 0;
     for (const ActiveLayer& al : c->active) n_style += al.s;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->tile.fused) HIP_TRY(hipStreamSynchronize(c->stream));
     if (dev_ptr) *dev_ptr = c->tile.p3;
     if (n_floats) *n_floats = 6 + (c->tile.s2_in_p2 ? 0 : n_style);
     return ST_OK;
@@ -321,7 +321,7 @@ int st_vec_dot(st_ctx* c, const float* a_dev, const float* b_dev, long long n, f
     if (!c || !a_dev || !b_dev || !out_dev || n < 0) return fail(ST_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_vec_dot(a_dev, b_dev, (size_t)n, c->image_part, out_dev, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->tile.fused) HIP_TRY(hipStreamSynchronize(c->stream));
     return ST_OK;
 }
 
@@ -330,7 +330,7 @@ int st_vec_axpy(st_ctx* c, float alpha, const float* x_dev, float* y_dev, long l
     if (!c || !x_dev || !y_dev || n < 0) return fail(ST_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_vec_axpy(alpha, x_dev, y_dev, (size_t)n, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->tile.fused) HIP_TRY(hipStreamSynchronize(c->stream));
     return ST_OK;
 }
 
@@ -339,7 +339,7 @@ int st_vec_div(st_ctx* c, double divisor, float* y_dev, long long n)
     if (!c || !y_dev || n < 0 || !(divisor != 0.0)) return fail(ST_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(launch_vec_div(divisor, y_dev, (size_t)n, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->tile.fused) HIP_TRY(hipStreamSynchronize(c->stream));
     return ST_OK;
 }
 
@@ -348,7 +348,7 @@ int st_tile_buffer(st_ctx* c, int which, float** dev_ptr)
 {
     if (c) c->epoch++;       // anything but st_step may change what a step launches: captured step graphs are stale
     if (!c || !dev_ptr) return fail(ST_ERR_ARG, "bad argument");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->tile.fused) HIP_TRY(hipStreamSynchronize(c->stream));
     if (which == 0) *dev_ptr = c->x[c->cur];
     else if (which == 1) *dev_ptr = c->x[c->cur ^ 1];
     else if (which == 2) *dev_ptr = c->tile.pd;
@@ -376,7 +376,7 @@ int st_tile_strips(st_ctx* c, void* tensor_dev, int C, int wh, int ww, int n, co
     }
     t.total = total;
     HIP_TRY(launch_strip_copy((float*)tensor_dev, (float*)buf_dev, t, C, wh, ww, mode, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!c->tile.fused) HIP_TRY(hipStreamSynchronize(c->stream));
     return ST_OK;
 }
 

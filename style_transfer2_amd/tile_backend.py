@@ -2,11 +2,12 @@
 the phases of tiled.TiledTransfer map 1:1 onto the ``st_tile_*`` entry points of the C ABI.  Device buffers
 are handed to torch (for RCCL) as zero-copy views through ``__cuda_array_interface__``."""
 
+import ctypes
 from ctypes import byref, c_int, c_void_p
 
 import numpy as np
-import torch
 
+from . import capi
 from .capi import check
 from .engine import Engine, OPT_ADAM
 from .tiling import blob_geometry
@@ -22,7 +23,19 @@ class _DevArray:
 
 
 def dev_tensor(ptr, shape, device):
+    import torch
     return torch.as_tensor(_DevArray(ptr, shape), device=device)
+
+
+class _LazyTorch:
+    """torch is needed only by the phase-by-phase driver (tiled.TiledTransfer: device buffers handed to torch.distributed) and by the
+    host-staged test transport.  The in-engine iteration (st_tile_step over RCCL) never imports it: one HIP runtime in the process."""
+    def __getattr__(self, name):
+        import torch
+        return getattr(torch, name)
+
+
+torch = _LazyTorch()
 
 
 class HipTileBackend:
@@ -33,7 +46,7 @@ class HipTileBackend:
         self.engine = Engine(topology, device, 'bf16-full' if precision == 'bf16' else precision)
         self.engine.load_weights(net_params)
         self.lib, self.ctx = self.engine.lib, self.engine._ctx
-        self.device = torch.device('cuda', device)
+        self.device_index = device
         self.grid, self.rank = grid, rank
         w, t = grid.windows[rank], grid.tiles[rank]
         crop = lambda im, r: np.ascontiguousarray(im[r.y0:r.y1, r.x0:r.x1])
@@ -60,8 +73,86 @@ class HipTileBackend:
                 self.active.append((r, names.index(r), F32(cw), F32(sw), F32(dw)) + flags + (c, c * gh * gw))
         self.n_style = sum(1 for a in self.active if a[6])
 
+    @property
+    def device(self):
+        return torch.device('cuda', self.device_index)
+
     def _sync(self):
         self.engine.sync()
+
+    # ---- the iteration with its communication inside the engine (st_tile_step; engine_comm.cpp) -------------------------------
+    def comm_init_rccl(self, unique_id, rank, world):
+        """One RCCL communicator for this context (unique_id: the 128 bytes of st_comm_unique_id from rank 0)."""
+        check(self.lib.st_comm_init(self.ctx, bytes(unique_id), int(rank), int(world)))
+
+    def comm_init_callbacks(self, dist, rank, world):
+        """Host-staged transport over a torch.distributed (gloo) group in place of RCCL: the tests run several ranks on one GPU."""
+        device = self.device
+
+        def allreduce(_user, ptr, n):
+            try:
+                t = dev_tensor(ptr, (n,), device)
+                h = t.cpu()
+                dist.all_reduce(h)
+                t.copy_(h)
+                torch.cuda.synchronize(device)
+                return 0
+            except Exception:               # noqa: BLE001 (reported through the status code)
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def exchange(_user, ns, speer, sbuf, scount, nr, rpeer, rbuf, rcount):
+            try:
+                ops, stage = [], []
+                for i in range(ns):
+                    ops.append(dist.P2POp(dist.isend, dev_tensor(sbuf[i], (scount[i],), device).cpu(), speer[i]))
+                for j in range(nr):
+                    h = torch.empty(rcount[j], dtype=torch.float32)
+                    stage.append((dev_tensor(rbuf[j], (rcount[j],), device), h))
+                    ops.append(dist.P2POp(dist.irecv, h, rpeer[j]))
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+                for t, h in stage:
+                    t.copy_(h)
+                torch.cuda.synchronize(device)
+                return 0
+            except Exception:               # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._callbacks = (capi.ALLREDUCE_FN(allreduce), capi.EXCHANGE_FN(exchange))       # keep the thunks alive
+        check(self.lib.st_comm_callbacks(self.ctx, int(rank), int(world), self._callbacks[0], self._callbacks[1], None))
+
+    def set_plan(self, phase, peers):
+        """peers: {peer rank: (send rects, recv rects)}, rects = [(y0, x0, h, w), ...] (tiled.fused_plans)."""
+        keep = []
+        arr = (capi.TilePeer * max(len(peers), 1))()
+        for k, peer in enumerate(sorted(peers)):
+            send, recv = peers[peer]
+            sa = (c_int * max(4 * len(send), 1))(*[int(v) for r in send for v in r])
+            ra = (c_int * max(4 * len(recv), 1))(*[int(v) for r in recv for v in r])
+            keep += [sa, ra]
+            arr[k].peer, arr[k].n_send, arr[k].n_recv = int(peer), len(send), len(recv)
+            arr[k].send_rects = ctypes.cast(sa, ctypes.POINTER(c_int))
+            arr[k].recv_rects = ctypes.cast(ra, ctypes.POINTER(c_int))
+        check(self.lib.st_tile_plan(self.ctx, int(phase), len(peers), arr))
+
+    def step_fused(self):
+        """One Adam iteration, every phase and collective enqueued by the engine; returns the trace values."""
+        trace = np.zeros(self.engine.trace_len(), np.float64)
+        check(self.lib.st_tile_step(self.ctx, trace.ctypes.data_as(c_void_p)))
+        return trace
+
+    def barrier(self):
+        check(self.lib.st_comm_barrier(self.ctx))
+
+    def tile_image(self):
+        t = self.grid.tiles[self.rank]
+        out = np.empty((t.y1 - t.y0, t.x1 - t.x0, 3), F32)
+        check(self.lib.st_tile_get_tile(self.ctx, out.ctypes.data_as(c_void_p)))
+        return out
 
     def _buf(self, which, shape):
         p = c_void_p()

@@ -18,9 +18,18 @@ backend built on the CPU oracle.
 """
 
 import numpy as np
-import torch
 
 from .tiling import Rect
+
+
+class _LazyTorch:
+    """Only the phase-by-phase driver (TiledTransfer / Comm) uses torch; FusedTiledTransfer (st_tile_step over RCCL) does not."""
+    def __getattr__(self, name):
+        import torch as _torch
+        return getattr(_torch, name)
+
+
+torch = _LazyTorch()
 
 
 class Comm:
@@ -259,6 +268,98 @@ class TiledTransfer:
         ys, xs = _local(self.tile, self.window)
         mean = torch.tensor((123.68, 116.779, 103.939), dtype=x.dtype, device=x.device).reshape(3, 1, 1)
         return (x[:, ys, xs] + mean).permute(1, 2, 0).contiguous().cpu().numpy()
+
+
+PLAN_OVERLAP, PLAN_RING, PLAN_REFRESH = 0, 1, 2          # st2.h ST_TILE_PLAN_*
+
+
+def fused_plans(grid, rank):
+    """The three strip exchanges of one iteration as st_tile_plan wants them: {phase: {peer: (send rects, recv rects)}}, rects
+    (y0, x0, h, w) in the coordinates of the tensor packed (the window) / unpacked into (the window; the ring for PLAN_RING).
+    Same plans, same order, as TiledTransfer.overlap_add / gather_ring / refresh_aprons build per step."""
+    window, tile = grid.windows[rank], grid.tiles[rank]
+
+    def lrect(rect, origin):
+        return (rect.y0 - origin.y0, rect.x0 - origin.x0, rect.y1 - rect.y0, rect.x1 - rect.x0)
+    plans = {PLAN_OVERLAP: {}, PLAN_RING: {}, PLAN_REFRESH: {}}
+    for phase, plan in ((PLAN_OVERLAP, grid.grad_overlap_plan()), (PLAN_REFRESH, grid.apron_refresh_plan())):
+        for src, dst, rect in plan:
+            if src == rank:
+                plans[phase].setdefault(dst, ([], []))[0].append(lrect(rect, window))
+            elif dst == rank:
+                plans[phase].setdefault(src, ([], []))[1].append(lrect(rect, window))
+    for dst, items in enumerate(grid.ring_plan()):
+        for src, rect, ry, rx in items:
+            h, w = rect.y1 - rect.y0, rect.x1 - rect.x0
+            if src == rank:
+                plans[PLAN_RING].setdefault(dst, ([], []))[0].append(lrect(rect, window))
+                if dst == rank:                                     # the periodic wrap lands on this rank's own tile: a local copy
+                    plans[PLAN_RING][dst][1].append((ry, rx, h, w))
+            elif dst == rank:
+                plans[PLAN_RING].setdefault(src, ([], []))[1].append((ry, rx, h, w))
+    return plans
+
+
+class FusedTiledTransfer:
+    """The tile-sharded Adam iteration with the communication INSIDE the engine (st_tile_step): the backend owns an RCCL communicator
+    (or, in tests, a host-staged transport), the exchange plans are handed over once, and a step is one call -- every compute phase,
+    all-reduce and strip exchange is enqueued on the engine's stream, the host synchronises once per iteration for the trace."""
+
+    def __init__(self, grid, rank, backend):
+        self.grid, self.rank, self.backend = grid, rank, backend
+        self.tile = grid.tiles[rank]
+        self.t = 0
+        for phase, peers in fused_plans(grid, rank).items():
+            backend.set_plan(phase, peers)
+
+    def step(self):
+        self.t += 1
+        return self.backend.step_fused()
+
+    def tile_image(self):
+        return self.backend.tile_image()
+
+
+def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=120.0):
+    """Hands rank 0's 128-byte communicator id to every rank over a plain TCP socket (MASTER_ADDR : MASTER_PORT + 17 of the launcher's
+    environment): the control plane of st_comm_init, so that the RCCL path needs neither torch.distributed nor a second HIP runtime."""
+    import os
+    import socket
+    import time
+    if world == 1:
+        return make_id()
+    addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(port if port is not None else int(os.environ.get('MASTER_PORT', '29500')) + 17)
+    if rank == 0:
+        uid = make_id()
+        srv = socket.socket()
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        for _ in range(world - 1):
+            conn, _ = srv.accept()
+            conn.sendall(uid)
+            conn.close()
+        srv.close()
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        try:
+            conn = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise
+            time.sleep(0.2)
+    uid = b''
+    while len(uid) < 128:
+        chunk = conn.recv(128 - len(uid))
+        if not chunk:
+            raise ConnectionError('rank 0 closed the rendezvous early')
+        uid += chunk
+    conn.close()
+    return uid
 
 
 def crop(image, rect):

@@ -430,6 +430,41 @@ def test_tiled_single_rank_equals_plain_engine():
         assert np.allclose(tt.tile_image(), img, rtol=0, atol=2e-3), i
 
 
+def test_fused_tile_step_on_a_one_rank_rccl_communicator_equals_the_plain_engine(monkeypatch):
+    """st_tile_step (every phase and collective enqueued by the engine) on a 1 x 1 grid with a REAL RCCL communicator of one rank:
+    st_comm_unique_id / st_comm_init, ncclAllReduce on the phase buffers, and -- test hook ST2_COMM_SELF_VIA_RCCL -- the ring's
+    periodic-wrap copies travelling as grouped ncclSend / ncclRecv to the own rank.  Must reproduce the ordinary engine step.
+    (More ranks need more GPUs: the multi-rank tests below run the same engine code over a host-staged transport.)"""
+    import ctypes
+    from style_transfer2_amd import capi, tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    monkeypatch.setenv('ST2_COMM_SELF_VIA_RCCL', '1')
+    h, w = 32, 48
+    content, style, init = _tiled_images(h, w)
+    params = oracle.he_init_weights(TILED_TOPO, 0, 0.1)
+    grid = tiling.TileGrid(h, w, 1, 1, TILED_TOPO, 5)
+    backend = HipTileBackend(params, grid, 0, content, style, init, TILED_WEIGHTS, TILED_PARAMS, step_size=10, topology=TILED_TOPO)
+    uid = ctypes.create_string_buffer(capi.COMM_ID_BYTES)
+    capi.check(backend.lib.st_comm_unique_id(uid))
+    assert tiled.rendezvous_unique_id(0, 1, lambda: uid.raw) == uid.raw
+    backend.comm_init_rccl(uid.raw, 0, 1)
+    ft = tiled.FusedTiledTransfer(grid, 0, backend)
+    ref = st2.StyleTransfer(st2.HipModel(params, topology=TILED_TOPO))
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(TILED_WEIGHTS, TILED_PARAMS)
+    ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
+    assert ref.start()
+    for i in range(4):
+        vals = ft.step()
+        img, tr = ref.step()
+        assert np.isclose(vals[-2], tr['loss'], rtol=1e-5), (i, vals[-2], tr['loss'])
+        assert np.isclose(vals[-1], tr['grad'], rtol=1e-5), i
+        assert np.allclose(ft.tile_image(), img, rtol=0, atol=2e-3), i
+    backend.barrier()
+    prof = backend.engine  # the communicator is released with the context
+    capi.check(backend.lib.st_comm_destroy(backend.ctx))
+
+
 @pytest.mark.parametrize('h,w', [(32, 48), (75, 100)])
 def test_tiled_lbfgs_single_rank_equals_plain_engine(h, w):
     """optimizer='lbfgs' on a 1x1 grid (every all-reduce a no-op) against the engine's device-resident L-BFGS: the same
@@ -489,7 +524,7 @@ def test_tiled_single_rank_with_bf16_convs_tracks_the_bf16_engine():
             assert vals[-2] != tr32['loss'] and np.isclose(vals[-2], tr32['loss'], rtol=2e-2)      # bf16 operands really are in use
 
 
-def _tiled_gpu_rank(rank, world, rows, cols, port, steps, h, w, q, optimizer='adam'):
+def _tiled_gpu_rank(rank, world, rows, cols, port, steps, h, w, q, optimizer='adam', fused=False):
     import os, sys
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -500,8 +535,12 @@ def _tiled_gpu_rank(rank, world, rows, cols, port, steps, h, w, q, optimizer='ad
     grid = tiling.TileGrid(h, w, rows, cols, TILED_TOPO, 5)
     backend = HipTileBackend(oracle.he_init_weights(TILED_TOPO, 0, 0.1), grid, rank, content, style, init,
                              TILED_WEIGHTS, TILED_PARAMS, step_size=10, topology=TILED_TOPO)
-    tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world), optimizer=optimizer,
-                             step_size={'adam': 10, 'lbfgs': 1}[optimizer])
+    if fused:       # the iteration with its communication inside the engine (st_tile_step); the transport is host-staged gloo here
+        backend.comm_init_callbacks(dist, rank, world)
+        tt = tiled.FusedTiledTransfer(grid, rank, backend)
+    else:
+        tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world), optimizer=optimizer,
+                                 step_size={'adam': 10, 'lbfgs': 1}[optimizer])
     res = []
     for _ in range(steps):
         vals = tt.step()
@@ -543,8 +582,8 @@ def test_tiled_lbfgs_two_ranks_on_one_gpu_match_oracle():
         assert np.mean((full - ref[step][0]) ** 2) <= (1e-3 if step < 3 else 1.0), step
 
 
-@pytest.mark.parametrize('rows,cols', [(1, 2), (2, 2)])
-def test_tiled_multi_rank_on_one_gpu_matches_oracle(rows, cols):
+@pytest.mark.parametrize('rows,cols,fused', [(1, 2, False), (2, 2, False), (1, 2, True), (2, 2, True)])
+def test_tiled_multi_rank_on_one_gpu_matches_oracle(rows, cols, fused):
     """2 / 4 processes share the GPU (each with its own engine + window), exchange through gloo, and must
     reproduce the single-process CPU oracle on the whole image."""
     import torch.multiprocessing as mp
@@ -560,8 +599,8 @@ def test_tiled_multi_rank_on_one_gpu_matches_oracle(rows, cols):
         ref.append((np.asarray(img, F32).copy(), dict(tr)))
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29900 + (__import__('os').getpid() + rows * 5 + cols) % 1000
-    procs = [ctx.Process(target=_tiled_gpu_rank, args=(r, world, rows, cols, port, steps, h, w, q)) for r in range(world)]
+    port = 29900 + (__import__('os').getpid() + rows * 5 + cols + 17 * fused) % 1000
+    procs = [ctx.Process(target=_tiled_gpu_rank, args=(r, world, rows, cols, port, steps, h, w, q, 'adam', fused)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in procs]
@@ -578,7 +617,7 @@ def test_tiled_multi_rank_on_one_gpu_matches_oracle(rows, cols):
     assert np.allclose(full, ref[-1][0], rtol=0, atol=0.5) or np.mean(np.abs(full - ref[-1][0]) > 0.5) < 0.02
 
 
-def _tiled_vgg_rank(rank, world, port, steps, h, w, q):
+def _tiled_vgg_rank(rank, world, port, steps, h, w, q, fused=False):
     import os
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -594,7 +633,11 @@ def _tiled_vgg_rank(rank, world, port, steps, h, w, q):
                'deepdream': {}}
     backend = HipTileBackend(oracle.he_init_weights(topo, seed=0), grid, rank, content, style, init, weights,
                              {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}, step_size=10)
-    tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world))
+    if fused:
+        backend.comm_init_callbacks(dist, rank, world)
+        tt = tiled.FusedTiledTransfer(grid, rank, backend)
+    else:
+        tt = tiled.TiledTransfer(grid, rank, backend, tiled.Comm(dist, rank, world))
     res = []
     for _ in range(steps):
         vals = tt.step()
@@ -604,8 +647,8 @@ def _tiled_vgg_rank(rank, world, port, steps, h, w, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('h,w,loss_rtol', [(176, 416, 1e-4), (1024, 4096, 2e-5)])
-def test_tiled_vgg19_two_ranks_match_single_gpu_engine(h, w, loss_rtol):
+@pytest.mark.parametrize('h,w,loss_rtol,fused', [(176, 416, 1e-4, False), (176, 416, 1e-4, True), (1024, 4096, 2e-5, True)])
+def test_tiled_vgg19_two_ranks_match_single_gpu_engine(h, w, loss_rtol, fused):
     """Full VGG19 to conv5_1 (receptive-field apron 80 px): 2 ranks (1 x 2 grid) vs the plain engine on the whole image.
     176 x 416 is the quick case; 1024 x 4096 is BASELINE configs[4]'s per-rank GEOMETRY on the one GPU there is: windows of
     1024 x 2128 whose levels are 2128, 1064, 532, 266 and 133 wide (the any-width Winograd kernels, ceil-mode pools, 0.9 GB blobs),
@@ -627,8 +670,8 @@ def test_tiled_vgg19_two_ranks_match_single_gpu_engine(h, w, loss_rtol):
     want = [(np.asarray(i, F32).copy(), dict(t)) for i, t in want]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29300 + __import__('os').getpid() % 500
-    procs = [ctx.Process(target=_tiled_vgg_rank, args=(r, 2, port, steps, h, w, q)) for r in range(2)]
+    port = 29300 + (__import__('os').getpid() + 7 * fused + h) % 500
+    procs = [ctx.Process(target=_tiled_vgg_rank, args=(r, 2, port, steps, h, w, q, fused)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=400) for _ in procs]

@@ -21,6 +21,7 @@ WEIGHTS = {'content': {'conv2_2': 0.08, 'conv1_2': 0.5}, 'style': {'conv1_1': 1,
            'deepdream': {'conv2_1': 0.02}}
 PARAMS = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
 GH, GW = 32, 48
+F32 = np.float32
 
 
 def test_receptive_apron_and_stride():
@@ -169,3 +170,73 @@ def test_tiled_lbfgs_matches_single_process_oracle(rows, cols):
         assert np.mean((full - ref[step][0]) ** 2) <= (1e-4 if step < 3 else 0.05), (step, np.abs(full - ref[step][0]).max())
     losses = [r[1]['loss'] for r in ref]
     assert all(np.isfinite(losses)) and len({round(float(v), 3) for v in losses}) == steps       # a moving trajectory, not a fixed point
+
+
+# ------------------------------------------------------------------------------ the exchange plans of the in-engine iteration
+@pytest.mark.parametrize('gh,gw,rows,cols', [(64, 96, 1, 2), (64, 96, 2, 2), (96, 160, 2, 4), (8192, 8192, 2, 4)])
+def test_fused_plans_are_consistent_across_ranks_and_move_the_right_pixels(gh, gw, rows, cols):
+    """tiled.fused_plans (what st_tile_plan receives, engine_comm.cpp) for every rank of a grid: what a sends to b is exactly what b
+    expects from a, in the same order; played on numpy arrays the three exchanges do what TiledTransfer's per-step exchanges do --
+    aprons end up holding the owner's pixels, window gradients add up to the whole-image gradient, the ring is the periodic wrap."""
+    import oracle
+    from style_transfer2_amd import tiled, tiling
+    topo = oracle.VGG19_TOPOLOGY if gh >= 4096 else oracle.tiny_topology((8, 16), (2, 2))
+    grid = tiling.TileGrid(gh, gw, rows, cols, topo, 17 if gh >= 4096 else 5)
+    world = rows * cols
+    plans = [tiled.fused_plans(grid, r) for r in range(world)]
+    for phase in (tiled.PLAN_OVERLAP, tiled.PLAN_RING, tiled.PLAN_REFRESH):
+        for a in range(world):
+            for b, (send, _) in plans[a][phase].items():
+                if a == b:
+                    assert [r[2:] for r in send] == [r[2:] for r in plans[a][phase][a][1]]
+                    continue
+                recv = plans[b][phase].get(a, ([], []))[1]
+                assert [r[2:] for r in send] == [r[2:] for r in recv], (phase, a, b)       # same sizes, same order
+    if gh >= 4096:
+        return                                                                         # geometry only at the production size
+    rng = np.random.RandomState(0)
+    image = rng.randn(3, gh, gw).astype(F32)
+
+    def play(phase, src, dst, add):
+        """src / dst: per-rank arrays; messages = concatenated rects, as the engine packs them."""
+        for a in range(world):
+            for b, (send, _) in plans[a][phase].items():
+                msg = [src[a][:, y:y + h, x:x + w].copy() for y, x, h, w in send]
+                for piece, (y, x, h, w) in zip(msg, plans[b][phase][a][1]):
+                    if add:
+                        dst[b][:, y:y + h, x:x + w] += piece
+                    else:
+                        dst[b][:, y:y + h, x:x + w] = piece
+
+    def crop(arr, r):
+        return arr[:, r.y0:r.y1, r.x0:r.x1].copy()
+    # apron refresh: windows whose tile part is current get their aprons from the owners
+    wins = []
+    for r in range(world):
+        w, t = grid.windows[r], grid.tiles[r]
+        x = np.full((3, w.y1 - w.y0, w.x1 - w.x0), np.nan, F32)
+        x[:, t.y0 - w.y0:t.y1 - w.y0, t.x0 - w.x0:t.x1 - w.x0] = crop(image, t)
+        wins.append(x)
+    play(tiled.PLAN_REFRESH, wins, wins, False)
+    for r in range(world):
+        assert np.array_equal(wins[r], crop(image, grid.windows[r])), r
+    # overlap-add: per-window gradients (each window contributes `image` on its whole extent) add up on the tile pixels
+    grads = [crop(image, grid.windows[r]) for r in range(world)]
+    before = [g.copy() for g in grads]
+    play(tiled.PLAN_OVERLAP, before, grads, True)
+    cover = np.zeros((gh, gw), F32)
+    for w in grid.windows:
+        cover[w.y0:w.y1, w.x0:w.x1] += 1
+    for r in range(world):
+        w, t = grid.windows[r], grid.tiles[r]
+        got = grads[r][:, t.y0 - w.y0:t.y1 - w.y0, t.x0 - w.x0:t.x1 - w.x0]
+        assert np.allclose(got, crop(image, t) * cover[t.y0:t.y1, t.x0:t.x1], rtol=1e-6), r
+    # ring: the tile's 1-px neighbourhood under the image's periodic wrap
+    rings = [np.zeros((3, t.y1 - t.y0 + 2, t.x1 - t.x0 + 2), F32) for t in grid.tiles]
+    play(tiled.PLAN_RING, [crop(image, w) for w in grid.windows], rings, False)
+    padded = np.pad(image, ((0, 0), (1, 1), (1, 1)), mode='wrap')
+    for r, t in enumerate(grid.tiles):
+        want = padded[:, t.y0:t.y1 + 2, t.x0:t.x1 + 2]
+        ring = rings[r]
+        assert np.array_equal(ring[:, 0], want[:, 0]) and np.array_equal(ring[:, -1], want[:, -1]), r
+        assert np.array_equal(ring[:, :, 0], want[:, :, 0]) and np.array_equal(ring[:, :, -1], want[:, :, -1]), r

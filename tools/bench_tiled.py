@@ -5,7 +5,9 @@
         --size 8192 --grid 2x4 --steps 10
     python tools/bench_tiled.py --size 2048 --grid 1x1          # one GPU: the tile phases without communication
 
-One rank per GPU, RCCL for the all-reduces and the strip exchanges.  Prints one JSON line on rank 0."""
+One rank per GPU.  Default: the iteration with its communication inside the engine (st_tile_step: RCCL all-reduces and grouped
+send / recv strip exchanges on the engine's stream; torch is not imported, the communicator id travels over a plain socket).
+--driver phases: the phase-by-phase driver over torch.distributed (the path the gloo tests use).  One JSON line on rank 0."""
 import argparse
 import json
 import os
@@ -26,6 +28,7 @@ ap.add_argument('--grid', default='2x4')
 ap.add_argument('--steps', type=int, default=10)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--optimizer', default='adam', choices=('adam', 'lbfgs'))
+ap.add_argument('--driver', default='engine', choices=('engine', 'phases'))
 ap.add_argument('--solo-rank', type=int, default=-1,
                 help='run ONE rank of the grid alone on this GPU (its window, its pack / unpack kernels; nothing is exchanged, what a\n'
                      'neighbour would send arrives as zeros): the per-rank compute of a multi-GPU run, e.g. --size 8192 --grid 2x4 --solo-rank 1\n'
@@ -41,7 +44,8 @@ if solo:
     assert world == 1 and args.solo_rank < rows * cols
     rank = args.solo_rank
 dist = None
-if world > 1:
+use_engine = args.driver == 'engine' and args.optimizer == 'adam' and not solo
+if world > 1 and not use_engine:
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local)
@@ -89,19 +93,30 @@ class SoloComm(tiled.Comm):
             t.zero_()
 
 
-tt = tiled.TiledTransfer(grid, rank, backend, SoloComm() if solo else tiled.Comm(dist, rank, world), optimizer=args.optimizer,
-                         step_size={'adam': 10, 'lbfgs': 1}[args.optimizer])
+if use_engine:
+    import ctypes
+    from style_transfer2_amd import capi
+
+    def make_id():
+        uid = ctypes.create_string_buffer(capi.COMM_ID_BYTES)
+        capi.check(backend.lib.st_comm_unique_id(uid))
+        return uid.raw
+    backend.comm_init_rccl(tiled.rendezvous_unique_id(rank, world, make_id), rank, world)
+    tt = tiled.FusedTiledTransfer(grid, rank, backend)
+    barrier = backend.barrier
+else:
+    tt = tiled.TiledTransfer(grid, rank, backend, SoloComm() if solo else tiled.Comm(dist, rank, world), optimizer=args.optimizer,
+                             step_size={'adam': 10, 'lbfgs': 1}[args.optimizer])
+    barrier = dist.barrier if dist is not None else (lambda: None)
 for _ in range(args.warmup):
     tt.step()
 backend.engine.sync()
-if dist is not None:
-    dist.barrier()
+barrier()
 t0 = time.perf_counter()
 for _ in range(args.steps):
     vals = tt.step()
 backend.engine.sync()
-if dist is not None:
-    dist.barrier()
+barrier()
 dt = time.perf_counter() - t0
 if rank == 0 or solo:
     print(json.dumps({'metric': 'tile-sharded style-transfer iters/sec @%sx%s VGG19' % (gH, gW), 'value': args.steps / dt,
@@ -109,6 +124,7 @@ if rank == 0 or solo:
                       'higher_is_better': True, 'vs_baseline': None,
                       'config': {'workload': 'configs[4]: ONE %dx%d image tile-sharded %s (apron design, RCCL all-reduces + strip exchange), %s %s' % (gH, gW, args.grid, args.optimizer, args.precision),
                                  'measured_on_hardware': 'by the driver only; the builder has one GPU'},
+                      'driver': 'engine (st_tile_step, RCCL inside the engine)' if use_engine else 'phases (torch.distributed between the st_tile_* phases)',
                       'solo_rank': (args.solo_rank if solo else None), 'apron_px': grid.apron, 'window': [win.y1 - win.y0, win.x1 - win.x0], 'loss': float(vals[-2]),
                       'dtype': 'f32' if args.precision == 'fp32' else 'bf16 conv operands, f32 accumulate/Gram/optimizer', 'scaling': 'strong', 'data': 'synthetic'}))
 if dist is not None:
