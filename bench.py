@@ -120,7 +120,7 @@ def workload_label(args):
     if args.examples:
         return ('configs[0]: examples golden_gate + starry_night fitted to %d px (content 192x256, style 160x256) by jobs.resize_to_fit, '
                 'uniform-noise init, VGG19 (seeded weights), initial_weights.yaml losses, adam fp32, %d iterations per image'
-                % (EXAMPLES_FIT, EXAMPLES_ITERS))
+                % (EXAMPLES_FIT, args.examples_iters))
     what = '%dx%d single image per GPU, VGG19 to conv5_1, content conv4_2 + 5 style layers, %s %s, %d iterations per image' % (
         args.size, args.size, args.optimizer, args.precision, ITERS_PER_IMAGE)
     if (args.size, args.optimizer, args.precision) == (1024, 'adam', 'fp32'):
@@ -436,6 +436,7 @@ def main(argv=None):
                     help="bf16 = BASELINE configs[2] 'bf16 features / fp32 Gram'; the headline metric is fp32")
     ap.add_argument('--examples', action='store_true',
                     help='BASELINE configs[0]: the example pair fitted to 256 px by jobs.resize_to_fit, noise init, 50 Adam iterations, CPU oracle beside it')
+    ap.add_argument('--examples-iters', type=int, default=EXAMPLES_ITERS, help=argparse.SUPPRESS)       # (the GPU test shortens the job)
     ap.add_argument('--tiled', default='', help='RxC: ONE image of --size tile-sharded over R*C GPUs (BASELINE configs[4])')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-worker-level', action='store_true')
@@ -487,7 +488,7 @@ def main(argv=None):
         sync = job.engine.sync
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and args.engine == 'hip'
     cpu_size = args.cpu_size or args.size
-    cpu_iters = EXAMPLES_ITERS if args.examples else 1
+    cpu_iters = args.examples_iters if args.examples else 1
     dev_steps = cpu_iters + (1 if (args.optimizer == 'lbfgs' and cpu_iters == 1) else 0)      # (the oracle leg's untimed first L-BFGS step)
     dev_eval = device_eval_for_parity(job, dev_steps) if want_cpu and cpu_size == args.size else None
 

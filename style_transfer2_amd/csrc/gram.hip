@@ -329,34 +329,43 @@ __global__ __launch_bounds__(256) void gram_fold_k(const float* __restrict__ sla
 // Both stages in one launch for many splits: 16 lanes share an element, lane j sums splits j, j + 16, ... (16 loads in flight
 // per lane pair of rounds), the 16 partial sums meet in LDS and are added in lane order -- a fixed order again, and a tenth of
 // the launches' latency (two ~10 us kernels per style layer become one).
-constexpr int GR_LANES = 16, GR_ELEMS = 256 / GR_LANES;
+constexpr int GR_LANES = 8, GR_QUADS = 256 / GR_LANES, GR_ELEMS = 4 * GR_QUADS;
 __global__ __launch_bounds__(256) void gram_reduce_wide_k(const float* __restrict__ slabs, const float* __restrict__ target,
                                                           float* __restrict__ out, float* __restrict__ partial,
                                                           int cc, int splits, float n, int C, int out_ld, int bt)
 {
-    __shared__ float part_s[GR_LANES][GR_ELEMS + 1];
+    // one thread = four consecutive elements of a row (C % 4 == 0: same row, same tile), 32 threads = 512 contiguous bytes of
+    // one slab per load instruction; GR_LANES such rows of threads take the splits round-robin
+    __shared__ float4 part_s[GR_LANES][GR_QUADS];
     __shared__ float scratch[4];
-    const int el = threadIdx.x % GR_ELEMS, ln = threadIdx.x / GR_ELEMS;      // neighbouring threads: neighbouring elements of one slab
+    const int q = threadIdx.x % GR_QUADS, ln = threadIdx.x / GR_QUADS;
     float acc[1] = {0.f};
     for (int base = blockIdx.x * GR_ELEMS; base < cc; base += gridDim.x * GR_ELEMS) {
-        const int i = base + el;
+        const int i = base + 4 * q;
         const int r = i < cc ? i / C : 0, c = i < cc ? i - r * C : 0;
         const bool live = i < cc && r / bt <= c / bt;        // lower-triangular tiles are produced by the mirror of (c, r)
-        float sum = 0.f;
+        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
         if (live)
-            for (int s = ln; s < splits; s += GR_LANES) sum += slabs[(size_t)s * cc + i];
+            for (int s = ln; s < splits; s += GR_LANES) {
+                const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)s * cc + i);
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
         __syncthreads();                                     // the previous group's partial sums are consumed
-        part_s[ln][el] = sum;
+        part_s[ln][q] = sum;
         __syncthreads();
         if (ln == 0 && live) {
-            float tot = part_s[0][el];
+            float4 tot = part_s[0][q];
 #pragma unroll
-            for (int j = 1; j < GR_LANES; ++j) tot += part_s[j][el];
-            float v = tot / n;                               // np.dot(x, x.T) / np.float32(x.size)
-            if (target) v -= target[i];
-            out[r * out_ld + c] = v;
-            acc[0] += v * v;
-            if (r / bt < c / bt) { out[c * out_ld + r] = v; acc[0] += v * v; }
+            for (int j = 1; j < GR_LANES; ++j) { const float4 p = part_s[j][q]; tot.x += p.x; tot.y += p.y; tot.z += p.z; tot.w += p.w; }
+            float v[4] = {tot.x / n, tot.y / n, tot.z / n, tot.w / n};       // np.dot(x, x.T) / np.float32(x.size)
+            if (target) { const float4 t = *reinterpret_cast<const float4*>(target + i); v[0] -= t.x; v[1] -= t.y; v[2] -= t.z; v[3] -= t.w; }
+            const bool mirror = r / bt < c / bt;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                out[r * out_ld + c + k] = v[k];
+                acc[0] += v[k] * v[k];
+                if (mirror) { out[(c + k) * out_ld + r] = v[k]; acc[0] += v[k] * v[k]; }
+            }
         }
     }
     block_sum(acc, scratch);
@@ -372,7 +381,7 @@ hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* ta
     int splits = pl.splits;
     // ST2_GRAM_REDUCE=2 keeps the two-stage reduction (read per launch)
     const char* two = getenv("ST2_GRAM_REDUCE");
-    if (splits > 32 && !(two && *two == '2')) {
+    if (splits > 32 && C % 4 == 0 && pl.bt % 4 == 0 && !(two && *two == '2')) {
         const int grid = reduce_grid((size_t)cc, GR_ELEMS, kMaxPartials);
         if (n_partial) *n_partial = grid;
         gram_reduce_wide_k<<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)divisor, C, out_ld, pl.bt);
