@@ -74,7 +74,11 @@ struct Conv16KArgs {
     const unsigned short* s_in16; const unsigned short* s_wpack; int s_nch; unsigned s_in_bytes, s_w_bytes;
 };
 
-template <int BM, int ROWS, int WAVES_M, int WAVES_N>
+// SB = true: ONE staging buffer instead of two.  A short reduction (K <= 128: two to eight chunks) never reaches the steady state
+// the double buffer is built for -- the workgroup waits for its first chunks at HBM latency with nothing to overlap -- so the
+// short-K launches trade the second buffer for occupancy: 39 KiB of LDS per workgroup, FOUR workgroups per CU, and one
+// workgroup's DMA wait runs under the other three's MFMAs.
+template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false>
 __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 {
     constexpr int TM = BM / WAVES_M / 32;
@@ -94,7 +98,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     constexpr int PPS = (NPIECE + NSTEP - 2) / (NSTEP - 1);
     static_assert(W_QUADS % 64 == 0, "weight slab is a whole number of 1-KiB DMA pieces");
 
-    __shared__ __attribute__((aligned(16))) uint4 smem[2 * BUF_Q];
+    __shared__ __attribute__((aligned(16))) uint4 smem[(SB ? 1 : 2) * BUF_Q];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -174,6 +178,32 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 
 #pragma unroll
     for (int t = 0; t < NPIECE; ++t) dma_piece(t, 0, 0);
+  if constexpr (SB) {
+    for (int ch = 0; ch < a.nch; ++ch) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                         // chunk ch has landed
+        fetch(smem, 0, av[0], bv[0]);
+#pragma unroll
+        for (int s2 = 0; s2 < NSTEP; ++s2) {
+#pragma unroll
+            for (int ij = 0; ij < TM * TN; ++ij) {
+                const int i = ij / TN, j = ij % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2 % 3][i], bv[s2 % 3][j], acc[i][j], 0, 0, 0);
+                if (ij == 0 && s2 + 1 < NSTEP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    fetch(smem, s2 + 1, av[(s2 + 1) % 3], bv[(s2 + 1) % 3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ch + 1 < a.nch) {
+            __syncthreads();                                     // every wave has read its last operands of chunk ch
+#pragma unroll
+            for (int t = 0; t < NPIECE; ++t) dma_piece(t, ch + 1, 0);
+        }
+    }
+  } else {
     __syncthreads();
     fetch(smem, 0, av[0], bv[0]);
     for (int ch = 0; ch < a.nch; ++ch) {
@@ -206,6 +236,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+  }
 
     // ---- epilogue: fp32 blob (same as the fp32 kernel, optional) + bf16 channel-blocked copy (optional) + fused pool (optional)
     // Written for the memory system, not for brevity: every load the epilogue needs (the bf16 ReLU masks of the whole tile,
@@ -297,8 +328,8 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         for (int ch = 0; ch < a.s_nch; ++ch) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                     // chunk ch has landed; the other buffer is free again
-            if (ch + 1 < a.s_nch) s_dma(ch + 1, (ch + 1) & 1);
-            const uint4* base = smem + (ch & 1) * BUF_Q;
+            if (!SB && ch + 1 < a.s_nch) s_dma(ch + 1, (ch + 1) & 1);
+            const uint4* base = smem + (SB ? 0 : (ch & 1)) * BUF_Q;
             bf16x8 ahi[TM], alo[TM], bq[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -314,6 +345,10 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bq[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bq[j], acc[i][j], 0, 0, 0);
                 }
+            if (SB && ch + 1 < a.s_nch) {
+                __syncthreads();                                 // the operands of chunk ch are in registers everywhere
+                s_dma(ch + 1, 0);
+            }
         }
     }
     if (MK_ALL && has_mask16) {
@@ -456,6 +491,8 @@ ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x256, 64, 8, 1, 4, 2)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_128x128, 128, 4, 2, 2, 1)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x128, 64, 4, 1, 4, 3)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x512, 64, 16, 1, 4, 2)     // 4 rows per wave: twice the MFMA work per staged weight slab
+// single staging buffer, three workgroups per CU (162 registers, 30 KiB of LDS each): the short-K launches (conv16_body, SB)
+__global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true>(a); }
 
 static int conv16_pick_cfg(const Conv16Problem& p)
 {
@@ -485,7 +522,13 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     if (pools && !conv16_can_pool(p)) return hipErrorInvalidValue;
     if (!p.out && !p.out16 && !pools) return hipErrorInvalidValue;          // nothing to write
     const long long tx = (p.W + 31) / 32;
-    const int cfg = conv16_pick_cfg(p);
+    int cfg = conv16_pick_cfg(p);
+    // short reductions (K <= ST2_CONV16_SB_MAXK; default 0 = off until measured faster): the 64x256 tile with ONE staging buffer,
+    // three workgroups per CU
+    const char* sbe = getenv("ST2_CONV16_SB_MAXK");          // read per launch: the tests compare both pipelines
+    const int sb_maxk = sbe && *sbe ? atoi(sbe) : 0;
+    const bool sb = p.K <= sb_maxk && (cfg == 3 || cfg == 0);
+    if (sb) cfg = 0;
     const int BM = cfg == 1 ? 128 : 64, ROWS = cfg == 0 ? 8 : cfg == 3 ? 16 : 4;
     Conv16KArgs k{};
     k.in16 = p.in16; k.wpack = p.wpack16; k.bias = p.bias; k.out = p.out; k.out16 = p.out16;
@@ -506,7 +549,8 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     k.in_bytes = (unsigned)in_bytes; k.w_bytes = (unsigned)w_bytes;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (cfg == 3) conv3x3_mfma_bf16_64x512<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    if (cfg == 0 && sb) conv3x3_mfma_bf16_64x256_sb<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    else if (cfg == 3) conv3x3_mfma_bf16_64x512<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else if (cfg == 0) conv3x3_mfma_bf16_64x256<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else if (cfg == 1) conv3x3_mfma_bf16_128x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else conv3x3_mfma_bf16_64x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);

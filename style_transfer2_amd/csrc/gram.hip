@@ -329,13 +329,15 @@ __global__ __launch_bounds__(256) void gram_fold_k(const float* __restrict__ sla
 // Both stages in one launch for many splits: 16 lanes share an element, lane j sums splits j, j + 16, ... (16 loads in flight
 // per lane pair of rounds), the 16 partial sums meet in LDS and are added in lane order -- a fixed order again, and a tenth of
 // the launches' latency (two ~10 us kernels per style layer become one).
-constexpr int GR_LANES = 8, GR_QUADS = 256 / GR_LANES, GR_ELEMS = 4 * GR_QUADS;
+template <int GR_LANES>
 __global__ __launch_bounds__(256) void gram_reduce_wide_k(const float* __restrict__ slabs, const float* __restrict__ target,
                                                           float* __restrict__ out, float* __restrict__ partial,
                                                           int cc, int splits, float n, int C, int out_ld, int bt)
 {
-    // one thread = four consecutive elements of a row (C % 4 == 0: same row, same tile), 32 threads = 512 contiguous bytes of
-    // one slab per load instruction; GR_LANES such rows of threads take the splits round-robin
+    // one thread = four consecutive elements of a row (C % 4 == 0: same row, same tile), a row of threads = contiguous bytes of
+    // one slab per load instruction; GR_LANES such rows of threads take the splits round-robin (8 rows of 32 threads for the
+    // large matrices; 32 rows of 8 for C <= 128, whose few elements would otherwise leave most of the chip idle)
+    constexpr int GR_QUADS = 256 / GR_LANES, GR_ELEMS = 4 * GR_QUADS;
     __shared__ float4 part_s[GR_LANES][GR_QUADS];
     __shared__ float scratch[4];
     const int q = threadIdx.x % GR_QUADS, ln = threadIdx.x / GR_QUADS;
@@ -382,9 +384,11 @@ hipError_t launch_gram_reduce(const float* slabs, float* folded, const float* ta
     // ST2_GRAM_REDUCE=2 keeps the two-stage reduction (read per launch)
     const char* two = getenv("ST2_GRAM_REDUCE");
     if (splits > 32 && C % 4 == 0 && pl.bt % 4 == 0 && !(two && *two == '2')) {
-        const int grid = reduce_grid((size_t)cc, GR_ELEMS, kMaxPartials);
+        const bool small = cc <= 128 * 128;
+        const int grid = reduce_grid((size_t)cc, small ? 32 : 128, kMaxPartials);
         if (n_partial) *n_partial = grid;
-        gram_reduce_wide_k<<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)divisor, C, out_ld, pl.bt);
+        if (small) gram_reduce_wide_k<32><<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)divisor, C, out_ld, pl.bt);
+        else gram_reduce_wide_k<8><<<grid, 256, 0, s>>>(slabs, target, out, partial, cc, splits, (float)divisor, C, out_ld, pl.bt);
         return hipGetLastError();
     }
     const int groups = gram_fold_groups(pl);

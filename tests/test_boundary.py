@@ -206,11 +206,20 @@ def test_worker_pipelined_iterations_keep_the_wire_and_the_message_order(async_i
     assert not worker_mod.Worker({}, sock_in=FakeSockets([]), sock_out=FakeSockets([]), transfer=FakeTransfer()).pipelined
 
 
-def test_worker_over_real_pyzmq_sockets_loopback():
-    """The transport the reference uses (worker.py:321-324: PULL bind / PUSH connect, send_pyobj / recv_pyobj) with the sender
-    thread on: WorkerReady -> Iterates in order -> Shutdown last.  pyzmq is not in the build image: skipped there, runs wherever
-    it is installed."""
-    zmq = pytest.importorskip('zmq')
+def zmq_module(monkeypatch):
+    """pyzmq where it is installed; otherwise tests/minizmq.py (ZMTP 3.0 PUSH / PULL on real TCP sockets) stands in as `zmq`."""
+    try:
+        import zmq
+        return zmq, 'pyzmq'
+    except ImportError:
+        import minizmq
+        monkeypatch.setitem(sys.modules, 'zmq', minizmq)
+        return minizmq, 'minizmq (ZMTP 3.0 over TCP; pyzmq is not installed)'
+
+
+def run_worker_over_tcp(zmq, transfer_obj, n_iterates, extra_config=None):
+    """The reference's deployment (worker.py:321-324): the worker creates its own PULL (bind) / PUSH (connect) sockets from the config;
+    an "app" on the other side of two TCP connections sends SetImages + StartIteration, collects, then sends Shutdown."""
     import threading
     ctx = zmq.Context()
     app_in = ctx.socket(zmq.PULL)
@@ -219,8 +228,9 @@ def test_worker_over_real_pyzmq_sockets_loopback():
     port_worker = probe.bind_to_random_port('tcp://127.0.0.1')
     probe.close(0)
     config = {'worker_socket': 'tcp://127.0.0.1:%d' % port_worker, 'app_socket': 'tcp://127.0.0.1:%d' % port_app, 'async_iterate': '1'}
+    config.update(extra_config or {})
     img = np.zeros((4, 4, 3), np.uint8)
-    wk = worker_mod.Worker(config, transfer=FakePipelinedTransfer(4))
+    wk = worker_mod.Worker(config, transfer=transfer_obj)
     t = threading.Thread(target=wk.run, daemon=True)
     t.start()
     app_out = ctx.socket(zmq.PUSH)
@@ -230,7 +240,7 @@ def test_worker_over_real_pyzmq_sockets_loopback():
     got = []
     poller = zmq.Poller()
     poller.register(app_in, zmq.POLLIN)
-    while len(got) < 5 and poller.poll(10000):
+    while len(got) < 1 + n_iterates and poller.poll(10000):
         got.append(app_in.recv_pyobj())
     app_out.send_pyobj(messages.Shutdown())
     while poller.poll(10000):
@@ -240,9 +250,54 @@ def test_worker_over_real_pyzmq_sockets_loopback():
     t.join(20)
     wk.close()
     app_out.close(0); app_in.close(0); ctx.destroy(0)
+    return wk, got
+
+
+def test_worker_over_its_own_tcp_sockets_loopback(monkeypatch):
+    """The transport the reference uses (worker.py:321-324: PULL bind / PUSH connect, send_pyobj / recv_pyobj) with the sender
+    thread on: WorkerReady -> Iterates in order -> Shutdown last, over real TCP connections.  With pyzmq where it exists; in this
+    image through tests/minizmq.py, which frames the same pickles per ZMTP 3.0."""
+    zmq, which = zmq_module(monkeypatch)
+    wk, got = run_worker_over_tcp(zmq, FakePipelinedTransfer(4), 4)
+    print('[transport] worker loopback ran over', which)
     kinds = [type(m).__name__ for m in got]
     assert kinds == ['WorkerReady'] + ['Iterate'] * 4 + ['Shutdown']
     assert [m.i for m in got[1:5]] == [1, 2, 3, 4]
+    assert not wk.zero_copy                                  # this backend offers no frames: owned copies through send_pyobj
+
+
+def test_minizmq_frames_follow_zmtp_3(monkeypatch):
+    """What tests/minizmq.py puts on the wire, read back byte by byte: 64-byte greeting (signature, version 3.0, NULL mechanism),
+    a READY command naming the socket type, then one frame per message -- short (1-byte size) or long (flag 0x02, 8-byte size)."""
+    import socket as socket_mod
+    import minizmq
+    srv = socket_mod.socket()
+    srv.bind(('127.0.0.1', 0))
+    srv.listen(1)
+    ctx = minizmq.Context()
+    push = ctx.socket(minizmq.PUSH)
+    push.connect('tcp://127.0.0.1:%d' % srv.getsockname()[1])
+    import threading
+    big = bytes(range(256)) * 5
+    th = threading.Thread(target=lambda: (push.send(b'abc'), push.send(big, copy=False, track=True).wait()), daemon=True)
+    th.start()
+    conn, _ = srv.accept()
+    conn.sendall(minizmq._greeting() + minizmq._ready(minizmq.PULL))
+
+    def exact(n):
+        out = b''
+        while len(out) < n:
+            out += conn.recv(n - len(out))
+        return out
+    g = exact(64)
+    assert g[0] == 0xff and g[9] == 0x7f and g[10:12] == b'\x03\x00' and g[12:16] == b'NULL' and not any(g[16:32]) and g[32] == 0
+    flags, size = exact(2)
+    ready = exact(size)
+    assert flags == 0x04 and ready.startswith(b'\x05READY\x0bSocket-Type\x00\x00\x00\x04PUSH')
+    assert exact(2) == b'\x00\x03' and exact(3) == b'abc'                            # short frame
+    assert exact(1) == b'\x02' and int.from_bytes(exact(8), 'big') == len(big) and exact(len(big)) == big     # long frame
+    th.join(5)
+    conn.close(); srv.close(); ctx.destroy(0)
 
 
 def test_worker_asks_for_images_when_it_cannot_start_and_survives_garbage():

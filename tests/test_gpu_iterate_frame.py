@@ -135,3 +135,56 @@ def test_views_handed_out_before_a_reallocation_keep_their_bytes():
         assert got.i == index and np.array_equal(got.image, image) and got.trace['loss'] == trace['loss']
     for view, copy in held[-1:]:
         assert np.array_equal(view, copy)
+
+
+def test_worker_on_its_own_tcp_sockets_with_zero_copy_iterates(monkeypatch):
+    """The deployment path end to end: Worker(config) creates its own PULL / PUSH sockets (reference worker.py:321-324), the engine
+    copies every iterate into its pickle frame in pinned memory, the sender thread hands the frames to the transport with
+    send(copy=False, track=True); an "app" across two TCP connections unpickles them with recv_pyobj.  pyzmq where it is installed,
+    otherwise tests/minizmq.py (the same pickles framed per ZMTP 3.0).  The iterates are those of a synchronous run, bit for bit."""
+    from test_boundary import zmq_module
+    zmq, which = zmq_module(monkeypatch)
+    print('[transport] GPU worker ran over', which)
+    content, style, init = _inputs()
+    ctx = zmq.Context()
+    app_in = ctx.socket(zmq.PULL)
+    port_app = app_in.bind_to_random_port('tcp://127.0.0.1')
+    probe = ctx.socket(zmq.PULL)
+    port_worker = probe.bind_to_random_port('tcp://127.0.0.1')
+    probe.close(0)
+    config = {'worker_socket': 'tcp://127.0.0.1:%d' % port_worker, 'app_socket': 'tcp://127.0.0.1:%d' % port_app}
+    wk = worker_mod.Worker(config, transfer=st2.StyleTransfer(_model()))
+    assert wk.pipelined and wk.zero_copy and isinstance(wk.sock_out, worker_mod.AsyncSender)
+    th = threading.Thread(target=wk.run, daemon=True)
+    th.start()
+    app_out = ctx.socket(zmq.PUSH)
+    app_out.connect(config['worker_socket'])
+    for m in (messages.SetImages(None, init, content, style, True), messages.SetWeights(WEIGHTS, PARAMS),
+              messages.SetOptimizer('adam', 10), messages.StartIteration()):
+        app_out.send_pyobj(m)
+    got = []
+    poller = zmq.Poller()
+    poller.register(app_in, zmq.POLLIN)
+    while sum(isinstance(m, messages.Iterate) for m in got) < 8 and poller.poll(20000):
+        got.append(app_in.recv_pyobj())
+    app_out.send_pyobj(messages.Shutdown())
+    while poller.poll(20000):
+        got.append(app_in.recv_pyobj())
+        if isinstance(got[-1], messages.Shutdown):
+            break
+    th.join(30)
+    wk.close()
+    app_out.close(0); app_in.close(0); ctx.destroy(0)
+    kinds = [type(m).__name__ for m in got]
+    its = [m for m in got if isinstance(m, messages.Iterate)]
+    n = len(its)
+    assert n >= 8 and kinds == ['WorkerReady'] + ['Iterate'] * n + ['Shutdown']
+    assert [m.i for m in its] == list(range(1, n + 1))
+    ref = st2.StyleTransfer(_model())
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(WEIGHTS, PARAMS)
+    ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
+    assert ref.start()
+    for m in its:
+        img, tr = ref.step()
+        assert m.image.dtype == F32 and np.array_equal(m.image, img) and m.trace['loss'] == tr['loss'], m.i

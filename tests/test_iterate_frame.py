@@ -12,7 +12,7 @@ import messages
 import worker as worker_mod
 from style_transfer2_amd import iterate_frame
 from helpers import load_json
-from test_boundary import FakePipelinedTransfer, FakeSockets
+from test_boundary import FakePipelinedTransfer, FakeSockets, run_worker_over_tcp, zmq_module
 
 F32 = np.float32
 
@@ -147,3 +147,19 @@ def test_injected_sockets_get_owned_copies_by_default():
     wk.run()
     assert socks.raw_sends == 0
     assert [type(m).__name__ for m in socks.sent] == ['WorkerReady'] + ['Iterate'] * 3 + ['Shutdown']
+
+
+def test_zero_copy_frames_over_the_workers_own_tcp_sockets(monkeypatch):
+    """The worker's default on sockets it created itself: every Iterate leaves as `send(frame, copy=False, track=True)` -- here over
+    real TCP connections (pyzmq where installed, tests/minizmq.py's ZMTP 3.0 framing otherwise) and is unpickled by the app side's
+    plain recv_pyobj."""
+    zmq, which = zmq_module(monkeypatch)
+    tr = FakeFramedTransfer(6)
+    wk, got = run_worker_over_tcp(zmq, tr, 6)
+    print('[transport] zero-copy iterates ran over', which)
+    assert wk.zero_copy and tr.frames_on                                    # auto: the worker owns these sockets
+    kinds = [type(m).__name__ for m in got]
+    assert kinds == ['WorkerReady'] + ['Iterate'] * 6 + ['Shutdown']
+    its = got[1:7]
+    assert [m.i for m in its] == [1, 2, 3, 4, 5, 6] and [float(m.image[0, 0, 0]) for m in its] == [1, 2, 3, 4, 5, 6]
+    assert all(m.image.dtype == F32 and m.image.shape == (2, 2, 3) and type(m.trace) is OrderedDict for m in its)
