@@ -40,7 +40,14 @@ torch = _LazyTorch()
 
 class HipTileBackend:
     def __init__(self, net_params, grid, rank, content, style, init, weights, params, step_size=10,
-                 topology=None, device=0, precision='fp32'):
+                 topology=None, device=0, precision='fp32', use_torch=True):
+        # torch bundles its own copy of the HIP runtime; when both live in one process torch's must come up FIRST.
+        # The phase-by-phase driver and the host-staged test transport need torch; the in-engine iteration over RCCL
+        # (comm_init_rccl + tiled.FusedTiledTransfer) does not: pass use_torch=False and the process never loads it.
+        if use_torch:
+            import torch as _torch
+            if _torch.cuda.is_available():
+                _torch.cuda.init()
         # precision='bf16': the convs of the window run on the bf16 matrix cores (fp32 accumulation); the Gram / style / loss kernels of
         # the tile phases stay fp32 on the fp32 blobs (the region-of-interest forms exist for those only), i.e. the 'bf16-full' data flow
         self.engine = Engine(topology, device, 'bf16-full' if precision == 'bf16' else precision)
@@ -123,6 +130,12 @@ class HipTileBackend:
                 traceback.print_exc()
                 return 1
         self._callbacks = (capi.ALLREDUCE_FN(allreduce), capi.EXCHANGE_FN(exchange))       # keep the thunks alive
+        check(self.lib.st_comm_callbacks(self.ctx, int(rank), int(world), self._callbacks[0], self._callbacks[1], None))
+
+    def comm_init_solo(self, rank, world):
+        """ONE rank of a larger grid alone on a GPU (timing the per-rank compute of a multi-GPU run): the all-reduces see one rank,
+        what the neighbours would send never arrives (the receive buffers keep whatever they held)."""
+        self._callbacks = (capi.ALLREDUCE_FN(lambda user, ptr, n: 0), capi.EXCHANGE_FN(lambda *a: 0))
         check(self.lib.st_comm_callbacks(self.ctx, int(rank), int(world), self._callbacks[0], self._callbacks[1], None))
 
     def set_plan(self, phase, peers):

@@ -17,10 +17,6 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import style_transfer2_amd as st2                                    # noqa: E402
-from style_transfer2_amd import tiled, tiling, weights as st2_weights   # noqa: E402
-from style_transfer2_amd.tile_backend import HipTileBackend             # noqa: E402
-
 ap = argparse.ArgumentParser()
 ap.add_argument('--size', default='8192', help='N or HxW of the whole image')
 ap.add_argument('--style-size', type=int, default=1024)
@@ -35,6 +31,10 @@ ap.add_argument('--solo-rank', type=int, default=-1,
                      '= an interior column (window 4176 x 2208)')
 ap.add_argument('--precision', default='fp32', choices=('fp32', 'bf16'), help='bf16: conv operands bf16, everything else fp32')
 args = ap.parse_args()
+# native libraries (RCCL prints its version banner, gloo, the HIP runtime) write to fd 1 at will: keep the real stdout for the ONE JSON line
+sys.stdout.flush()
+json_out = os.fdopen(os.dup(1), 'w')
+os.dup2(2, 1)
 rows, cols = (int(v) for v in args.grid.split('x'))
 gH, gW = (int(v) for v in args.size.split('x')) if 'x' in args.size else (int(args.size), int(args.size))
 rank, local, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
@@ -44,12 +44,16 @@ if solo:
     assert world == 1 and args.solo_rank < rows * cols
     rank = args.solo_rank
 dist = None
-use_engine = args.driver == 'engine' and args.optimizer == 'adam' and not solo
+use_engine = args.driver == 'engine' and args.optimizer == 'adam'
 if world > 1 and not use_engine:
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(local)
     dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+import style_transfer2_amd as st2                                    # noqa: E402  (after torch, when torch is used at all)
+from style_transfer2_amd import tiled, tiling, weights as st2_weights   # noqa: E402
+from style_transfer2_amd.tile_backend import HipTileBackend             # noqa: E402
 
 WEIGHTS = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
            'deepdream': {}}
@@ -83,7 +87,8 @@ class WindowView:
 
 style = np.random.RandomState(2).randint(0, 256, (args.style_size, args.style_size, 3)).astype(np.uint8)
 backend = HipTileBackend(st2_weights.he_normal(topo, seed=0), grid, rank, WindowView(window_image(1)), style,
-                         WindowView(window_image(3)), WEIGHTS, PARAMS, step_size=10, device=local, precision=args.precision)
+                         WindowView(window_image(3)), WEIGHTS, PARAMS, step_size=10, device=local, precision=args.precision,
+                         use_torch=not use_engine)
 
 
 class SoloComm(tiled.Comm):
@@ -101,9 +106,12 @@ if use_engine:
         uid = ctypes.create_string_buffer(capi.COMM_ID_BYTES)
         capi.check(backend.lib.st_comm_unique_id(uid))
         return uid.raw
-    backend.comm_init_rccl(tiled.rendezvous_unique_id(rank, world, make_id), rank, world)
+    if solo:
+        backend.comm_init_solo(rank, rows * cols)
+    else:
+        backend.comm_init_rccl(tiled.rendezvous_unique_id(rank, world, make_id), rank, world)
     tt = tiled.FusedTiledTransfer(grid, rank, backend)
-    barrier = backend.barrier
+    barrier = (lambda: None) if solo else backend.barrier
 else:
     tt = tiled.TiledTransfer(grid, rank, backend, SoloComm() if solo else tiled.Comm(dist, rank, world), optimizer=args.optimizer,
                              step_size={'adam': 10, 'lbfgs': 1}[args.optimizer])
@@ -119,13 +127,14 @@ backend.engine.sync()
 barrier()
 dt = time.perf_counter() - t0
 if rank == 0 or solo:
-    print(json.dumps({'metric': 'tile-sharded style-transfer iters/sec @%sx%s VGG19' % (gH, gW), 'value': args.steps / dt,
+    json_out.write(json.dumps({'metric': 'tile-sharded style-transfer iters/sec @%sx%s VGG19' % (gH, gW), 'value': args.steps / dt,
                       'unit': 'it/s', 'n_gpus': world, 'grid': args.grid, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
                       'higher_is_better': True, 'vs_baseline': None,
                       'config': {'workload': 'configs[4]: ONE %dx%d image tile-sharded %s (apron design, RCCL all-reduces + strip exchange), %s %s' % (gH, gW, args.grid, args.optimizer, args.precision),
                                  'measured_on_hardware': 'by the driver only; the builder has one GPU'},
                       'driver': 'engine (st_tile_step, RCCL inside the engine)' if use_engine else 'phases (torch.distributed between the st_tile_* phases)',
                       'solo_rank': (args.solo_rank if solo else None), 'apron_px': grid.apron, 'window': [win.y1 - win.y0, win.x1 - win.x0], 'loss': float(vals[-2]),
-                      'dtype': 'f32' if args.precision == 'fp32' else 'bf16 conv operands, f32 accumulate/Gram/optimizer', 'scaling': 'strong', 'data': 'synthetic'}))
+                      'dtype': 'f32' if args.precision == 'fp32' else 'bf16 conv operands, f32 accumulate/Gram/optimizer', 'scaling': 'strong', 'data': 'synthetic'}) + '\n')
+    json_out.flush()
 if dist is not None:
     dist.destroy_process_group()
