@@ -87,6 +87,9 @@ struct WinoKArgs {
     float* pool_out; int pool_h, pool_w;   // optional fused 2x2/2 max-pool of the (post-ReLU) output: [M][pool_h][pool_w]
     unsigned char* pool_amap;              // optional, with pool_out: [M][pool_h][pool_w] bytes, bits 0-1 = slot of the FIRST maximum
                                            // (row-major in the window), bit 2 = maximum > 0 after bias: all the pool backward needs
+    // optional (data-gradient launches below a pool, UNPOOL builds): `in` is the POOLED diff [K][ph][pw] and `unpool_amap` the arg-max map
+    // of that pool ([K][ph][pw] bytes: slot | positive << 2); the input transform expands them (conv_wino_can_unpool)
+    const unsigned char* unpool_amap; unsigned amap_bytes; int ph, pw;
     int splits; float* scratch;   // split-K (few workgroups, deep K): split s accumulates chunks [s, s+1) * nch / splits into scratch[s]
     unsigned long long* stamps;   // DIAG builds only: per block {shader cycles, 100 MHz ticks} of the main loop
 };
@@ -125,9 +128,16 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 //                MFMAs).  For layers whose K loop is short (conv1_2: 8 chunks) the epilogue of the one-wave-per-SIMD kernels
 //                is ~40 % of a workgroup's time and nothing overlaps it.  Epilogue exchange as W8 (partner = wave ^ 2), the
 //                exchange buffer is the dead V images.
-template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false, bool H4 = false>
+// UNPOOL = true (QUAD, one tile group; data-gradient launches directly below a max-pool): the launch reads the POOLED diff and the
+//                pool's one-byte arg-max map instead of the full-resolution diff the pool backward would have written: per chunk
+//                8 channels x 4 pooled rows x 24 columns of floats and of bytes are staged (3 + 0.75 KiB instead of 7.5), and the input
+//                transform of a 4x4 tile reads its 3x3 pooling windows: d[i][j] = (slot of window == position of (i, j) in it, and the
+//                maximum was positive) ? pooled diff : 0 -- exactly the values maxpool_bwd_amap_k stores, so the result is the same bit
+//                for bit, and that kernel, its 4x larger output and this launch's read of it are gone.
+template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false, bool H4 = false, bool UNPOOL = false>
 __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
+    static_assert(!UNPOOL || (QUAD && TG == 1 && !PS && !W8), "unpool: aligned widths, one tile group, four waves");
     static_assert(H4 || (WM * TG == 4 && (TG == 1 || TG == 2)), "4 waves");
     static_assert(!PS || (WM == 2 && TG == 2), "position split: 2 channel slices x 2 position halves");
     static_assert(!W8 || (WM == 4 && TG == 1 && QUAD && !PS), "eight waves: 4 channel slices x 2 position halves, aligned widths");
@@ -143,9 +153,15 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     constexpr int IW = QUAD ? WN_IW : 64;                // floats per staged row
     constexpr int COL0 = QUAD ? 3 : 0;                   // staged column of pixel x0 - 1
     constexpr int PLANE = IN_ROWS * IW;
-    constexpr int N_RAW = WN_CH * PLANE;                 // floats staged per chunk
-    constexpr int I_PER_WAVE = QUAD ? (N_RAW / 4 + 64 * NW - 1) / (64 * NW) : WN_CH * IN_ROWS / 4;   // wave-DMAs per wave (64 quads / 64 dwords each)
-    constexpr int RAW = QUAD ? I_PER_WAVE * NW * 256 : N_RAW;                          // floats per raw buffer
+    constexpr int UP_ROWS = PROWS / 2 + 2, UP_COLS = 24;  // UNPOOL: staged pooled rows y0/2 - 1 .., columns x0/2 - 4 .. x0/2 + 19
+    constexpr int UP_PLANE = UP_ROWS * UP_COLS;          // per channel: floats of the pooled diff = bytes of the arg-max map
+    constexpr int UP_F = WN_CH * UP_PLANE;               // 768 floats, then the same geometry in bytes
+    constexpr int UP_FQ = UP_F / 256, UP_AQ = UP_F / 256; // wave-DMAs: 16-byte pieces of floats, 4-byte pieces of map bytes (64 lanes each)
+    static_assert(!UNPOOL || (UP_F % 256 == 0 && NW == 4), "unpool staging is a whole number of wave-DMAs");
+    constexpr int N_RAW = UNPOOL ? UP_F + UP_F / 4 : WN_CH * PLANE;                 // floats staged per chunk
+    constexpr int I_PER_WAVE = UNPOOL ? (UP_FQ + UP_AQ + NW - 1) / NW
+                             : QUAD ? (N_RAW / 4 + 64 * NW - 1) / (64 * NW) : WN_CH * IN_ROWS / 4;   // wave-DMAs per wave (64 quads / 64 dwords each)
+    constexpr int RAW = UNPOOL ? 1024 : QUAD ? I_PER_WAVE * NW * 256 : N_RAW;          // floats per raw buffer
     static_assert(QUAD || (WN_CH * IN_ROWS) % 4 == 0, "rows divide over the four waves");
 
     __shared__ __attribute__((aligned(16))) float raw_s[2][RAW];
@@ -180,8 +196,26 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     const unsigned long long t_begin = DIAG ? __builtin_amdgcn_s_memtime() : 0ull;
 
     const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(UNPOOL ? a.unpool_amap : nullptr), 0, UNPOOL ? a.amap_bytes : 0u, 0x00020000);
+    const unsigned pplane = UNPOOL ? (unsigned)a.ph * a.pw : 0u;
     unsigned ioff[QUAD ? I_PER_WAVE : 1];
-    if (QUAD) {
+    if (UNPOOL) {
+        // pieces 0 .. UP_FQ - 1: quads of pooled floats; pieces UP_FQ .. UP_FQ + UP_AQ - 1: dwords of map bytes -- the same
+        // (channel, row, column) geometry, 4 columns per lane either way
+#pragma unroll
+        for (int t = 0; t < I_PER_WAVE; ++t) {
+            const int piece = wave + NW * t;
+            const bool bytes = piece >= UP_FQ;
+            const int e = ((bytes ? piece - UP_FQ : piece) * 64 + lane) * 4;          // element (float / byte) index in the staged image
+            const int c = e / UP_PLANE;
+            const int rem = e - c * UP_PLANE;
+            const int rr = rem / UP_COLS;
+            const int col = rem - rr * UP_COLS;
+            const int gy = (y0 >> 1) - 1 + rr, gx = (x0 >> 1) - 4 + col;
+            const bool ok = piece < UP_FQ + UP_AQ && gy >= 0 && gy < a.ph && gx >= 0 && gx + 3 < a.pw;
+            ioff[t] = ok ? ((unsigned)(c_first * WN_CH + c) * pplane + (unsigned)gy * a.pw + gx) * (bytes ? 1u : 4u) : kOOB;
+        }
+    } else if (QUAD) {
 #pragma unroll
         for (int t = 0; t < I_PER_WAVE; ++t) {
             const int e = ((wave + NW * t) * 64 + lane) * 4;
@@ -198,7 +232,19 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
         ioff[0] = (lane < 34 && gx >= 0 && gx < a.W) ? (unsigned)gx * 4u : kOOB;
     }
     auto dma_raw = [&](int ch, int buf) {
-        if (QUAD) {
+        if (UNPOOL) {
+#pragma unroll
+            for (int t = 0; t < I_PER_WAVE; ++t) {
+                const int piece = wave + NW * t;                           // wave-uniform
+                if (piece < UP_FQ) {
+                    const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + (unsigned)ch * WN_CH * pplane * 4u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s[buf] + piece * 256), 16, vo, 0, 0, 0);
+                } else if (piece < UP_FQ + UP_AQ) {
+                    const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + (unsigned)ch * WN_CH * pplane;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(raw_s[buf] + UP_F + (piece - UP_FQ) * 64), 4, vo, 0, 0, 0);
+                }
+            }
+        } else if (QUAD) {
             const unsigned coff = (unsigned)ch * WN_CH * plane * 4u;
 #pragma unroll
             for (int t = 0; t < I_PER_WAVE; ++t) {
@@ -222,7 +268,9 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     // V image of one (chunk, tile group): [k-pair 4][pos/4][k parity * 32 + tile][pos%4] -- the B operands of four
     // positions are one ds_read_b128, a transformed row is one ds_write_b128.
     const int xt = tid & 31, xch = (tid >> 5) & 7;       // W8: both position halves map onto the same 256 pairs; one of them works per chunk
-    const int x_raw = xch * PLANE + (2 * (xt >> 4)) * IW + 2 * (xt & 15) + COL0;          // column COL0 = pixel x0 - 1
+    // UNPOOL: first of the tile's 3x3 pooling windows: staged row xt >> 4 (= pooled row y0/2 - 1 + ...), staged column (xt & 15) + 3
+    const int x_raw = UNPOOL ? xch * UP_PLANE + (xt >> 4) * UP_COLS + (xt & 15) + 3
+                             : xch * PLANE + (2 * (xt >> 4)) * IW + 2 * (xt & 15) + COL0;          // column COL0 = pixel x0 - 1
     const int x_v = (((xch >> 1) * 4) * 64 + (xch & 1) * 32 + xt) * 4;
     float d[TG][16];
     // Empty asm with the 16 values as in/out operands: arithmetic on them cannot be scheduled across it, which is
@@ -234,7 +282,34 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
             asm volatile("" : "+v"(d[g][8]), "+v"(d[g][9]), "+v"(d[g][10]), "+v"(d[g][11]), "+v"(d[g][12]), "+v"(d[g][13]), "+v"(d[g][14]), "+v"(d[g][15]));
         }
     };
+    float up_v[UNPOOL ? 9 : 1];
+    unsigned up_m[UNPOOL ? 9 : 1];
+    // UNPOOL: window (r, c) of the 3x3 covers tile rows {0}, {1, 2}, {3} for r = 0, 1, 2 (the row's parity inside the window is 1, 0,
+    // 1, 0) and the same along x; an element keeps the pooled diff iff the map byte is 4 | 2 * parity_y + parity_x
+    auto up_expand = [&]() {
+        if constexpr (UNPOOL) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = (i + 1) >> 1, cc = (j + 1) >> 1;
+                    const unsigned want = 4u | (2u * ((i + 1) & 1)) | ((j + 1) & 1);
+                    d[0][4 * i + j] = up_m[3 * r + cc] == want ? up_v[3 * r + cc] : 0.f;
+                }
+        }
+    };
     auto xf_read = [&](const float* rp) {
+        if constexpr (UNPOOL) {
+            const unsigned char* bp = reinterpret_cast<const unsigned char*>(rp - x_raw + UP_F) + x_raw;      // same geometry, in bytes
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    up_v[3 * r + cc] = rp[r * UP_COLS + cc];
+                    up_m[3 * r + cc] = bp[r * UP_COLS + cc];
+                }
+            return;
+        }
 #pragma unroll
         for (int g = 0; g < TG; ++g)
 #pragma unroll
@@ -309,6 +384,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
     __syncthreads();
     if (!W8 || ph == 0) {
         xf_read(raw_s[0] + x_raw);
+        up_expand();
         xf_math();
         xf_write(&v_s[0][0][0] + x_v);
     }
@@ -351,7 +427,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
                     if (MORE || kpl == 0) u_fill(kp + 3);
                     if (MORE && do_xf) {
                         if (kpl == 0) xf_read(raw_s[cur ^ 1] + x_raw);
-                        if (kpl == 1) { pin(); xf_math(); pin(); }
+                        if (kpl == 1) { up_expand(); pin(); xf_math(); pin(); }
                         if (kpl == 2) xf_write(&v_s[cur ^ 1][0][0] + x_v);
                     }
                     if (MORE2 && kpl == 0) dma_raw(c + 2, cur);
@@ -618,6 +694,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_w8_128x128(const Wino
 __global__ __launch_bounds__(512, 2) void conv3x3_wino_f32_w8_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1, true, false, true>(a); }
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true>(a); }
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 1, 1, true, false, false, true>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_unpool(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, false, false, true>(a); }
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_unpool(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true, true>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1>(a); }
 
@@ -646,6 +724,7 @@ __global__ __launch_bounds__(256) void wino_combine_k(const float* __restrict__ 
 
 static int wino_default_variant(int M, int W);
 static bool wino_variant_small(int variant);
+bool conv_wino_ok(int K, int M, int H, int W);
 
 // Split-K factor for a launch that would leave most CUs idle (conv5_1 at 1024^2: 128 workgroups on 256 CUs)
 int conv_wino_splits(int K, int M, int H, int W)
@@ -678,6 +757,17 @@ bool conv_wino_pool_amap_ok(int K, int M, int H, int W)
     if (!conv_wino_can_pool(K, M, H, W) || W % 4 != 0 || H % 2 != 0) return false;
     const int v = wino_default_variant(M, W);
     return v == 0 || v == 6 || v == 8;
+}
+
+// may a data-gradient launch of this shape read the pooled diff + the arg-max map of the pool above its input (ConvProblem::unpool_amap)?
+// The 128-channel and the half-tile build have the variant; the staged pooled rows need W % 32 == 0 and H % 2 == 0.
+bool conv_wino_can_unpool(int K, int M, int H, int W)
+{
+    const char* e = getenv("ST2_WINO_UNPOOL");               // =0: keep maxpool_bwd_amap_k (read per launch: the tests compare both)
+    if ((e && *e == '0') || !conv_wino_ok(K, M, H, W) || W % 32 != 0 || H % 2 != 0) return false;
+    if (4ull * K * (H / 2) * (W / 2) >= 0xfffffff0ull) return false;
+    const int v = wino_default_variant(M, W);
+    return v == 0 || v == 8;
 }
 
 bool conv_wino_ok(int K, int M, int H, int W)
@@ -730,6 +820,13 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     k.K = p.K; k.M = p.M; k.H = p.H; k.W = p.W; k.nch = p.K / WN_CH;
     k.tiles_x = (p.W + 31) / 32; k.tiles_y = (p.H + prows - 1) / prows; k.n_mtiles = (p.M + bm - 1) / bm; k.relu = p.relu;
     k.in_bytes = (unsigned)(4ull * p.K * p.H * p.W);
+    const bool unpool = p.unpool_amap != nullptr;
+    if (unpool) {
+        if (!(variant == 0 || variant == 8) || !quad || p.W % 32 != 0 || p.H % 2 != 0 || p.pool_out) return hipErrorInvalidValue;
+        k.unpool_amap = p.unpool_amap; k.ph = p.H / 2; k.pw = p.W / 2;
+        k.in_bytes = (unsigned)(4ull * p.K * k.ph * k.pw);
+        k.amap_bytes = (unsigned)((unsigned long long)p.K * k.ph * k.pw);
+    }
     k.u_bytes = (unsigned)(4ull * wino_pack_floats(p.K, p.M));
     k.stamps = p.stamps;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
@@ -746,14 +843,15 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     if (k.splits > 1 && p.pool_out) return hipErrorInvalidValue;              // the caller asks conv_wino_can_pool() first
     const dim3 g((unsigned)(nblk * k.splits)), b(256);
     switch (variant) {
-    case 0: if (quad) conv3x3_wino_f32_128x128<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_128x128_anyw<<<g, b, 0, s>>>(k); break;
+    case 0: if (unpool) conv3x3_wino_f32_128x128_unpool<<<g, b, 0, s>>>(k);
+            else if (quad) conv3x3_wino_f32_128x128<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_128x128_anyw<<<g, b, 0, s>>>(k); break;
     case 1: if (quad) conv3x3_wino_f32_64x256<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_64x256_anyw<<<g, b, 0, s>>>(k); break;
     case 3: conv3x3_wino_f32_ps64x256<<<g, b, 0, s>>>(k); break;
     case 2: conv3x3_wino_f32_128x128_stamped<<<g, b, 0, s>>>(k); break;
     case 4: conv3x3_wino_f32_ps64x256_stamped<<<g, b, 0, s>>>(k); break;
     case 6: conv3x3_wino_f32_w8_128x128<<<g, dim3(512), 0, s>>>(k); break;
     case 7: conv3x3_wino_f32_w8_128x128_stamped<<<g, dim3(512), 0, s>>>(k); break;
-    case 8: conv3x3_wino_f32_h4_64x128<<<g, b, 0, s>>>(k); break;
+    case 8: if (unpool) conv3x3_wino_f32_h4_64x128_unpool<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128<<<g, b, 0, s>>>(k); break;
     case 9: conv3x3_wino_f32_h4_64x128_stamped<<<g, b, 0, s>>>(k); break;
     default: conv3x3_wino_f32_64x256_stamped<<<g, b, 0, s>>>(k); break;
     }

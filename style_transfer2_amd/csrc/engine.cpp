@@ -291,6 +291,7 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
     const ActSet& a = c->act;
     const float* cur = top_diff;
     const unsigned short* cur16 = nullptr;             // bf16 copy of the running diff, when a producer already made it
+    const unsigned char* pending_unpool = nullptr;     // arg-max map of the pool just passed: `cur` is still the POOLED diff (Winograd unpool)
     if (c->bf16 && !c->diff16A) {
         const size_t cap = c->max_blob + 8 * (size_t)a.h[0] * a.w[0];
         ST_TRY(dmalloc16(&c->diff16A, cap)); ST_TRY(dmalloc16(&c->diff16B, cap));
@@ -367,7 +368,10 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
                 p.in = cur; p.wpack = L.w_bwd; p.bias = nullptr; p.out = dst;
                 p.mask_src = mask_src; p.inject = inject;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
-                ProfScope ps(c, wino_bwd ? P_CONV_DGRAD_WINO : P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
+                if (pending_unpool && !wino_bwd) return fail(ST_ERR_STATE, "internal: an unpooling data gradient was planned for %s but the direct kernel runs", L.name.c_str());
+                p.unpool_amap = pending_unpool; pending_unpool = nullptr;
+                ProfScope ps(c, wino_bwd ? P_CONV_DGRAD_WINO : P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px,
+                             4.0 * px * (L.cin + (p.unpool_amap ? 0.3125 : 1.0) * L.cout));
                 if (wino_bwd) { p.wpack = L.u_bwd; ST_TRY(wino_scratch(c, p)); HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
                 else HIP_TRY(launch_conv3x3(p, c->stream));
                 cur = dst;
@@ -388,7 +392,16 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
             HIP_TRY(launch_maxpool_bwd_idx16(cur16, a.amap[i], dst16, C, a.h[below], a.w[below], c->stream));
             cur16 = dst16; cur = nullptr;
         } else if (a.amap_ok[i] == 2 && !inject && mask_src && cur) {
-            // pool fused into its producing Winograd conv (fp32): route the diff through the arg-max map, ReLU mask included
+            // pool fused into its producing Winograd conv (fp32): route the diff through the arg-max map, ReLU mask included ...
+            const Layer& P = c->topo[below - 1];             // the conv that produced the pooled-from blob: its data gradient runs next
+            const bool p_wino = !c->bf16 && c->wino && P.u_bwd && !(below - 1 < 1 && conv_dgrad_smallM_ok(P.cout, P.cin)) &&
+                                conv_wino_ok(P.cout, P.cin, a.h[below], a.w[below]);
+            if (p_wino && conv_wino_can_unpool(P.cout, P.cin, a.h[below], a.w[below])) {
+                // ... inside that data gradient: it stages the pooled diff and the map and unpools in its input transform
+                // (maxpool_bwd_amap_k, its full-resolution output and the conv's read of it are gone; same values bit for bit)
+                pending_unpool = a.amap[i];
+                continue;
+            }
             ProfScope ps(c, P_POOL_BWD, 0, (double)a.C[below] * ((double)a.h[i] * a.w[i] * 5.0 + (double)a.h[below] * a.w[below] * 4.0));
             HIP_TRY(launch_maxpool_bwd_amap(cur, a.amap[i], dst, a.C[below], a.h[below], a.w[below], c->stream));
             cur16 = nullptr; cur = dst;
@@ -401,6 +414,7 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
             cur16 = nullptr; cur = dst;
         }
     }
+    if (pending_unpool) return fail(ST_ERR_STATE, "internal: a pooled diff was left un-expanded");
     if (!cur) return fail(ST_ERR_STATE, "internal: the backward chain ended without an fp32 image gradient");
     *out = cur;
     return ST_OK;

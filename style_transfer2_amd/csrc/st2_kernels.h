@@ -32,6 +32,9 @@ struct ConvProblem {
     unsigned short* out16 = nullptr;        // optional (direct kernel): bf16 channel-blocked copy of `out`, [M/8][H][W][8], M % 8 == 0
     float* pool_out = nullptr;              // optional (Winograd forward, see conv_wino_can_pool): also write maxpool2x2/2 of `out`
     unsigned char* pool_amap = nullptr;     // optional, with pool_out: [M][ph][pw] bytes = first-max slot | (max > 0) << 2 (launch_maxpool_bwd_amap)
+    // optional (Winograd data-gradient directly below a max-pool, conv_wino_can_unpool): `in` is then the POOLED diff [K][H/2][W/2] and
+    // unpool_amap the pool's arg-max map [K][H/2][W/2] (ConvProblem::pool_amap of the forward); the launch unpools while it stages
+    const unsigned char* unpool_amap = nullptr;
     float* scratch = nullptr;               // optional: room for split-K partial sums (Winograd launches with few workgroups)
     size_t scratch_floats = 0;
 };
@@ -55,6 +58,7 @@ bool conv_wino_ok(int K, int M, int H, int W);
 // blob included (bit 2); H even, W % 4 == 0.  352 instead of 603 bytes moved per 64 outputs: neither the conv blob nor the pooled one is read.
 hipError_t launch_maxpool_bwd_amap(const float* dy, const unsigned char* amap, float* dx, int C, int H, int W, hipStream_t s);
 bool conv_wino_pool_amap_ok(int K, int M, int H, int W);   // ... and such a launch fills ConvProblem::pool_amap
+bool conv_wino_can_unpool(int K, int M, int H, int W);   // a data-gradient launch of this shape may take ConvProblem::unpool_amap
 bool conv_wino_can_pool(int K, int M, int H, int W);   // launch_conv3x3_wino may fuse the following max-pool (ConvProblem::pool_out)
 int conv_wino_splits(int K, int M, int H, int W);   // split-K factor the automatic path would use (1 = none); needs splits*M*H*W floats of scratch
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);

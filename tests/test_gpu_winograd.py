@@ -83,26 +83,39 @@ def test_winograd_chain_with_masks_and_injections(wino_cfg):
             assert err <= 3e-5, (names, h, w, err)
 
 
-@pytest.mark.parametrize('h,w', [(64, 96), (32, 40), (66, 100), (48, 64)])
+@pytest.mark.parametrize('h,w', [(64, 96), (32, 40), (66, 100), (48, 64), (64, 128), (70, 256), (8, 32)])
 def test_pool_backward_through_the_arg_max_map_is_the_classic_one_bit_for_bit(h, w, monkeypatch):
     """A pool fused into its producing Winograd conv (aligned widths, one-tile-group builds) also leaves a one-byte arg-max map
     (first maximum of the stored blob, positive-after-bias flag), and the pool's backward routes the diff through it instead of
-    re-reading the conv blob (maxpool_bwd_amap_k; ST2_POOL_AMAP=0 keeps maxpool_bwd_v4_k).  Same routing rule, so the image gradient
-    is identical -- through conv1_2 (half-tile build) and conv2_2 (128-channel build), with diffs injected above and between."""
+    re-reading the conv blob (maxpool_bwd_amap_k; ST2_POOL_AMAP=0 keeps maxpool_bwd_v4_k).  Where the width allows (W % 32 == 0) the
+    data-gradient conv below the pool goes one further: it stages the POOLED diff and the map and unpools in its input transform
+    (UNPOOL builds of the 128-channel and the half-tile kernel; ST2_WINO_UNPOOL=0 keeps the separate kernel).  Same routing rule and
+    the same values into the same arithmetic, so the image gradient is identical bit for bit in all three forms -- through conv1_2
+    (half-tile build) and conv2_2 (128-channel build), with diffs injected above and between."""
     topo = oracle.VGG19_TOPOLOGY[:7]                    # conv1_1 conv1_2 pool1 conv2_1 conv2_2 pool2 conv3_1
     params = oracle.he_init_weights(topo, seed=3, bias_std=0.3)
     rng = np.random.RandomState(h + w)
     x = (rng.randn(1, 3, h, w) * 40).astype(F32)
     out = {}
-    for flag in ('1', '0'):
-        monkeypatch.setenv('ST2_POOL_AMAP', flag)
+    for amap, unpool in (('1', '1'), ('1', '0'), ('0', '1')):
+        monkeypatch.setenv('ST2_POOL_AMAP', amap)
+        monkeypatch.setenv('ST2_WINO_UNPOOL', unpool)
         gpu = st2.HipModel(params, topology=topo)
         f = gpu.forward(x, ['pool1', 'conv2_1', 'pool2', 'conv3_1'])
         r2 = np.random.RandomState(7)
         diffs = {n: r2.randn(*f[n].shape).astype(F32) for n in ('conv3_1', 'conv2_1')}
-        out[flag] = (f, gpu.backward(diffs), gpu.backward({'pool2': r2.randn(*f['pool2'].shape).astype(F32)}))
-    for n in out['1'][0]:
-        assert np.array_equal(out['1'][0][n], out['0'][0][n]), n
-    assert np.array_equal(out['1'][1], out['0'][1])
-    assert np.array_equal(out['1'][2], out['0'][2])
-    assert float(np.abs(out['1'][1]).max()) > 0
+        out[amap + unpool] = (f, gpu.backward(diffs), gpu.backward({'pool2': r2.randn(*f['pool2'].shape).astype(F32)}))
+    for key in ('10', '01'):
+        for n in out['11'][0]:
+            assert np.array_equal(out['11'][0][n], out[key][0][n]), (key, n)
+        assert np.array_equal(out['11'][1], out[key][1]), key
+        assert np.array_equal(out['11'][2], out[key][2]), key
+    assert float(np.abs(out['11'][1]).max()) > 0
+    # ... and it is the oracle's gradient
+    cpu = oracle.NetOracle(topo, params)
+    cpu.forward(x, ['conv3_1'])
+    cpu.adopt_forward_state(out['11'][0])
+    cpu.adopt_forward_state(st2.HipModel(params, topology=topo).forward(x, ['conv1_1', 'conv1_2', 'conv2_2']))
+    r2 = np.random.RandomState(7)
+    diffs = {n: r2.randn(*out['11'][0][n].shape).astype(F32) for n in ('conv3_1', 'conv2_1')}
+    assert rel_l2(out['11'][1], cpu.backward(diffs)) <= 3e-5
