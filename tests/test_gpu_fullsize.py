@@ -376,7 +376,10 @@ def test_bf16_follows_the_fp32_loss_curve_at_size(size, optimizer, steps, stable
     report('bf16 vs fp32 engine, %d %s steps at %d' % (steps, optimizer, size),
            {'loss_fp32': [c[0] for c in curve], 'loss_bf16': [c[1] for c in curve], 'loss_rel': rel, 'compared_steps': stable,
             'image_mse_after_compared_steps': mse, 'fp32_moved_mse': moved})
-    assert curve[stable - 1][0] < curve[0][0] and curve[stable - 1][1] < curve[0][1]          # both descend
+    if optimizer == 'lbfgs':
+        assert curve[stable - 1][0] < curve[0][0] and curve[stable - 1][1] < curve[0][1]      # both descend
+    # (Adam at step size 10 does not: its first step throws the loss from 3.8e7 to 1.4e11 -- in the reference too, the oracle's
+    # three-step test above agrees with the engine to 7e-5 on exactly that curve)
     assert max(rel[:stable]) <= rtol, rel                                    # the two loss curves stay together while the iteration is stable
     if optimizer == 'lbfgs':
         assert mse <= 0.1 * moved + 0.05, (mse, moved)                        # the iterates differ by a small part of how far they moved
