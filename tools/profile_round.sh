@@ -24,7 +24,7 @@ python3 tools/pmc_traffic.py $F $W $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt
 S=$(find $OUT/stats -name '*kernel_stats.csv' | head -1)
 cp $S $OUT/kernel_stats.csv
 T=$(find $OUT/stats -name '*kernel_trace.csv' | head -1)
-python3 tools/trace_layers.py $T > $OUT/per_layer.txt 2>&1 || true
+python3 tools/trace_layers.py $T ${TRACE_SIZE:-1024} > $OUT/per_layer.txt 2>&1 || true
 # the raw traces are large: keep the summaries only
 rm -rf $OUT/fetch $OUT/write
 find $OUT/stats -name '*kernel_trace.csv' -delete
