@@ -73,7 +73,9 @@ int st_tile_forward(st_ctx* c, float** dev_ptr, int* n_floats)
     }
     ST_TRY(tile_ensure(&c->tile.p1, &c->tile.p1_n, std::max<size_t>(n1, 1)));
     HIP_TRY(hipMemsetAsync(c->tile.p1, 0, std::max<size_t>(n1, 1) * sizeof(float), c->stream));
-    ST_TRY(forward_range(c, a, c->x[c->cur], last));
+    // bf16 operands: the lean data flow here too -- an fp32 blob / diff is written only where something reads fp32 (the weighted
+    // blobs: the region-of-interest loss kernels are fp32), pools ride on their producing conv, the backward masks from the bf16 copies
+    ST_TRY(forward_range(c, a, c->x[c->cur], last, c->bf16 && c->lean));
     size_t pos = 0;
     for (const ActiveLayer& al : c->active) {
         const int b = al.blob, C = a.C[b];
@@ -245,7 +247,7 @@ int st_tile_backward(st_ctx* c, float** dev_grad)
     else {
         if (!c->diffA) { ST_TRY(dmalloc(&c->diffA, c->max_blob)); ST_TRY(dmalloc(&c->diffB, c->max_blob)); }
         const float* g = inj[0];
-        if (last > 0) ST_TRY(backward_chain(c, last, inj[last], inj, &g));
+        if (last > 0) ST_TRY(backward_chain(c, last, inj[last], inj, &g, c->bf16 && c->lean));
         HIP_TRY(hipMemcpyAsync(c->tile.wgrad, g, n3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     }
     if (!c->tile.fused) HIP_TRY(hipStreamSynchronize(c->stream));

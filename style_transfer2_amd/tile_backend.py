@@ -48,9 +48,10 @@ class HipTileBackend:
             import torch as _torch
             if _torch.cuda.is_available():
                 _torch.cuda.init()
-        # precision='bf16': the convs of the window run on the bf16 matrix cores (fp32 accumulation); the Gram / style / loss kernels of
-        # the tile phases stay fp32 on the fp32 blobs (the region-of-interest forms exist for those only), i.e. the 'bf16-full' data flow
-        self.engine = Engine(topology, device, 'bf16-full' if precision == 'bf16' else precision)
+        # precision='bf16': the convs of the window run on the bf16 matrix cores (fp32 accumulation) with the lean data flow (fp32 blobs /
+        # diffs only where something reads fp32); the Gram / style / loss kernels of the tile phases stay fp32 on the fp32 blobs of the
+        # weighted layers (the region-of-interest forms exist for those only).  'bf16-full' writes every fp32 tensor: same results.
+        self.engine = Engine(topology, device, precision)
         self.engine.load_weights(net_params)
         self.lib, self.ctx = self.engine.lib, self.engine._ctx
         self.device_index = device

@@ -491,6 +491,29 @@ def test_tiled_lbfgs_single_rank_equals_plain_engine(h, w):
         assert np.mean((tt.tile_image() - img) ** 2) <= (1e-4 if i < 3 else 0.1), i
 
 
+def test_tiled_bf16_lean_and_full_data_flows_are_bit_identical():
+    """The tile phases with bf16 conv operands run the lean data flow (fp32 blobs / diffs only where the fp32 region-of-interest loss
+    kernels read them, pools riding on their producing conv, ReLU masks from the bf16 copies); 'bf16-full' writes every fp32 tensor.
+    Same arithmetic: identical traces and iterates, through the in-engine step."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    h, w = 64, 96
+    content, style, init = _tiled_images(h, w)
+    topo = oracle.VGG19_TOPOLOGY[:7]
+    params = oracle.he_init_weights(topo, 0, 0.1)
+    weights = {'content': {'conv2_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1}, 'deepdream': {}}
+    grid = tiling.TileGrid(h, w, 1, 1, topo, 5)
+    runs = []
+    for precision in ('bf16', 'bf16-full'):
+        backend = HipTileBackend(params, grid, 0, content, style, init, weights, TILED_PARAMS, step_size=10, topology=topo, precision=precision)
+        backend.comm_init_solo(0, 1)
+        ft = tiled.FusedTiledTransfer(grid, 0, backend)
+        runs.append([(ft.step(), ft.tile_image()) for _ in range(3)])
+    for (va, ia), (vb, ib) in zip(*runs):
+        assert np.array_equal(va, vb) and np.array_equal(ia, ib)
+    assert np.isfinite(runs[0][-1][0]).all()
+
+
 def test_tiled_single_rank_with_bf16_convs_tracks_the_bf16_engine():
     """precision='bf16' in the tile backend: the window's convs on the bf16 matrix cores, Gram / style / loss kernels in their fp32
     region-of-interest forms.  Against the plain engine in its bf16 mode (whose Gram and style gradient read the bf16 copies instead):
