@@ -122,9 +122,13 @@ bool blob_active(const st_ctx* c, int b)
 // shapes only, so that the forward (which may then skip the fp32 blob) and the objective agree.
 bool style_runs16(const st_ctx* c, const ActSet& a, int b)
 {
-    if (!c->bf16 || c->tile.on || b < 1 || !c->topo[b - 1].is_conv) return false;
+    if (!c->bf16 || b < 1 || !c->topo[b - 1].is_conv) return false;
     const int C = a.C[b], hw = a.h[b] * a.w[b];
-    return conv16_ok(c, C) && style_grad16_ok(C, (size_t)hw) && C % 8 == 0 && hw % 64 == 0 && gram16_ok(C, hw, gram_plan16(C, hw));
+    if (!(conv16_ok(c, C) && style_grad16_ok(C, (size_t)hw) && C % 8 == 0)) return false;
+    // tile-sharded mode: the region-of-interest forms of both kernels take any region (ragged last step, 4-byte stores when the
+    // region's rows are not 16-byte aligned); ST2_TILE_STYLE16=0 keeps the fp32 region-of-interest kernels
+    if (c->tile.on) { const char* e = getenv("ST2_TILE_STYLE16"); return !(e && *e == '0'); }
+    return hw % 64 == 0 && gram16_ok(C, hw, gram_plan16(C, hw));
 }
 
 // lean evaluation: does anything read blob b in fp32?  Content / deep-dream terms do (layer_elem_k); a style term only when
@@ -162,7 +166,7 @@ int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
             bool next16 = c->bf16 && i < last && c->topo[i].is_conv && conv16_ok(c, L.cout);
             const bool conv_next16 = next16;
             // ... or does the style gradient of this blob (bf16 path: style16.hip reads the bf16 copy)?
-            if (c->bf16 && !c->tile.on && conv16_ok(c, L.cout) && style_grad16_ok(L.cout, (size_t)a.h[i] * a.w[i]))
+            if (c->bf16 && conv16_ok(c, L.cout) && style_grad16_ok(L.cout, (size_t)a.h[i] * a.w[i]))
                 for (const ActiveLayer& al : c->active) if (al.blob == i && al.s) next16 = true;
             if (next16 && !a.data16[i]) ST_TRY(dmalloc16(&a.data16[i], act16_elems(a.C[i], (size_t)a.h[i] * a.w[i])));
             a.has32[i] = 1;
@@ -434,6 +438,7 @@ int ensure_input_buffers(st_ctx* c, int H, int W)
     c->H = H; c->W = W; c->cur = 0;
     // work buffers that follow the input geometry
     for (auto& p : c->inject) dfree(p);
+    std::fill(c->inject_roi_zero.begin(), c->inject_roi_zero.end(), 0);
     dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree16(c->diff16A); dfree16(c->diff16B);
     std::vector<int> C, h, w;
     shapes_for(c, H, W, C, h, w);
@@ -541,6 +546,7 @@ int st_create(st_ctx** out, int device_id, const st_layer_desc* layers, int n_la
     c->content_feat.assign(c->nb, nullptr);
     c->style_gram.assign(c->nb, nullptr);
     c->inject.assign(c->nb, nullptr);
+    c->inject_roi_zero.assign(c->nb, 0);
     c->layer_part.assign(c->nb, nullptr);
     c->s2_part.assign(c->nb, nullptr);
     c->sfuse_w.assign(c->nb, nullptr); c->sfuse_cap.assign(c->nb, 0);
@@ -741,6 +747,7 @@ int st_backward(st_ctx* c, int n, const int* blob_index, const float* const* dif
         const size_t nb = (size_t)c->act.C[b] * c->act.h[b] * c->act.w[b];
         if (!c->inject[b]) ST_TRY(dmalloc(&c->inject[b], nb));
         HIP_TRY(hipMemcpyAsync(c->inject[b], diffs[i], nb * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        c->inject_roi_zero[b] = 0;
         inj[b] = c->inject[b];
         top = std::max(top, b);
     }

@@ -99,6 +99,7 @@ struct st_ctx {
     std::vector<char> norm_valid;                  // [nb*3]
     // work buffers (input geometry)
     std::vector<float*> inject;
+    std::vector<char> inject_roi_zero;             // per blob: the inject buffer is zero outside the tile's region of interest (tile-sharded bf16 style term)
     float *diffA = nullptr, *diffB = nullptr, *stmp = nullptr;
     size_t max_blob = 0;
     float *gram_slabs = nullptr, *gram_fold = nullptr, *dbuf = nullptr;

@@ -26,6 +26,7 @@ int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad_out, b
         const int C = a.C[b], hw = a.h[b] * a.w[b];
         const size_t n = (size_t)C * hw;
         if (!c->inject[b]) ST_TRY(dmalloc(&c->inject[b], n));
+        c->inject_roi_zero[b] = 0;
         if (!c->layer_part[b]) ST_TRY(dmalloc(&c->layer_part[b], 5 * kMaxPartials));
         float* part = c->layer_part[b];
         float* nrm = c->norms + b * 3;

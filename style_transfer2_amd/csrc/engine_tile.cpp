@@ -26,6 +26,45 @@ int tile_ensure(float** p, size_t* cap, size_t n)
     if (n > *cap) { dfree(*p); ST_TRY(dmalloc(p, n)); *cap = n; }
     return ST_OK;
 }
+// bf16 operands: does the style term of blob b run on its bf16 copy here (region-of-interest forms of gram16.hip / style16.hip)?
+bool tile_style16(const st_ctx* c, int b)
+{
+    return c->bf16 && c->act.data16[b] && style_runs16(c, c->act, b);
+}
+
+// the style gradient of blob b over the tile's region (worker.py:262-269): fp32 kernel on the fp32 blob, or -- bf16 operands -- the
+// bf16 kernel on the blob's bf16 copy, which touches the region's pixels only (the inject buffer is zeroed outside it once)
+int tile_style_grad(st_ctx* c, int b, const BlobRoi& r, float* dst, bool is_inject, float c2, int fused, float sw, int accumulate, int* np)
+{
+    const ActSet& a = c->act;
+    const int C = a.C[b];
+    if (!tile_style16(c, b)) {
+        if (!a.has32[b]) return fail(ST_ERR_STATE, "internal: style blob %d has no fp32 copy", b);
+        const int need = style_grad_blocks(C, a.h[b], a.w[b]);
+        if (c->s2_cap[b] < need) { dfree(c->s2_part[b]); ST_TRY(dmalloc(&c->s2_part[b], need)); c->s2_cap[b] = need; }
+        PixRoi pr{r.y0, r.x0, r.y1, r.x1};
+        HIP_TRY(launch_style_grad(c->dbuf, a.data[b], dst, c2, fused, sw, c->norms + b * 3 + 1, accumulate, c->s2_part[b], np, C, a.h[b], a.w[b], c->stream, &pr));
+        return ST_OK;
+    }
+    const int rw = r.x1 - r.x0, rh = r.y1 - r.y0;
+    const size_t hw = (size_t)rw * rh, plane = (size_t)a.h[b] * a.w[b];
+    const int need = style_grad16_blocks(C, hw);
+    if (c->s2_cap[b] < need) { dfree(c->s2_part[b]); ST_TRY(dmalloc(&c->s2_part[b], need)); c->s2_cap[b] = need; }
+    if (style_grad16_pack_elems(C) > c->d16_cap) {
+        dfree16(c->d16); c->d16_cap = 0;
+        ST_TRY(dmalloc16(&c->d16, style_grad16_pack_elems(C)));
+        c->d16_cap = style_grad16_pack_elems(C);
+    }
+    if (is_inject && !accumulate && !c->inject_roi_zero[b]) {
+        HIP_TRY(hipMemsetAsync(dst, 0, (size_t)C * plane * sizeof(float), c->stream));
+        c->inject_roi_zero[b] = 1;
+    }
+    GramRoi roi{r.y0, r.x0, rw, a.w[b], plane};
+    HIP_TRY(launch_style_grad16(c->dbuf, conv_mpad(C), c->d16, a.data16[b], dst, c2, fused, sw, c->norms + b * 3 + 1, accumulate, c->s2_part[b], np,
+                                C, hw, c->stream, &roi));
+    return ST_OK;
+}
+
 // D = Graw / n_global - G_style into dbuf ([C][MPad]); sum D^2 -> pd[k]
 int tile_style_D(st_ctx* c, int b, const float* graw, double n_global, float* pd_slot)
 {
@@ -98,9 +137,15 @@ int st_tile_forward(st_ctx* c, float** dev_ptr, int* n_floats)
         if (al.s) {
             const int rw = r.x1 - r.x0, rh = r.y1 - r.y0, hw = rw * rh;
             GramPlan pl;
-            ST_TRY(ensure_gram_bufs(c, C, hw, pl));
             GramRoi roi{r.y0, r.x0, rw, a.w[b], (size_t)a.h[b] * a.w[b]};
-            HIP_TRY(launch_gram_partial(a.data[b], c->gram_slabs, C, hw, pl, c->stream, &roi));
+            if (tile_style16(c, b)) {       // bf16 operands: the partials on the bf16 matrix cores, from the blob's bf16 copy (gram16.hip)
+                ST_TRY(ensure_gram_bufs(c, C, hw, pl, true));
+                HIP_TRY(launch_gram16_partial(a.data16[b], c->gram_slabs, C, hw, pl, c->stream, &roi));
+            } else {
+                if (!a.has32[b]) return fail(ST_ERR_STATE, "internal: style blob %d has no fp32 copy", b);
+                ST_TRY(ensure_gram_bufs(c, C, hw, pl));
+                HIP_TRY(launch_gram_partial(a.data[b], c->gram_slabs, C, hw, pl, c->stream, &roi));
+            }
             // raw sum over this rank's region (divisor 1, no target), contiguous C x C
             HIP_TRY(launch_gram_reduce(c->gram_slabs, c->gram_fold, nullptr, c->tile.p1 + pos, C, nullptr, nullptr, C, 1.0, pl, c->stream));
             pos += (size_t)C * C;
@@ -179,9 +224,6 @@ int st_tile_losses_finish(st_ctx* c)
         if (al.s) {
             ST_TRY(tile_style_D(c, b, c->tile.p1 + pos, r.n_global, c->tile.pd + k));
             const float c2 = (float)(2.0 / ((double)C * C * r.n_global));
-            const int need = style_grad_blocks(C, a.h[b], a.w[b]);
-            if (c->s2_cap[b] < need) { dfree(c->s2_part[b]); ST_TRY(dmalloc(&c->s2_part[b], need)); c->s2_cap[b] = need; }
-            PixRoi pr{r.y0, r.x0, r.y1, r.x1};
             int np = 0;
             if (two_step) {
                 // norm from the all-reduced sum S^2 of the first pass (st_tile_style_raw), then saxpy
@@ -189,9 +231,9 @@ int st_tile_losses_finish(st_ctx* c)
                     HIP_TRY(launch_finalize_norm(c->tile.p2 + k, 1, r.n_global, nrm + 1, c->stream));
                     c->norm_valid[b * 3 + 1] = 1;
                 }
-                HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->inject[b], c2, 1, al.sw, nrm + 1, wrote, c->s2_part[b], &np, C, a.h[b], a.w[b], c->stream, &pr));
+                ST_TRY(tile_style_grad(c, b, r, c->inject[b], true, c2, 1, al.sw, wrote, &np));
             } else {
-                HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->inject[b], c2, 1, al.sw, nrm + 1, wrote, c->s2_part[b], &np, C, a.h[b], a.w[b], c->stream, &pr));
+                ST_TRY(tile_style_grad(c, b, r, c->inject[b], true, c2, 1, al.sw, wrote, &np));
                 // sum S^2 of this rank's region -> p3 tail (all-reduced with the image sums)
                 ST_TRY(tile_ensure(&c->tile.p3, &c->tile.p3_n, 6 + kMaxTraceLayers));
                 HIP_TRY(launch_sum_partials(c->s2_part[b], np, c->tile.p3 + 6 + k, c->stream));
@@ -219,12 +261,9 @@ int st_tile_style_raw(st_ctx* c)
         const BlobRoi r = tile_roi(c, b);
         ST_TRY(tile_style_D(c, b, c->tile.p1 + pos, r.n_global, c->tile.pd + k));
         const float c2 = (float)(2.0 / ((double)C * C * r.n_global));
-        const int need = style_grad_blocks(C, a.h[b], a.w[b]);
-        if (c->s2_cap[b] < need) { dfree(c->s2_part[b]); ST_TRY(dmalloc(&c->s2_part[b], need)); c->s2_cap[b] = need; }
         if (!c->stmp) ST_TRY(dmalloc(&c->stmp, c->max_blob));
-        PixRoi pr{r.y0, r.x0, r.y1, r.x1};
         int np = 0;
-        HIP_TRY(launch_style_grad(c->dbuf, a.data[b], c->stmp, c2, 0, al.sw, c->norms + b * 3 + 1, 0, c->s2_part[b], &np, C, a.h[b], a.w[b], c->stream, &pr));
+        ST_TRY(tile_style_grad(c, b, r, c->stmp, false, c2, 0, al.sw, 0, &np));
         HIP_TRY(launch_sum_partials(c->s2_part[b], np, c->tile.p2 + k, c->stream));
         pos += (size_t)C * C;
         ++k;

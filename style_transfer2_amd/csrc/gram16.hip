@@ -24,9 +24,11 @@ typedef __attribute__((address_space(3))) void* g16_lptr_t;
 constexpr int G16_STEP = 64;                 // pixels staged per step (4 MFMA k-steps)
 constexpr int G16_ROWQ = 68;                 // quads per channel-block row in LDS: 64 + 4 of padding (1088 bytes)
 
+// roi (tile-sharded mode): the contraction runs over the hw = rw x rows pixels of a rectangle of the blob (first pixel (y0, x0), row
+// pitch `pitch`, `plane` pixels per channel-block row); rw == 0: the whole blob, pixel k at offset k.
 template <int BT>
 __device__ __forceinline__ void gram16_body(const unsigned short* __restrict__ F16, unsigned f_bytes, float* __restrict__ slabs,
-                                            int C, int hw, int tiles_1d, int kslab)
+                                            int C, int hw, int tiles_1d, int kslab, GramRoi roi)
 {
     constexpr int T = BT / 64;                       // 32x32 MFMA tiles per wave per dimension
     constexpr int CBR = BT / 8;                      // channel-block rows per operand image
@@ -47,7 +49,8 @@ __device__ __forceinline__ void gram16_body(const unsigned short* __restrict__ F
     const bool diag = ti == tj;
     const int kbeg = split * kslab;
     const int kend = min(hw, kbeg + kslab);
-    const int nsteps = (kend - kbeg) / G16_STEP;
+    const int nsteps = (kend - kbeg + G16_STEP - 1) / G16_STEP;      // a ragged last step (regions of interest) reads zeros past kend
+    const unsigned plane = roi.rw ? (unsigned)roi.plane : (unsigned)hw;
 
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)F16, 0, f_bytes, 0x00020000);
     unsigned aoff[PPW], boff[PPW];
@@ -55,18 +58,21 @@ __device__ __forceinline__ void gram16_body(const unsigned short* __restrict__ F
     for (int t = 0; t < PPW; ++t) {
         const int cbr = wave + 4 * t;                // channel-block row of this piece; lane = pixel within the step
         const int ca = i0 / 8 + cbr, cb = j0 / 8 + cbr;
-        aoff[t] = ca * 8 < C ? ((unsigned)ca * (unsigned)hw + (unsigned)kbeg + lane) * 16u : 0xffffffffu;
-        boff[t] = cb * 8 < C ? ((unsigned)cb * (unsigned)hw + (unsigned)kbeg + lane) * 16u : 0xffffffffu;
+        aoff[t] = ca * 8 < C ? (unsigned)ca * plane * 16u : 0xffffffffu;
+        boff[t] = cb * 8 < C ? (unsigned)cb * plane * 16u : 0xffffffffu;
     }
     auto dma = [&](int step, int stage) {
-        const unsigned so = (unsigned)step * G16_STEP * 16u;
+        const int k = kbeg + step * G16_STEP + lane;                 // this lane's pixel of the contraction
+        unsigned pix = (unsigned)k;
+        if (roi.rw) { const int ky = k / roi.rw; pix = (unsigned)(roi.y0 + ky) * roi.pitch + roi.x0 + (k - ky * roi.rw); }
+        const unsigned so = k < kend ? pix * 16u : 0xffffffffu;
 #pragma unroll
         for (int t = 0; t < PPW; ++t) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (g16_lptr_t)(smem[stage][0] + (wave + 4 * t) * G16_ROWQ), 16,
-                                                     aoff[t] == 0xffffffffu ? aoff[t] : aoff[t] + so, 0, 0, 0);
+                                                     (aoff[t] == 0xffffffffu || so == 0xffffffffu) ? 0xffffffffu : aoff[t] + so, 0, 0, 0);
             if (!diag)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (g16_lptr_t)(smem[stage][1] + (wave + 4 * t) * G16_ROWQ), 16,
-                                                         boff[t] == 0xffffffffu ? boff[t] : boff[t] + so, 0, 0, 0);
+                                                         (boff[t] == 0xffffffffu || so == 0xffffffffu) ? 0xffffffffu : boff[t] + so, 0, 0, 0);
         }
     };
 
@@ -130,25 +136,32 @@ __device__ __forceinline__ void gram16_body(const unsigned short* __restrict__ F
         }
 }
 
-__global__ __launch_bounds__(256, 2) void gram16_partial_128(const unsigned short* F16, unsigned f_bytes, float* slabs, int C, int hw, int tiles_1d, int kslab)
-{ gram16_body<128>(F16, f_bytes, slabs, C, hw, tiles_1d, kslab); }
-__global__ __launch_bounds__(256, 2) void gram16_partial_64(const unsigned short* F16, unsigned f_bytes, float* slabs, int C, int hw, int tiles_1d, int kslab)
-{ gram16_body<64>(F16, f_bytes, slabs, C, hw, tiles_1d, kslab); }
+__global__ __launch_bounds__(256, 2) void gram16_partial_128(const unsigned short* F16, unsigned f_bytes, float* slabs, int C, int hw, int tiles_1d, int kslab, GramRoi roi)
+{ gram16_body<128>(F16, f_bytes, slabs, C, hw, tiles_1d, kslab, roi); }
+__global__ __launch_bounds__(256, 2) void gram16_partial_64(const unsigned short* F16, unsigned f_bytes, float* slabs, int C, int hw, int tiles_1d, int kslab, GramRoi roi)
+{ gram16_body<64>(F16, f_bytes, slabs, C, hw, tiles_1d, kslab, roi); }
 
 // whole blobs with hw % 64 == 0, C % 8 == 0 and a plan whose slabs are whole 64-pixel steps
 bool gram16_ok(int C, int hw, const GramPlan& pl)
 {
     return C % 8 == 0 && hw % G16_STEP == 0 && pl.kslab % G16_STEP == 0 && 16ull * (C / 8) * hw < 0xfffffff0ull;
 }
-
-hipError_t launch_gram16_partial(const unsigned short* F16, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s)
+// a region of interest of hw pixels inside a blob of `plane` pixels per channel: any hw (the last step is zero-padded)
+bool gram16_roi_ok(int C, int hw, size_t plane, const GramPlan& pl)
 {
-    if (!gram16_ok(C, hw, pl) || (reinterpret_cast<uintptr_t>(F16) & 15) != 0) return hipErrorInvalidValue;
+    return C % 8 == 0 && hw > 0 && pl.kslab % G16_STEP == 0 && 16ull * (C / 8) * plane < 0xfffffff0ull;
+}
+
+hipError_t launch_gram16_partial(const unsigned short* F16, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s, const GramRoi* roi)
+{
+    if ((reinterpret_cast<uintptr_t>(F16) & 15) != 0) return hipErrorInvalidValue;
+    if (roi ? !gram16_roi_ok(C, hw, roi->plane, pl) || roi->rw <= 0 : !gram16_ok(C, hw, pl)) return hipErrorInvalidValue;
     const int t1 = (C + pl.bt - 1) / pl.bt;
     const unsigned grid = (unsigned)(pl.tiles * pl.splits);
-    const unsigned fb = (unsigned)(16ull * (C / 8) * hw);
-    if (pl.bt == 128) gram16_partial_128<<<grid, 256, 0, s>>>(F16, fb, slabs, C, hw, t1, pl.kslab);
-    else gram16_partial_64<<<grid, 256, 0, s>>>(F16, fb, slabs, C, hw, t1, pl.kslab);
+    const unsigned fb = (unsigned)(16ull * (C / 8) * (roi ? roi->plane : (size_t)hw));
+    const GramRoi r = roi ? *roi : GramRoi{0, 0, 0, 0, 0};
+    if (pl.bt == 128) gram16_partial_128<<<grid, 256, 0, s>>>(F16, fb, slabs, C, hw, t1, pl.kslab, r);
+    else gram16_partial_64<<<grid, 256, 0, s>>>(F16, fb, slabs, C, hw, t1, pl.kslab, r);
     return hipGetLastError();
 }
 

@@ -131,9 +131,11 @@ GramPlan gram_plan(int C, int hw);
 // accumulation; same slab format (gram_reduce finishes it).  Needs C % 8 == 0, hw % 64 == 0 and a gram_plan16 plan.
 GramPlan gram_plan16(int C, int hw);
 bool gram16_ok(int C, int hw, const GramPlan& pl);
-hipError_t launch_gram16_partial(const unsigned short* F16, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s);
 // region of interest of a blob [C][H][W]: hw (= rw * rows) pixels starting at (y0, x0); pitch = W, plane = H*W
 struct GramRoi { int y0, x0, rw, pitch; size_t plane; };
+bool gram16_roi_ok(int C, int hw, size_t plane, const GramPlan& pl);
+hipError_t launch_gram16_partial(const unsigned short* F16, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s,
+                                 const GramRoi* roi = nullptr);
 hipError_t launch_gram_partial(const float* F, float* slabs, int C, int hw, const GramPlan& pl, hipStream_t s,
                                const GramRoi* roi = nullptr);
 // out[i][j] = sum_s slabs[s][i][j] / n  - (target ? target[i][j] : 0);  partial[blockIdx] = sum out^2
@@ -160,7 +162,8 @@ bool style_grad16_ok(int C, size_t hw);
 size_t style_grad16_pack_elems(int C);
 int style_grad16_blocks(int C, size_t hw);
 hipError_t launch_style_grad16(const float* Dp, int ld, unsigned short* A16, const unsigned short* F16, float* dst, float c2, int fused,
-                               float sw, const float* norm, int accumulate, float* partial, int* n_partial, int C, size_t hw, hipStream_t s);
+                               float sw, const float* norm, int accumulate, float* partial, int* n_partial, int C, size_t hw, hipStream_t s,
+                               const GramRoi* roi = nullptr);   // roi: hw = its pixel count; reads / writes only those pixels of the blob
 // out[0] = sum(part[0..n)) in double, rounded to float (deterministic, one workgroup)
 hipError_t launch_sum_partials(const float* part, int n, float* out, hipStream_t s);
 // inject = (sw / *norm) * S + (accumulate ? inject : 0)

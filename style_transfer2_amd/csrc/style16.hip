@@ -131,6 +131,9 @@ struct Style16Args {
     const unsigned short* A16; const unsigned short* F16; float* out; const float* norm; float* partial;
     float c2, sw; int fused, accumulate;
     int C, Mp, n_mtiles; unsigned hw, a_bytes, f_bytes;
+    // region of interest (tile-sharded mode): hw counts the pixels of a rectangle of the blob (first pixel (ry0, rx0), rrw wide, row
+    // pitch rpitch, rplane pixels per channel); only those pixels are read and written.  rrw == 0: the whole blob.
+    int ry0, rx0, rrw, rpitch; unsigned rplane;
 };
 
 template <int BM>
@@ -151,6 +154,12 @@ __device__ __forceinline__ void style_grad16_body(const Style16Args& a)
     const int m0 = mt * BM;
     const unsigned p0 = (unsigned)pt * S16_PX;
     const int nch = a.C / S16_KC;
+    const unsigned plane = a.rrw ? a.rplane : a.hw;                  // pixels per channel (block) of the blob itself
+    auto pixel = [&](unsigned q) -> unsigned {                       // q-th pixel of the (region of the) blob -> offset inside a channel
+        if (!a.rrw) return q;
+        const unsigned qy = q / (unsigned)a.rrw;
+        return (a.ry0 + qy) * (unsigned)a.rpitch + a.rx0 + (q - qy * (unsigned)a.rrw);
+    };
 
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.A16, 0, a.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_f = __builtin_amdgcn_make_buffer_rsrc((void*)a.F16, 0, a.f_bytes, 0x00020000);
@@ -165,7 +174,7 @@ __device__ __forceinline__ void style_grad16_body(const Style16Args& a)
     for (int t = 0; t < B_PW; ++t) {
         const int q = (wave + 4 * t) * 64 + lane;                   // [ks][half][px]
         const int px = q % S16_PX, r = q / S16_PX;                  // r = ks * 2 + half = channel block within the chunk
-        boff[t] = p0 + px < a.hw ? ((unsigned)r * a.hw + p0 + px) * 16u : 0xffffffffu;
+        boff[t] = p0 + px < a.hw ? ((unsigned)r * plane + pixel(p0 + px)) * 16u : 0xffffffffu;
     }
 
     s16_f32x16 acc[TM];
@@ -177,7 +186,7 @@ __device__ __forceinline__ void style_grad16_body(const Style16Args& a)
     for (int ch = 0; ch < nch; ++ch) {
         if (ch) __syncthreads();                                    // every wave is done with the previous chunk
         const unsigned ca = (unsigned)ch * 16u * a.Mp * 16u;        // 4 k-steps x 2 x 2 rows of Mp quads
-        const unsigned cb = (unsigned)ch * 8u * a.hw * 16u;         // 8 channel blocks
+        const unsigned cb = (unsigned)ch * 8u * plane * 16u;        // 8 channel blocks
 #pragma unroll
         for (int t = 0; t < A_PW; ++t)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (s16_lptr_t)(smem + (wave + 4 * t) * 64), 16, aoff[t] + ca, 0, 0, 0);
@@ -207,7 +216,8 @@ __device__ __forceinline__ void style_grad16_body(const Style16Args& a)
     const bool live = p < a.hw;
     const float coef = a.fused ? a.sw / *a.norm : 0.0f;
     float ss = 0.0f;
-    if ((a.hw & 3u) == 0) {
+    // (a region of interest takes the 16-byte store path when its rows start and end on 16-byte boundaries of the blob)
+    if ((a.hw & 3u) == 0 && (!a.rrw || ((a.rrw | a.rx0 | a.rpitch) & 3) == 0)) {
         // Rows of 128 pixels through LDS: a lane-per-pixel store is 4 bytes per lane and channel (64 store instructions per
         // wave, issue-bound); staged, every lane stores 16 bytes of one channel row (4x fewer instructions, whole lines).
         float* stage = reinterpret_cast<float*>(smem);              // [64 channels][128 pixels]
@@ -232,7 +242,7 @@ __device__ __forceinline__ void style_grad16_body(const Style16Args& a)
                 const int m = m0 + 64 * half + row;
                 if (m < a.C && p0 + c4 < a.hw) {
                     float4 v = *reinterpret_cast<const float4*>(stage + row * S16_PX + c4);
-                    float* dst = a.out + (size_t)m * a.hw + p0 + c4;
+                    float* dst = a.out + (size_t)m * plane + pixel(p0 + c4);
                     if (a.fused && a.accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
                     *reinterpret_cast<float4*>(dst) = v;
                 }
@@ -249,7 +259,7 @@ __device__ __forceinline__ void style_grad16_body(const Style16Args& a)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int m = mbase + (e & 3) + 8 * (e >> 2);
-                    off[e] = (unsigned)(m < a.C ? m : a.C - 1) * a.hw + (live ? p : 0u);
+                    off[e] = (unsigned)(m < a.C ? m : a.C - 1) * plane + (live ? pixel(p) : 0u);
                     v[e] = live && m < a.C ? acc[i][8 * h + e] * a.c2 : 0.0f;
                     ss += v[e] * v[e];
                 }
@@ -282,9 +292,11 @@ size_t style_grad16_pack_elems(int C) { return (size_t)(C / 16) * 4 * ((C + 127)
 int style_grad16_blocks(int C, size_t hw) { return (int)((hw + S16_PX - 1) / S16_PX) * ((C + style16_bm(C) - 1) / style16_bm(C)); }
 
 hipError_t launch_style_grad16(const float* Dp, int ld, unsigned short* A16, const unsigned short* F16, float* dst, float c2, int fused,
-                               float sw, const float* norm, int accumulate, float* partial, int* n_partial, int C, size_t hw, hipStream_t s)
+                               float sw, const float* norm, int accumulate, float* partial, int* n_partial, int C, size_t hw, hipStream_t s,
+                               const GramRoi* roi)
 {
-    if (!style_grad16_ok(C, hw)) return hipErrorInvalidValue;
+    // roi: hw = the region's pixel count; the blob itself has roi->plane pixels per channel
+    if (!style_grad16_ok(C, roi ? roi->plane : hw) || hw == 0 || (roi && (roi->rw <= 0 || hw > roi->plane))) return hipErrorInvalidValue;
     const int bm = style16_bm(C), Mp = (C + 127) / 128 * 128;
     const int nq = (C / 16) * 4 * Mp;
     style16_pack_d_k<<<(nq + 255) / 256, 256, 0, s>>>(Dp, ld, C, Mp, A16);
@@ -292,7 +304,8 @@ hipError_t launch_style_grad16(const float* Dp, int ld, unsigned short* A16, con
     a.A16 = A16; a.F16 = F16; a.out = dst; a.norm = norm; a.partial = partial;
     a.c2 = c2; a.sw = sw; a.fused = fused; a.accumulate = accumulate;
     a.C = C; a.Mp = Mp; a.n_mtiles = (C + bm - 1) / bm; a.hw = (unsigned)hw;
-    a.a_bytes = (unsigned)(style_grad16_pack_elems(C) * 2); a.f_bytes = (unsigned)(16ull * (C / 8) * hw);
+    a.a_bytes = (unsigned)(style_grad16_pack_elems(C) * 2); a.f_bytes = (unsigned)(16ull * (C / 8) * (roi ? roi->plane : hw));
+    if (roi) { a.ry0 = roi->y0; a.rx0 = roi->x0; a.rrw = roi->rw; a.rpitch = roi->pitch; a.rplane = (unsigned)roi->plane; }
     const int grid = style_grad16_blocks(C, hw);
     if (n_partial) *n_partial = grid;
     if (bm == 128) style_grad16_128<<<grid, 256, 0, s>>>(a);

@@ -514,6 +514,31 @@ def test_tiled_bf16_lean_and_full_data_flows_are_bit_identical():
     assert np.isfinite(runs[0][-1][0]).all()
 
 
+def test_tiled_bf16_style_term_on_the_bf16_matrix_cores_tracks_the_fp32_region_kernels(monkeypatch):
+    """Tile phases, bf16 operands: the style term's two GEMMs in their region-of-interest bf16 forms (default) against the fp32
+    region-of-interest kernels on fp32 blobs (ST2_TILE_STYLE16=0), same windows, same convs: the loss and the iterate agree to the
+    accuracy of a bf16-rounded feature operand."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    h, w = 96, 160
+    content, style, init = _tiled_images(h, w)
+    topo = oracle.VGG19_TOPOLOGY[:7]
+    params = oracle.he_init_weights(topo, 0, 0.1)
+    weights = {'content': {'conv2_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1}, 'deepdream': {}}
+    grid = tiling.TileGrid(h, w, 1, 1, topo, 5)
+    runs = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('ST2_TILE_STYLE16', flag)
+        backend = HipTileBackend(params, grid, 0, content, style, init, weights, TILED_PARAMS, step_size=10, topology=topo, precision='bf16')
+        backend.comm_init_solo(0, 1)
+        ft = tiled.FusedTiledTransfer(grid, 0, backend)
+        runs[flag] = [(ft.step(), ft.tile_image()) for _ in range(3)]
+    for (va, ia), (vb, ib) in zip(runs['1'], runs['0']):
+        assert np.isclose(va[-2], vb[-2], rtol=2e-3), (va[-2], vb[-2])
+        assert not np.array_equal(va, vb)                        # other kernels really ran
+        assert np.mean((ia - ib) ** 2) <= 1.0
+
+
 def test_tiled_single_rank_with_bf16_convs_tracks_the_bf16_engine():
     """precision='bf16' in the tile backend: the window's convs on the bf16 matrix cores, Gram / style / loss kernels in their fp32
     region-of-interest forms.  Against the plain engine in its bf16 mode (whose Gram and style gradient read the bf16 copies instead):
@@ -641,7 +666,7 @@ def test_tiled_multi_rank_on_one_gpu_matches_oracle(rows, cols, fused):
     assert np.allclose(full, ref[-1][0], rtol=0, atol=0.5) or np.mean(np.abs(full - ref[-1][0]) > 0.5) < 0.02
 
 
-def _tiled_vgg_rank(rank, world, port, steps, h, w, q, fused=False):
+def _tiled_vgg_rank(rank, world, port, steps, h, w, q, fused=False, precision='fp32'):
     import os
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -656,7 +681,7 @@ def _tiled_vgg_rank(rank, world, port, steps, h, w, q, fused=False):
     weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
                'deepdream': {}}
     backend = HipTileBackend(oracle.he_init_weights(topo, seed=0), grid, rank, content, style, init, weights,
-                             {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}, step_size=10)
+                             {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}, step_size=10, precision=precision)
     if fused:
         backend.comm_init_callbacks(dist, rank, world)
         tt = tiled.FusedTiledTransfer(grid, rank, backend)
@@ -671,13 +696,16 @@ def _tiled_vgg_rank(rank, world, port, steps, h, w, q, fused=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('h,w,loss_rtol,fused', [(176, 416, 1e-4, False), (176, 416, 1e-4, True), (1024, 4096, 2e-5, True)])
-def test_tiled_vgg19_two_ranks_match_single_gpu_engine(h, w, loss_rtol, fused):
+@pytest.mark.parametrize('h,w,loss_rtol,fused,precision', [(176, 416, 1e-4, False, 'fp32'), (176, 416, 1e-4, True, 'fp32'), (1024, 4096, 2e-5, True, 'fp32'),
+                                                           (176, 416, 5e-3, True, 'bf16'), (512, 2048, 5e-3, True, 'bf16')])
+def test_tiled_vgg19_two_ranks_match_single_gpu_engine(h, w, loss_rtol, fused, precision):
     """Full VGG19 to conv5_1 (receptive-field apron 80 px): 2 ranks (1 x 2 grid) vs the plain engine on the whole image.
     176 x 416 is the quick case; 1024 x 4096 is BASELINE configs[4]'s per-rank GEOMETRY on the one GPU there is: windows of
     1024 x 2128 whose levels are 2128, 1064, 532, 266 and 133 wide (the any-width Winograd kernels, ceil-mode pools, 0.9 GB blobs),
     aprons, overlap-add, the torus ring of the TV term -- two ranks sharing the card over host-staged gloo, so still unmeasured on
-    xGMI / RCCL hardware."""
+    xGMI / RCCL hardware.  precision = 'bf16': the windows run the bf16 data flow of the plain engine -- bf16 conv operands, lean fp32
+    tensors, the Gram partials and the style gradient on the bf16 matrix cores in their region-of-interest forms (gram16.hip /
+    style16.hip: only the tile's pixels of each style blob are contracted / written) -- against the plain engine in its bf16 mode."""
     import torch.multiprocessing as mp
     steps = 2
     rs = np.random.RandomState
@@ -685,7 +713,7 @@ def test_tiled_vgg19_two_ranks_match_single_gpu_engine(h, w, loss_rtol, fused):
                             rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
     weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
                'deepdream': {}}
-    ref = st2.StyleTransfer(st2.HipModel(oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0)))
+    ref = st2.StyleTransfer(st2.HipModel(oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0), precision=precision))
     ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
     ref.set_weights(weights, {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2})
     ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
@@ -694,8 +722,8 @@ def test_tiled_vgg19_two_ranks_match_single_gpu_engine(h, w, loss_rtol, fused):
     want = [(np.asarray(i, F32).copy(), dict(t)) for i, t in want]
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29300 + (__import__('os').getpid() + 7 * fused + h) % 500
-    procs = [ctx.Process(target=_tiled_vgg_rank, args=(r, 2, port, steps, h, w, q, fused)) for r in range(2)]
+    port = 29300 + (__import__('os').getpid() + 7 * fused + h + 13 * (precision == 'bf16')) % 500
+    procs = [ctx.Process(target=_tiled_vgg_rank, args=(r, 2, port, steps, h, w, q, fused, precision)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=400) for _ in procs]
@@ -709,11 +737,11 @@ def test_tiled_vgg19_two_ranks_match_single_gpu_engine(h, w, loss_rtol, fused):
         for rank, (y0, x0, y1, x1), window, res in got:
             full[y0:y1, x0:x1] = res[step][0]
             assert np.isclose(res[step][1][-2], want[step][1]['loss'], rtol=loss_rtol), (step, rank, res[step][1][-2], want[step][1]['loss'])
-            assert np.isclose(res[step][1][-1], want[step][1]['grad'], rtol=1e-3), (step, rank)
+            assert np.isclose(res[step][1][-1], want[step][1]['grad'], rtol=1e-3 if precision == 'fp32' else 3e-2), (step, rank)
         mse = float(np.mean((full.astype(np.float64) - want[step][0]) ** 2))
         print('[tiled %dx%d] step %d: loss %.9g vs %.9g, image MSE %.3g, pixels off by > 1: %.2e' % (
             h, w, step, got[0][3][step][1][-2], want[step][1]['loss'], mse, float(np.mean(np.abs(full - want[step][0]) > 1.0))))
-        assert mse <= (1.0 if h < 1024 else 0.25), (step, mse)   # 0..255 units; Adam's first steps are sign-like (a flipped tiny gradient = 20 levels)
+        assert mse <= (1.0 if (h < 1024 or precision == 'bf16') else 0.25), (step, mse)   # 0..255 units; Adam's first steps are sign-like (a flipped tiny gradient = 20 levels)
 
 
 def test_vgg19_odd_default_size_225x300_unaligned_paths():

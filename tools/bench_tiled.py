@@ -29,7 +29,7 @@ ap.add_argument('--solo-rank', type=int, default=-1,
                 help='run ONE rank of the grid alone on this GPU (its window, its pack / unpack kernels; nothing is exchanged, what a\n'
                      'neighbour would send arrives as zeros): the per-rank compute of a multi-GPU run, e.g. --size 8192 --grid 2x4 --solo-rank 1\n'
                      '= an interior column (window 4176 x 2208)')
-ap.add_argument('--precision', default='fp32', choices=('fp32', 'bf16'), help='bf16: conv operands bf16, everything else fp32')
+ap.add_argument('--precision', default='fp32', choices=('fp32', 'bf16', 'bf16-full'), help='bf16: conv operands bf16 (lean data flow), everything else fp32; bf16-full: every fp32 tensor written')
 args = ap.parse_args()
 # native libraries (RCCL prints its version banner, gloo, the HIP runtime) write to fd 1 at will: keep the real stdout for the ONE JSON line
 sys.stdout.flush()
