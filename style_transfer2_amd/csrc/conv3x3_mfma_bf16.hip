@@ -416,17 +416,18 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                             if (FULL || mbase + (e & 3) + 8 * (e >> 2) < a.M) a.out[off[e]] = v[j][e];
                     }
                     if (a.out16 && live) {
-                        // rows mbase..+3 and mbase+8..+11: two groups of 4 consecutive channels -> two 8-byte stores
+                        // rows mbase..+3 and mbase+8..+11: this lane holds HALF (4 channels) of two 8-channel quads of its pixel, lane ^ 32
+                        // the other halves (same pixel, so both are live together).  v_permlane32_swap exchanges them: lanes 0-31 own the
+                        // first quad, lanes 32-63 the second -- one 16-byte store per lane instead of two interleaved 8-byte ones.
+                        bf16x4 pk0, pk1;
 #pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            const int mg = mbase + 8 * g;
-                            if (FULL || mg < a.M) {         // M is a multiple of 8 on this path (checked at launch)
-                                bf16x4 pk;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) pk[e] = (__bf16)v[j][4 * g + e];
-                                *reinterpret_cast<bf16x4*>(a.out16 + ((size_t)(mg >> 3) * plane + pix) * 8 + (mg & 7)) = pk;
-                            }
-                        }
+                        for (int e = 0; e < 4; ++e) { pk0[e] = (__bf16)v[j][e]; pk1[e] = (__bf16)v[j][4 + e]; }
+                        const uint2 u0 = __builtin_bit_cast(uint2, pk0), u1 = __builtin_bit_cast(uint2, pk1);
+                        const auto sx = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
+                        const int mq = mbase - 4 * khalf + 8 * khalf;                  // first channel of this lane's quad
+                        if (FULL || mq < a.M)           // M is a multiple of 8 on this path (checked at launch)
+                            *reinterpret_cast<uint4*>(a.out16 + ((size_t)(mq >> 3) * plane + pix) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
                     }
                 }
                 if constexpr (TN % 2 == 0) {
