@@ -4,6 +4,7 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 1024] [--optimizer adam] [--precision fp32]
     python bench.py --size 2048 --optimizer lbfgs --precision bf16          # BASELINE configs[2]
+    python bench.py --examples                                              # BASELINE configs[0]: the example pair at 256 px, 50 Adam iterations
     python bench.py --gpus 8 --tiled 2x4 --size 8192                        # BASELINE configs[4] (tile-sharded image)
 
 One "step" = one ``StyleTransfer.step()`` = forward to conv5_1, 1 content + 5 style loss terms, ranged backward,
@@ -22,8 +23,10 @@ bracketed by barrier + device sync, max over ranks); all blocks are listed under
 dominant kernel class (the conv3x3 launches on the matrix cores): `achieved` counts the FLOPs the MFMA pipe executes
 (Winograd launches perform 4/9 of the direct-convolution FLOPs), so `frac` is a true fraction of the MFMA peak; the
 algorithmic (direct-convolution) figure is kept beside it.  `cpu_baseline` (kind "port") and `parity` come
-from the CPU oracle run on this host on the same inputs, N = 1 only.  `worker_level` is the rate including one
-`Iterate` (D2H + pickle) per step, which `value` excludes.
+from the CPU oracle run on this host on the same inputs, N = 1 only: the objective at the initial image (loss, gradient, ReLU
+sign census) and the ITERATE after the oracle's timed step(s) (`parity.image_mse`, 0..255 units).  `worker_level` is the rate
+including one `Iterate` per step, which `value` excludes: D2H + pickle on one thread / with the sender thread / pipelined, and the
+worker's zero-copy form (the GPU copies the iterate into a pre-formatted pickle in pinned memory; the transport gets that buffer).
 """
 
 import argparse
