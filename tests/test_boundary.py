@@ -472,3 +472,16 @@ def test_worker_synchronous_send_option():
     assert wk.sock_out is socks
     wk.run()
     assert [type(m).__name__ for m in socks.sent] == ['WorkerReady', 'GetImages', 'Shutdown']
+
+
+def test_new_entry_points_refuse_null_handles_without_a_gpu():
+    """The round-3 additions to the C ABI (frame room, communicator, exchange plans, the in-engine tile step) check their arguments
+    before they touch the device: a NULL context is ST_ERR_ARG / ST_ERR_STATE with a message, here, without a GPU."""
+    lib = capi.load_library()
+    assert lib.st_step_frame_room(None, 4096, 65536) == 1 and b'NULL' in lib.st_last_error()
+    assert lib.st_comm_unique_id(None) == 1
+    assert lib.st_comm_init(None, b'\0' * capi.COMM_ID_BYTES, 0, 1) == 1
+    assert lib.st_comm_destroy(None) == 1 and lib.st_comm_barrier(None) == 1
+    assert lib.st_tile_plan(None, 0, 0, None) == 1
+    assert lib.st_tile_step(None, None) == 2 and lib.st_tile_get_tile(None, None) == 2
+    assert lib.st_vec_div(None, 1.0, None, 0) == 1
