@@ -193,6 +193,7 @@ def cpu_baseline_and_parity(inputs, optimizer, precision, dev_eval, iterations=1
     whose last iterate is compared with the HIP path's iterate after the same steps from the same state."""
     import oracle
     from threadpoolctl import threadpool_info
+    oracle.keep_freed_memory()
     content, style, init, weights, params = inputs
     topo = oracle.VGG19_TOPOLOGY
     net = oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False,

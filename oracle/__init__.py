@@ -28,3 +28,17 @@ from .caffe_net import NetOracle, VGG19_TOPOLOGY, tiny_topology, he_init_weights
 from .objective import TransferOracle, gram  # noqa: F401
 from .image_norms import tv_term, p_term  # noqa: F401
 from .descent import AdamOracle, LBFGSOracle, EmaBiasCorrected  # noqa: F401
+
+
+def keep_freed_memory():
+    """Tell glibc malloc to serve every request from the heap and never to give freed heap back to the kernel (mallopt
+    M_MMAP_MAX = 0, M_TRIM_THRESHOLD = max) for the rest of this process.  The restated numpy code allocates a fresh temporary of
+    blob size (hundreds of MB at 1024^2) in almost every line, exactly as the reference does; by default each of them is an mmap
+    whose pages fault in one by one and are unmapped again a moment later -- about 40 % of an evaluation's wall time here.  This
+    changes no arithmetic.  Called by tests/conftest.py and by bench.py's cpu_baseline leg, i.e. only where the oracle runs."""
+    import ctypes
+    try:
+        libc = ctypes.CDLL('libc.so.6')
+        return bool(libc.mallopt(-4, 0)) and bool(libc.mallopt(-1, 2 ** 31 - 1))
+    except (OSError, AttributeError):
+        return False

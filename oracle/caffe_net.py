@@ -17,6 +17,8 @@ and Caffe cannot run here); tests/test_oracle_net.py pins it against torch CPU o
 """
 
 from collections import OrderedDict
+from concurrent.futures import ThreadPoolExecutor
+import os
 
 import numpy as np
 
@@ -86,6 +88,35 @@ def pooled_size(n):
 
 _COL_BUDGET = 48 * 1024 * 1024  # floats per im2col band
 
+# Scratch arrays are kept between calls and the im2col / col2im copies run on a few threads, each on its own channel range.
+# Neither changes a single bit of the result (the SGEMM calls and the order of the nine col2im additions per element are the
+# same); both only remove time that is not arithmetic: first-touch page faults on hundreds of MB of fresh memory per call and
+# single-threaded strided copies, which together were 4/5 of an evaluation at 1024^2.
+_SCRATCH = {}
+_COPY_THREADS = max(1, min(8, os.cpu_count() or 1))
+_pool = None
+
+
+def _scratch(tag, shape):
+    n = int(np.prod(shape))
+    buf = _SCRATCH.get(tag)
+    if buf is None or buf.size < n:
+        buf = _SCRATCH[tag] = np.empty(n, F32)
+    return buf[:n].reshape(shape)
+
+
+def _over_channels(fn, channels):
+    """fn(c0, c1) over disjoint channel ranges covering [0, channels), on the copy threads (numpy releases the GIL in copies)."""
+    global _pool
+    parts = min(_COPY_THREADS, channels)
+    if parts <= 1:
+        fn(0, channels)
+        return
+    if _pool is None:
+        _pool = ThreadPoolExecutor(_COPY_THREADS)
+    edges = [channels * i // parts for i in range(parts + 1)]
+    list(_pool.map(lambda i: fn(edges[i], edges[i + 1]), range(parts)))
+
 
 def _band_rows(k_rows, width, height):
     return int(max(1, min(height, _COL_BUDGET // max(1, k_rows * width))))
@@ -95,19 +126,30 @@ def conv3x3_forward(x, w, b):
     """Caffe ConvolutionLayer::Forward_cpu: im2col + SGEMM (+ bias); cross-correlation, pad 1."""
     cin, h, wd = x.shape
     cout = w.shape[0]
-    xp = np.zeros((cin, h + 2, wd + 2), F32)
-    xp[:, 1:-1, 1:-1] = x
+    xp = _scratch('xp', (cin, h + 2, wd + 2))
+    xp[:, 0] = 0; xp[:, -1] = 0; xp[:, :, 0] = 0; xp[:, :, -1] = 0
+
+    def pad(c0, c1):
+        xp[c0:c1, 1:-1, 1:-1] = x[c0:c1]
+    _over_channels(pad, cin)
     wmat = np.ascontiguousarray(w.reshape(cout, cin * 9))
     out = np.empty((cout, h, wd), F32)
     step = _band_rows(cin * 9, wd, h)
     for r0 in range(0, h, step):
         r1 = min(h, r0 + step)
-        col = np.empty((cin, 3, 3, r1 - r0, wd), F32)
-        for ky in range(3):
-            for kx in range(3):
-                col[:, ky, kx] = xp[:, r0 + ky:r1 + ky, kx:kx + wd]
-        band = wmat @ col.reshape(cin * 9, (r1 - r0) * wd)
-        out[:, r0:r1] = band.reshape(cout, r1 - r0, wd)
+        col = _scratch('col', (cin, 3, 3, r1 - r0, wd))
+
+        def im2col(c0, c1):
+            for ky in range(3):
+                for kx in range(3):
+                    col[c0:c1, ky, kx] = xp[c0:c1, r0 + ky:r1 + ky, kx:kx + wd]
+        _over_channels(im2col, cin)
+        if r0 == 0 and r1 == h:
+            np.matmul(wmat, col.reshape(cin * 9, h * wd), out=out.reshape(cout, h * wd))
+        else:
+            band = _scratch('band', (cout, (r1 - r0) * wd))
+            np.matmul(wmat, col.reshape(cin * 9, (r1 - r0) * wd), out=band)
+            out[:, r0:r1] = band.reshape(cout, r1 - r0, wd)
     out += b.reshape(cout, 1, 1)
     return out
 
@@ -117,15 +159,22 @@ def conv3x3_backward_data(dy, w):
     cout, h, wd = dy.shape
     cin = w.shape[1]
     wmat_t = np.ascontiguousarray(w.reshape(cout, cin * 9).T)
-    dxp = np.zeros((cin, h + 2, wd + 2), F32)
+    dxp = _scratch('dxp', (cin, h + 2, wd + 2))
+    dxp[...] = 0
     step = _band_rows(cin * 9, wd, h)
     for r0 in range(0, h, step):
         r1 = min(h, r0 + step)
-        col = (wmat_t @ np.ascontiguousarray(dy[:, r0:r1]).reshape(cout, (r1 - r0) * wd))
+        top = dy.reshape(cout, h * wd) if (r0 == 0 and r1 == h and dy.flags.c_contiguous) else \
+            np.ascontiguousarray(dy[:, r0:r1]).reshape(cout, (r1 - r0) * wd)
+        col = _scratch('col', (cin * 9, (r1 - r0) * wd))
+        np.matmul(wmat_t, top, out=col)
         col = col.reshape(cin, 3, 3, r1 - r0, wd)
-        for ky in range(3):
-            for kx in range(3):
-                dxp[:, r0 + ky:r1 + ky, kx:kx + wd] += col[:, ky, kx]
+
+        def col2im(c0, c1):
+            for ky in range(3):
+                for kx in range(3):
+                    dxp[c0:c1, r0 + ky:r1 + ky, kx:kx + wd] += col[c0:c1, ky, kx]
+        _over_channels(col2im, cin)
     return np.ascontiguousarray(dxp[:, 1:-1, 1:-1])
 
 

@@ -11,6 +11,9 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    if os.environ.get('ST2_ORACLE_MALLOPT', '1') != '0':
+        import oracle
+        oracle.keep_freed_memory()      # the oracle's blob-sized numpy temporaries: reuse the heap instead of mmap / page-fault / munmap
 
 
 @pytest.fixture(scope='session')
