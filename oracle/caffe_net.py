@@ -182,8 +182,20 @@ def bf16_round(a):
     """fp32 -> bf16 -> fp32 with round-to-nearest-even (no NaN/inf handling: blobs are finite).  Used to
     emulate the bf16 feature path (BASELINE config 3): conv OPERANDS rounded, products/accumulation fp32."""
     u = np.ascontiguousarray(a, F32).view(np.uint32)
-    r = (u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))) & np.uint32(0xFFFF0000)
-    return r.view(F32)
+    shape = u.shape
+    if u.ndim == 0 or u.size < (1 << 16):
+        return ((u + (np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1)))) & np.uint32(0xFFFF0000)).view(F32)
+    u = u.reshape(-1, shape[-1])
+    r = np.empty_like(u)
+
+    def part(c0, c1):                       # r = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000, slab by slab, one temporary
+        t = u[c0:c1] >> np.uint32(16)
+        t &= np.uint32(1)
+        t += np.uint32(0x7FFF)
+        t += u[c0:c1]
+        np.bitwise_and(t, np.uint32(0xFFFF0000), out=r[c0:c1])
+    _over_channels(part, u.shape[0])
+    return r.view(F32).reshape(shape)
 
 
 def _windows(x, fill):
