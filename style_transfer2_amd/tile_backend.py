@@ -93,16 +93,18 @@ class HipTileBackend:
         """One RCCL communicator for this context (unique_id: the 128 bytes of st_comm_unique_id from rank 0)."""
         check(self.lib.st_comm_init(self.ctx, bytes(unique_id), int(rank), int(world)))
 
-    def comm_init_callbacks(self, dist, rank, world):
-        """Host-staged transport over a torch.distributed (gloo) group in place of RCCL: the tests run several ranks on one GPU."""
+    def comm_init_host(self, rank, world, allreduce, exchange):
+        """Host-staged transport in place of RCCL (tests: several ranks share one GPU).  `allreduce(values)` sums a float32 numpy
+        array over the ranks in place; `exchange(sends, recvs)` delivers sends = [(peer, float32 array)] and fills
+        recvs = [(peer, float32 array to fill)].  The engine calls them from st_tile_step with its stream drained."""
         device = self.device
 
-        def allreduce(_user, ptr, n):
+        def on_allreduce(_user, ptr, n):
             try:
                 t = dev_tensor(ptr, (n,), device)
-                h = t.cpu()
-                dist.all_reduce(h)
-                t.copy_(h)
+                h = t.cpu().numpy()
+                allreduce(h)
+                t.copy_(torch.from_numpy(h))
                 torch.cuda.synchronize(device)
                 return 0
             except Exception:               # noqa: BLE001 (reported through the status code)
@@ -110,28 +112,35 @@ class HipTileBackend:
                 traceback.print_exc()
                 return 1
 
-        def exchange(_user, ns, speer, sbuf, scount, nr, rpeer, rbuf, rcount):
+        def on_exchange(_user, ns, speer, sbuf, scount, nr, rpeer, rbuf, rcount):
             try:
-                ops, stage = [], []
-                for i in range(ns):
-                    ops.append(dist.P2POp(dist.isend, dev_tensor(sbuf[i], (scount[i],), device).cpu(), speer[i]))
-                for j in range(nr):
-                    h = torch.empty(rcount[j], dtype=torch.float32)
-                    stage.append((dev_tensor(rbuf[j], (rcount[j],), device), h))
-                    ops.append(dist.P2POp(dist.irecv, h, rpeer[j]))
-                if ops:
-                    for req in dist.batch_isend_irecv(ops):
-                        req.wait()
-                for t, h in stage:
-                    t.copy_(h)
+                sends = [(int(speer[i]), dev_tensor(sbuf[i], (scount[i],), device).cpu().numpy()) for i in range(ns)]
+                recvs = [(int(rpeer[j]), np.empty(rcount[j], F32)) for j in range(nr)]
+                exchange(sends, recvs)
+                for j, (_, h) in enumerate(recvs):
+                    dev_tensor(rbuf[j], (rcount[j],), device).copy_(torch.from_numpy(h))
                 torch.cuda.synchronize(device)
                 return 0
             except Exception:               # noqa: BLE001
                 import traceback
                 traceback.print_exc()
                 return 1
-        self._callbacks = (capi.ALLREDUCE_FN(allreduce), capi.EXCHANGE_FN(exchange))       # keep the thunks alive
+        self._callbacks = (capi.ALLREDUCE_FN(on_allreduce), capi.EXCHANGE_FN(on_exchange))       # keep the thunks alive
         check(self.lib.st_comm_callbacks(self.ctx, int(rank), int(world), self._callbacks[0], self._callbacks[1], None))
+
+    def comm_init_callbacks(self, dist, rank, world):
+        """comm_init_host over a torch.distributed (gloo) group: one process per rank."""
+        def allreduce(values):
+            t = torch.from_numpy(values)
+            dist.all_reduce(t)
+
+        def exchange(sends, recvs):
+            ops = [dist.P2POp(dist.isend, torch.from_numpy(h), peer) for peer, h in sends]
+            ops += [dist.P2POp(dist.irecv, torch.from_numpy(h), peer) for peer, h in recvs]
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+        self.comm_init_host(rank, world, allreduce, exchange)
 
     def comm_init_solo(self, rank, world):
         """ONE rank of a larger grid alone on a GPU (timing the per-rank compute of a multi-GPU run): the all-reduces see one rank,

@@ -666,6 +666,106 @@ def test_tiled_multi_rank_on_one_gpu_matches_oracle(rows, cols, fused):
     assert np.allclose(full, ref[-1][0], rtol=0, atol=0.5) or np.mean(np.abs(full - ref[-1][0]) > 0.5) < 0.02
 
 
+class ThreadFabric:
+    """In-process transport for HipTileBackend.comm_init_host: every rank is a thread of this process (a GPU box admits six
+    processes on its card; BASELINE configs[4] has eight ranks).  All-reduce = sum in rank order behind a barrier; exchange =
+    one FIFO mailbox per (source, destination)."""
+
+    def __init__(self, world, timeout=120.0):
+        import threading
+        self.world, self.timeout = world, timeout
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.cond = threading.Condition()
+        self.mail = {}
+        self.reduces = self.messages = 0
+
+    def allreduce(self, rank, values):
+        self.slots[rank] = values.copy()
+        self.barrier.wait(self.timeout)
+        total = self.slots[0].copy()
+        for r in range(1, self.world):
+            total += self.slots[r]
+        self.barrier.wait(self.timeout)             # every rank has read the slots before anyone overwrites one
+        values[:] = total
+        if rank == 0:
+            self.reduces += 1
+
+    def exchange(self, rank, sends, recvs):
+        import time
+        with self.cond:
+            for peer, h in sends:
+                self.mail.setdefault((rank, peer), []).append(h.copy())
+                self.messages += 1
+            self.cond.notify_all()
+            deadline = time.time() + self.timeout
+            for peer, h in recvs:
+                while not self.mail.get((peer, rank)):
+                    if not self.cond.wait(max(0.0, deadline - time.time())) and time.time() >= deadline:
+                        raise TimeoutError('rank %d: nothing from rank %d' % (rank, peer))
+                h[:] = self.mail[(peer, rank)].pop(0)
+
+
+@pytest.mark.parametrize('precision,loss_rtol', [('fp32', 1e-4), ('bf16', 5e-3)])
+def test_fused_tile_step_on_the_eight_rank_2x4_grid_matches_oracle(precision, loss_rtol):
+    """BASELINE configs[4]'s layout -- 2 x 4 windows, corner and edge ranks with three and five grid neighbours -- on the HIP path:
+    eight engine contexts in this process, one thread each, every iteration one st_tile_step per rank whose all-reduces and strip
+    exchanges cross the ranks through ThreadFabric.  The stitched iterates against the single-process CPU oracle."""
+    import threading
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    rows, cols, h, w, steps = 2, 4, 64, 128, 3
+    world = rows * cols
+    content, style, init = _tiled_images(h, w)
+    net_params = oracle.he_init_weights(TILED_TOPO, 0, 0.1)
+    cpu = oracle.TransferOracle(oracle.NetOracle(TILED_TOPO, net_params, operands='bf16' if precision == 'bf16' else 'fp32'))
+    cpu.set_input(init); cpu.set_content(content); cpu.set_style(style); cpu.reset()
+    cpu.set_weights(TILED_WEIGHTS, TILED_PARAMS); cpu.set_optimizer('adam', 10)
+    assert cpu.start()
+    ref = []
+    for _ in range(steps):
+        img, tr = cpu.step()
+        ref.append((np.asarray(img, F32).copy(), dict(tr)))
+    grid = tiling.TileGrid(h, w, rows, cols, TILED_TOPO, 5)
+    fabric = ThreadFabric(world)
+    ranks = []
+    for r in range(world):
+        backend = HipTileBackend(net_params, grid, r, content, style, init, TILED_WEIGHTS, TILED_PARAMS, step_size=10,
+                                 topology=TILED_TOPO, precision=precision)
+        backend.comm_init_host(r, world, lambda v, r=r: fabric.allreduce(r, v), lambda s, rc, r=r: fabric.exchange(r, s, rc))
+        ranks.append(tiled.FusedTiledTransfer(grid, r, backend))
+    neighbours = sorted(len(tiled.fused_plans(grid, r)[tiled.PLAN_OVERLAP]) for r in range(world))
+    assert neighbours == [3, 3, 3, 3, 5, 5, 5, 5]
+    out, errors = [None] * world, []
+
+    def run(r):
+        try:
+            res = []
+            for _ in range(steps):
+                vals = ranks[r].step()
+                res.append((ranks[r].tile_image(), vals))
+            out[r] = res
+        except Exception as e:          # noqa: BLE001
+            errors.append((r, repr(e)))
+            fabric.barrier.abort()
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors and all(o is not None for o in out), errors
+    assert fabric.reduces >= 2 * steps and fabric.messages >= 3 * steps * sum(neighbours)
+    for step in range(steps):
+        full = np.zeros_like(ref[step][0])
+        for r in range(world):
+            t = grid.tiles[r]
+            full[t.y0:t.y1, t.x0:t.x1] = out[r][step][0]
+            assert np.isclose(out[r][step][1][-2], ref[step][1]['loss'], rtol=loss_rtol), (step, r)
+            assert np.isclose(out[r][step][1][-1], ref[step][1]['grad'], rtol=10 * loss_rtol), (step, r)
+            assert np.array_equal(np.asarray(out[r][step][1]), np.asarray(out[0][step][1]))    # every rank derives the same trace from the reduced sums
+        assert np.mean((full - ref[step][0]) ** 2) <= 1.0, step
+
+
 def _tiled_vgg_rank(rank, world, port, steps, h, w, q, fused=False, precision='fp32'):
     import os
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
