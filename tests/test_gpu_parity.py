@@ -706,12 +706,36 @@ class ThreadFabric:
                 h[:] = self.mail[(peer, rank)].pop(0)
 
 
+def _run_ranks_as_threads(ranks, steps, fabric):
+    """`steps` iterations of every FusedTiledTransfer in `ranks`, one thread per rank; [(tile image, trace values)] per rank."""
+    import threading
+    world = len(ranks)
+    out, errors = [None] * world, []
+
+    def run(r):
+        try:
+            res = []
+            for _ in range(steps):
+                vals = ranks[r].step()
+                res.append((ranks[r].tile_image(), vals))
+            out[r] = res
+        except Exception as e:          # noqa: BLE001
+            errors.append((r, repr(e)))
+            fabric.barrier.abort()
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors and all(o is not None for o in out), errors
+    return out
+
+
 @pytest.mark.parametrize('precision,loss_rtol', [('fp32', 1e-4), ('bf16', 5e-3)])
 def test_fused_tile_step_on_the_eight_rank_2x4_grid_matches_oracle(precision, loss_rtol):
     """BASELINE configs[4]'s layout -- 2 x 4 windows, corner and edge ranks with three and five grid neighbours -- on the HIP path:
     eight engine contexts in this process, one thread each, every iteration one st_tile_step per rank whose all-reduces and strip
     exchanges cross the ranks through ThreadFabric.  The stitched iterates against the single-process CPU oracle."""
-    import threading
     from style_transfer2_amd import tiled, tiling
     from style_transfer2_amd.tile_backend import HipTileBackend
     rows, cols, h, w, steps = 2, 4, 64, 128, 3
@@ -736,24 +760,7 @@ def test_fused_tile_step_on_the_eight_rank_2x4_grid_matches_oracle(precision, lo
         ranks.append(tiled.FusedTiledTransfer(grid, r, backend))
     neighbours = sorted(len(tiled.fused_plans(grid, r)[tiled.PLAN_OVERLAP]) for r in range(world))
     assert neighbours == [3, 3, 3, 3, 5, 5, 5, 5]
-    out, errors = [None] * world, []
-
-    def run(r):
-        try:
-            res = []
-            for _ in range(steps):
-                vals = ranks[r].step()
-                res.append((ranks[r].tile_image(), vals))
-            out[r] = res
-        except Exception as e:          # noqa: BLE001
-            errors.append((r, repr(e)))
-            fabric.barrier.abort()
-    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(300)
-    assert not errors and all(o is not None for o in out), errors
+    out = _run_ranks_as_threads(ranks, steps, fabric)
     assert fabric.reduces >= 2 * steps and fabric.messages >= 3 * steps * sum(neighbours)
     for step in range(steps):
         full = np.zeros_like(ref[step][0])
@@ -764,6 +771,53 @@ def test_fused_tile_step_on_the_eight_rank_2x4_grid_matches_oracle(precision, lo
             assert np.isclose(out[r][step][1][-1], ref[step][1]['grad'], rtol=10 * loss_rtol), (step, r)
             assert np.array_equal(np.asarray(out[r][step][1]), np.asarray(out[0][step][1]))    # every rank derives the same trace from the reduced sums
         assert np.mean((full - ref[step][0]) ** 2) <= 1.0, step
+
+
+@pytest.mark.parametrize('precision,loss_rtol', [('fp32', 2e-5), ('bf16', 5e-3)])
+def test_fused_tile_step_vgg19_on_the_2x4_grid_matches_the_single_gpu_engine(precision, loss_rtol):
+    """The eight ranks of BASELINE configs[4] with the real network: VGG19 to conv5_1 (80-px aprons), a 2048 x 4096 image cut 2 x 4 --
+    windows of 1104 x 1104 (corners) and 1104 x 1184 (the four ranks with neighbours on both sides), eight contexts on the one GPU,
+    st_tile_step per rank and iteration, transport = ThreadFabric.  Against the plain engine on the whole image (the largest whose
+    conv1 blobs stay below the 4 GiB the Winograd kernels index)."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    rows, cols, h, w, steps = 2, 4, 2048, 4096, 2
+    world = rows * cols
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (96, 80, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
+    weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
+               'deepdream': {}}
+    params = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+    net_params = oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0)
+    ref = st2.StyleTransfer(st2.HipModel(net_params, precision=precision))
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(weights, params)
+    ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
+    assert ref.start()
+    want = [ref.step() for _ in range(steps)]
+    want = [(np.asarray(i, F32).copy(), dict(t)) for i, t in want]
+    del ref
+    __import__('gc').collect()
+    grid = tiling.TileGrid(h, w, rows, cols, oracle.VGG19_TOPOLOGY, 17)
+    assert sorted((wd.y1 - wd.y0, wd.x1 - wd.x0) for wd in grid.windows) == [(1104, 1104)] * 4 + [(1104, 1184)] * 4
+    fabric = ThreadFabric(world, timeout=240.0)
+    ranks = []
+    for r in range(world):
+        backend = HipTileBackend(net_params, grid, r, content, style, init, weights, params, step_size=10, precision=precision)
+        backend.comm_init_host(r, world, lambda v, r=r: fabric.allreduce(r, v), lambda s, rc, r=r: fabric.exchange(r, s, rc))
+        ranks.append(tiled.FusedTiledTransfer(grid, r, backend))
+    out = _run_ranks_as_threads(ranks, steps, fabric)
+    for step in range(steps):
+        full = np.zeros_like(want[step][0])
+        for r in range(world):
+            t = grid.tiles[r]
+            full[t.y0:t.y1, t.x0:t.x1] = out[r][step][0]
+            assert np.isclose(out[r][step][1][-2], want[step][1]['loss'], rtol=loss_rtol), (step, r, out[r][step][1][-2], want[step][1]['loss'])
+            assert np.isclose(out[r][step][1][-1], want[step][1]['grad'], rtol=1e-3 if precision == 'fp32' else 3e-2), (step, r)
+        mse = float(np.mean((full.astype(np.float64) - want[step][0]) ** 2))
+        print('[tiled 2x4 %dx%d %s] step %d: loss %.9g vs %.9g, image MSE %.3g' % (h, w, precision, step, out[0][step][1][-2], want[step][1]['loss'], mse))
+        assert mse <= (0.25 if precision == 'fp32' else 1.0), (step, mse)
 
 
 def _tiled_vgg_rank(rank, world, port, steps, h, w, q, fused=False, precision='fp32'):
