@@ -431,6 +431,40 @@ def test_tiled_single_rank_equals_plain_engine():
         assert np.allclose(tt.tile_image(), img, rtol=0, atol=2e-3), i
 
 
+@pytest.mark.parametrize('h,w', [(4176, 2208), (4176, 2128)])
+def test_production_window_of_configs4_through_the_tile_phases_equals_the_plain_engine(h, w):
+    """The two window shapes a rank of the 8192^2 / 2 x 4 job holds -- 4176 x 2208 (a column with neighbours on both sides; levels
+    2208 .. 138 wide) and 4176 x 2128 (an edge column; levels 2128, 1064, 532, 266, 133: the any-width conv variants) -- as a 1 x 1
+    grid through st_tile_step (solo transport), VGG19 fp32, against the plain engine on the same image: one Adam iteration."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (96, 80, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
+    weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
+               'deepdream': {}}
+    params = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+    net_params = oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0)
+    ref = st2.StyleTransfer(st2.HipModel(net_params))
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(weights, params)
+    ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
+    assert ref.start()
+    img, tr = ref.step()
+    img = np.asarray(img, F32).copy()
+    del ref
+    __import__('gc').collect()
+    grid = tiling.TileGrid(h, w, 1, 1, oracle.VGG19_TOPOLOGY, 17)
+    backend = HipTileBackend(net_params, grid, 0, content, style, init, weights, params, step_size=10)
+    backend.comm_init_solo(0, 1)
+    tt = tiled.FusedTiledTransfer(grid, 0, backend)
+    vals = tt.step()
+    assert np.isclose(vals[-2], tr['loss'], rtol=1e-5) and np.isclose(vals[-1], tr['grad'], rtol=1e-4), (vals[-2], tr['loss'])
+    mse = float(np.mean((tt.tile_image().astype(np.float64) - img) ** 2))
+    print('[window %dx%d] loss %.9g vs %.9g, image MSE %.3g' % (h, w, vals[-2], tr['loss'], mse))
+    assert mse <= 0.05
+
+
 def test_fused_tile_step_on_a_one_rank_rccl_communicator_equals_the_plain_engine(monkeypatch):
     """st_tile_step (every phase and collective enqueued by the engine) on a 1 x 1 grid with a REAL RCCL communicator of one rank:
     st_comm_unique_id / st_comm_init, ncclAllReduce on the phase buffers, and -- test hook ST2_COMM_SELF_VIA_RCCL -- the ring's
