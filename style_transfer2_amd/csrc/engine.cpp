@@ -594,6 +594,8 @@ int st_destroy(st_ctx* c)
     dfree(c->tile.p1); dfree(c->tile.p2); dfree(c->tile.p3); dfree(c->tile.pd); dfree(c->tile.wgrad);
     dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->lb_part); dfree(c->hwc_dev);
     if (c->lb_dev) (void)hipFree(c->lb_dev);
+    if (c->lb_gram) (void)hipFree(c->lb_gram);
+    dfree(c->lb_gpart); dfree(c->lb_dots);
     if (c->stage_dev) (void)hipFree(c->stage_dev);
     if (c->trace_sums) (void)hipFree(c->trace_sums);
     if (c->trace_host) (void)hipHostFree(c->trace_host);

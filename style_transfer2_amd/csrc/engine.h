@@ -165,6 +165,10 @@ struct st_ctx {
     LbfgsDev* lb_dev = nullptr;                    // history bookkeeping (pair count, ring order, s.y, y.y): device-resident
     bool lb_clear = true;                          // history to be emptied before the next step (reset / objective_changed)
     float* lb_part = nullptr;                      // [4][kMaxPartials] partial sums of the chained dot products
+    LbfgsGram* lb_gram = nullptr;                  // Gram form (lbfgs.hip, second half): inner-product matrix + coefficients
+    float* lb_gpart = nullptr;                     // [kLbGramRows][kMaxPartials] partial sums of the inner-product pass
+    float* lb_dots = nullptr;                      // test hook: [kLbNB][kLbNB] pairwise inner products
+    bool lb_gram_form = false;                     // form of the current history (decided while it is empty)
     float* g_cur = nullptr; float* pvec = nullptr;
     bool have_cur = false;
     float last_loss = 0.f;

@@ -12,7 +12,22 @@ int lbfgs_alloc(st_ctx* c)
         if (!c->hs[i]) ST_TRY(dmalloc(&c->hs[i], n3));
         if (!c->hy[i]) ST_TRY(dmalloc(&c->hy[i], n3));
     }
+    if (!c->lb_gram) {
+        HIP_TRY(hipMalloc((void**)&c->lb_gram, sizeof(LbfgsGram)));
+        HIP_TRY(hipMemset(c->lb_gram, 0, sizeof(LbfgsGram)));
+    }
+    if (!c->lb_gpart) ST_TRY(dmalloc(&c->lb_gpart, (size_t)kLbGramRows * kMaxPartials));
     return ST_OK;
+}
+
+// Gram form (two passes over the history per step) where the objective is approximate anyway -- the bf16 feature path --, the
+// chain (the reference's operation order, fp32 axpy by axpy) otherwise; ST2_LBFGS_FORM=chain|gram overrides.  Decided while the
+// history is empty: the two forms keep different state.
+static bool lbfgs_wants_gram(const st_ctx* c)
+{
+    const char* e = getenv("ST2_LBFGS_FORM");
+    if (e && *e) return e[0] == 'g' || e[0] == 'G';
+    return c->bf16;
 }
 
 LbfgsArgs lbfgs_args(st_ctx* c, int apply)
@@ -20,6 +35,7 @@ LbfgsArgs lbfgs_args(st_ctx* c, int apply)
     LbfgsArgs a{};
     for (int i = 0; i < kLbfgsSlots; ++i) { a.v.s[i] = c->hs[i]; a.v.y[i] = c->hy[i]; }
     a.st = c->lb_dev; a.part = c->lb_part; a.part2 = c->lb_part + 2 * kMaxPartials;
+    a.gm = c->lb_gram; a.gpart = c->lb_gpart;
     a.g = c->g_cur; a.p = c->pvec; a.x = c->x[c->cur];
     a.n = (size_t)3 * c->H * c->W; a.step = (float)c->step_size; a.apply = apply;
     return a;
@@ -35,20 +51,30 @@ int lbfgs_step(st_ctx* c)
     hipStream_t s = c->stream;
     if (c->lb_clear) {              // objective_changed / a new optimizer: sy = [], ss = [], ys = [] (optimizers.py:121-125)
         HIP_TRY(hipMemsetAsync(c->lb_dev, 0, sizeof(LbfgsDev), s));
+        HIP_TRY(hipMemsetAsync(c->lb_gram, 0, sizeof(LbfgsGram), s));
         c->lb_clear = false;
+        c->lb_gram_form = lbfgs_wants_gram(c);
+        if (c->lb_gram_form) c->have_cur = false;      // (the gradient's inner products belong to the history that was just dropped)
     }
+    const bool gram = c->lb_gram_form;
     if (!c->have_cur) {             // optimizers.py:64-65
         ST_TRY(eval_objective(c, x, true, c->g_cur, false, nullptr));
         c->have_cur = true;
+        if (gram) {
+            ProfScope ps(c, P_VECTOR, 0, 4.0 * n);
+            HIP_TRY(launch_lbfgs_gram_pass(lbfgs_args(c, 1), nullptr, 0, s));
+        }
     }
     {   // s = -step * inv_hv(grad) ; x += s          (optimizers.py:68-69, 89-108)
-        ProfScope ps(c, P_VECTOR, 0, 4.0 * n * (8.0 * kLbfgsCorr + 3.0));
-        HIP_TRY(launch_lbfgs_two_loop(lbfgs_args(c, 1), s));
+        ProfScope ps(c, P_VECTOR, 0, 4.0 * n * (gram ? 2.0 * kLbfgsCorr + 4.0 : 8.0 * kLbfgsCorr + 3.0));
+        if (gram) HIP_TRY(launch_lbfgs_gram_apply(lbfgs_args(c, 1), s));
+        else HIP_TRY(launch_lbfgs_two_loop(lbfgs_args(c, 1), s));
     }
     ST_TRY(eval_objective(c, x, true, c->grad, false, nullptr));       // new loss / grad (optimizers.py:72)
     {   // y = grad - self.grad ; store_curvature_pair(s, y)            (optimizers.py:73-87)
-        ProfScope ps(c, P_VECTOR, 0, 4.0 * n * 4.0);
-        HIP_TRY(launch_lbfgs_pair(lbfgs_args(c, 1), c->grad, 0, s));
+        ProfScope ps(c, P_VECTOR, 0, 4.0 * n * (gram ? 2.0 * kLbfgsCorr + 4.0 : 4.0));
+        if (gram) HIP_TRY(launch_lbfgs_gram_pass(lbfgs_args(c, 1), c->grad, 1, s));
+        else HIP_TRY(launch_lbfgs_pair(lbfgs_args(c, 1), c->grad, 0, s));
     }
     std::swap(c->g_cur, c->grad);
     return ST_OK;
@@ -313,7 +339,23 @@ int st_lbfgs_inv_hv(st_ctx* c, int n_pairs, const float* const* s_vecs, const fl
     HIP_TRY(hipMemcpyAsync(&host, c->lb_dev, sizeof host, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (host.count != n_pairs) return fail(ST_ERR_ARG, "%d of %d pairs failed the s.y > 1e-10 gate", n_pairs - host.count, n_pairs);
-    HIP_TRY(launch_lbfgs_two_loop(lbfgs_args(c, 0), st));
+    if (lbfgs_wants_gram(c)) {      // the Gram form of the same recursion: its matrix from pairwise inner products taken one by one
+        const size_t n3 = (size_t)3 * c->H * c->W;
+        if (!c->lb_dots) ST_TRY(dmalloc(&c->lb_dots, (size_t)kLbNB * kLbNB));
+        HIP_TRY(hipMemsetAsync(c->lb_dots, 0, sizeof(float) * kLbNB * kLbNB, st));
+        std::vector<std::pair<int, const float*>> basis;
+        for (int k = 0; k < n_pairs; ++k) { basis.push_back({k, c->hs[k]}); basis.push_back({kLbfgsSlots + k, c->hy[k]}); }
+        basis.push_back({2 * kLbfgsSlots, c->g_cur});
+        for (size_t i = 0; i < basis.size(); ++i)
+            for (size_t j = i; j < basis.size(); ++j) {
+                HIP_TRY(launch_vec_dot(basis[i].second, basis[j].second, n3, c->lb_part, c->lb_dots + basis[i].first * kLbNB + basis[j].first, st));
+                if (i != j) HIP_TRY(hipMemcpyAsync(c->lb_dots + basis[j].first * kLbNB + basis[i].first, c->lb_dots + basis[i].first * kLbNB + basis[j].first,
+                                                  sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+        HIP_TRY(launch_lbfgs_gram_load(lbfgs_args(c, 0), c->lb_dots, st));
+        HIP_TRY(launch_lbfgs_gram_apply(lbfgs_args(c, 0), st));
+    } else
+        HIP_TRY(launch_lbfgs_two_loop(lbfgs_args(c, 0), st));
     HIP_TRY(hipMemcpyAsync(out_p, c->pvec, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return ST_OK;

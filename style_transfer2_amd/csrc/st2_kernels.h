@@ -283,10 +283,22 @@ struct LbfgsDev {                               // lives in device memory; zero 
     double alpha[kLbfgsSlots];                  // first-loop coefficients of the current recursion
     double last_sy;                             // s.y of the last candidate pair (kept or not)
 };
+// Gram form of the same recursion (lbfgs.hip, second half): the search direction lives in the span of the kept s and y
+// vectors and the gradient, so the two-loop recursion runs on 2 k + 1 COEFFICIENTS against the matrix of their inner
+// products; the vectors are streamed twice per step (one pass of inner products, one linear combination) instead of 4 k times.
+constexpr int kLbNB = 2 * kLbfgsSlots + 1;      // basis ids: s of slot i = i, y of slot i = kLbfgsSlots + i, the gradient = 2 kLbfgsSlots
+constexpr int kLbGramRows = 2 * kLbNB;          // partial-sum rows of the inner-product pass: g.b (kLbNB) then y.b (kLbNB)
+struct LbfgsGram {                              // lives in device memory
+    double B[kLbNB][kLbNB];                     // inner products of the live basis vectors (entries of dead ids are stale, never read)
+    double delta[kLbNB];                        // inv_hv(g) = sum delta[id] b_id
+    double r0;                                  // empty history: inv_hv(g) = g / r0
+};
 struct LbfgsVecs { float* s[kLbfgsSlots]; float* y[kLbfgsSlots]; };
 struct LbfgsArgs {
     LbfgsVecs v;
     LbfgsDev* st;
+    LbfgsGram* gm;          // Gram form only
+    float* gpart;           // Gram form only: [kLbGramRows][kMaxPartials]
     float* part;            // [2][kMaxPartials] ping-pong partial sums of the chained dot products
     float* part2;           // [2][kMaxPartials] partial sums of s.y and y.y of the candidate pair
     const float* g;         // gradient at the current x (self.grad)
@@ -302,6 +314,14 @@ hipError_t launch_lbfgs_two_loop(const LbfgsArgs& a, hipStream_t s);
 // candidate pair in the free slot: mode 0: y = g_new - a.g; mode 1: y already stored.  Then the s.y > 1e-10 gate,
 // the commit into the ring and the eviction of the oldest pair, all on the device.
 hipError_t launch_lbfgs_pair(const LbfgsArgs& a, const float* g_new, int mode, hipStream_t s);
+// Gram form.  launch_lbfgs_gram_pass: mode 0: inner products of a.g with the kept vectors (a fresh gradient, no candidate pair);
+// mode 1: y = g_new - a.g into the free slot, inner products of y and of g_new with the kept vectors, the candidate s and y;
+// then (one workgroup) the bookkeeping: rows of B, the s.y > 1e-10 gate / commit / eviction, and the coefficient recursion.
+// launch_lbfgs_gram_apply: p = sum delta b, then s = -step p into the free slot and x += s (a.apply) or p left in a.p.
+hipError_t launch_lbfgs_gram_pass(const LbfgsArgs& a, const float* g_new, int mode, hipStream_t s);
+hipError_t launch_lbfgs_gram_apply(const LbfgsArgs& a, hipStream_t s);
+// test hook support: B from a table of all pairwise inner products (float [kLbNB][kLbNB], row-major), then the recursion
+hipError_t launch_lbfgs_gram_load(const LbfgsArgs& a, const float* dots, hipStream_t s);
 // z = a*x + b*y  (host scalars; y may be nullptr)
 hipError_t launch_lincomb(float a, const float* x, float b, const float* y, float* z, size_t n, hipStream_t s);
 // tile-sharded L-BFGS: *out = sum a[i] b[i] over this rank's n elements (part: kMaxPartials floats of scratch); y = alpha x + y

@@ -14,6 +14,15 @@ pytestmark = pytest.mark.gpu
 F32 = np.float32
 
 
+@pytest.fixture(params=['chain', 'gram'], autouse=True)
+def lbfgs_form(request, monkeypatch):
+    """Every test below runs on both forms of the device recursion (lbfgs.hip): the chain of fused axpy + dot links in the
+    reference's operation order (the fp32 default) and the Gram form -- coefficients against the matrix of inner products, two
+    passes over the history per step (the bf16 feature path's default).  Same mathematics, different rounding."""
+    monkeypatch.setenv('ST2_LBFGS_FORM', request.param)
+    return request.param
+
+
 def _history(rng, shape, n_pairs):
     """(s, y, s.y) triples with positive curvature: y = D s + noise for a positive diagonal D."""
     d = (0.5 + rng.rand(*shape)).astype(F32)
@@ -27,7 +36,7 @@ def _history(rng, shape, n_pairs):
 
 @pytest.mark.parametrize('h,w', [(15, 17), (64, 96), (225, 300)])      # 3hw % 4 = 1, 0, 0: the scalar tail and the float4 body
 @pytest.mark.parametrize('n_pairs', [0, 1, 2, 5, 10])
-def test_device_two_loop_matches_oracle_inv_hessian_times(h, w, n_pairs):
+def test_device_two_loop_matches_oracle_inv_hessian_times(h, w, n_pairs, lbfgs_form):
     rng = np.random.RandomState(100 * n_pairs + h)
     shape = (1, 3, h, w)
     pairs = _history(rng, shape, n_pairs)
@@ -39,6 +48,7 @@ def test_device_two_loop_matches_oracle_inv_hessian_times(h, w, n_pairs):
     eng.set_input(np.zeros((h, w, 3), np.uint8))
     got = eng.lbfgs_inv_hv([(s, y) for s, y, _ in pairs], g)
     assert got.shape == want.shape
+    print('[inv_hv %s] %dx%d, %d pairs: rel-L2 %.2e' % (lbfgs_form, h, w, n_pairs, rel_l2(got, want)))
     assert rel_l2(got, want) <= 1e-5, rel_l2(got, want)
     again = eng.lbfgs_inv_hv([(s, y) for s, y, _ in pairs], g)
     assert np.array_equal(again, got)                                  # fixed-order reductions: bitwise reproducible
