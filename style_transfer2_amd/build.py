@@ -27,6 +27,7 @@ SOURCES = (
     ('style16.hip', ()),
     ('gram16.hip', ()),
     ('conv3x3_dgrad_first.hip', ()),
+    ('conv3x3_first_split.hip', ()),
     ('engine.cpp', ('-x', 'hip')),
     ('engine_objective.cpp', ('-x', 'hip')),
     ('engine_step.cpp', ('-x', 'hip')),

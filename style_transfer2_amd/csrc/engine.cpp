@@ -227,7 +227,10 @@ int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
                   else { if (next16 && L.cout % 8 == 0) { p.out16 = a.data16[i]; packed = true; }      // the epilogue writes the bf16 copy too
                          // lean: conv1_1's fp32 blob is written only if something reads it (conv1_2, the ReLU mask and a style term take the copy)
                          if (lean && packed && conv_next16 && i < last && !blob_needs32(c, a, i)) { p.out = nullptr; a.has32[i] = 0; }
-                         HIP_TRY(launch_conv3x3(p, c->stream)); } }
+                         // bf16 path: the image keeps its fp32 precision (three-way bf16 split, six partial products on the bf16 matrix cores)
+                         if (c->bf16 && L.w_split && conv_first_split_ok(p.K, p.M, p.H, p.W))
+                             HIP_TRY(launch_conv3x3_first_split(p.in, L.w_split, p.out, p.out16, p.K, p.M, p.H, p.W, p.relu, c->stream));
+                         else HIP_TRY(launch_conv3x3(p, c->stream)); } }
                 if (next16 && !packed) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
             }
         } else if (i == pooled_by_conv) {
@@ -575,7 +578,7 @@ int st_destroy(st_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 2; ++i) if (c->gexec[i]) { (void)hipGraphExecDestroy(c->gexec[i]); c->gexec[i] = nullptr; }
     dfree(c->adam_dyn);
-    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree(L.u_fwd); dfree(L.u_bwd); }
+    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree16(L.w_split); dfree(L.u_fwd); dfree(L.u_bwd); }
     dfree16(c->diff16A); dfree16(c->diff16B);
     act_free(c->act);
     for (int i = 0; i < 2; ++i) dfree(c->x[i]);
@@ -629,7 +632,7 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
         pack_conv_weights_fwd(w, L.cout, L.cin, pf.data());
         pack_conv_weights_dgrad(w, L.cout, L.cin, pb.data());
         if (bias) memcpy(bp.data(), bias, L.cout * sizeof(float));
-        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree(L.u_fwd); dfree(L.u_bwd);
+        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree16(L.w_split); dfree(L.u_fwd); dfree(L.u_bwd);
         for (int dir = 0; dir < 2; ++dir) {   // Winograd packs for the directions the Winograd kernel can take (any image size)
             const int K = dir ? L.cout : L.cin, M = dir ? L.cin : L.cout;
             if (!conv_wino_ok(K, M, 4, 4)) continue;
@@ -647,6 +650,12 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
             ST_TRY(dmalloc16(&L.w16_fwd, n16f)); ST_TRY(dmalloc16(&L.w16_bwd, n16b));
             HIP_TRY(hipMemcpy(L.w16_fwd, hf.data(), n16f * 2, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(L.w16_bwd, hb.data(), n16b * 2, hipMemcpyHostToDevice));
+        }
+        if (L.cin == 3 && L.cout % 32 == 0) {   // first layer on the bf16 path: split weights for conv3x3_first_split.hip
+            std::vector<unsigned short> hs(conv_first_split_pack_elems(L.cout));
+            pack_conv_first_split(w, bias, L.cout, L.cin, hs.data());
+            ST_TRY(dmalloc16(&L.w_split, hs.size()));
+            HIP_TRY(hipMemcpy(L.w_split, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
         }
         ST_TRY(dmalloc(&L.w_fwd, nf)); ST_TRY(dmalloc(&L.w_bwd, nb));
         ST_TRY(dmalloc(&L.w_raw, (size_t)L.cout * L.cin * 9)); ST_TRY(dmalloc(&L.bias, bp.size()));

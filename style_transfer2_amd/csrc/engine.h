@@ -46,6 +46,7 @@ struct Layer {
     int cin = 0, cout = 0;
     float *w_fwd = nullptr, *w_bwd = nullptr, *w_raw = nullptr, *w_raw_r = nullptr, *bias = nullptr;   // w_raw_r: w_raw rounded to bf16 values
     unsigned short *w16_fwd = nullptr, *w16_bwd = nullptr;       // bf16 packs (bf16 feature path)
+    unsigned short* w_split = nullptr;                           // first layer, bf16 path: three-way bf16 split of the weights (conv3x3_first_split.hip)
     float *u_fwd = nullptr, *u_bwd = nullptr;                    // Winograd F(2x2,3x3) packs (null: not eligible)
     bool loaded = false;
 };

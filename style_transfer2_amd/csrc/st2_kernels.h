@@ -71,6 +71,14 @@ bool conv_dgrad_first_quad_ok(int Cout, int Cin, int H, int W, const float* dy);
 hipError_t launch_conv3x3_dgrad_first_quad(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s);
 hipError_t launch_conv3x3_dgrad_first16(const unsigned short* dy16, const float* w_rounded, float* dx, const float* inject, int Cout, int Cin,
                                         int H, int W, hipStream_t s);
+// Forward of the first conv for the bf16 feature path (conv3x3_first_split.hip): fp32 operands split into three bf16 terms each, six exact
+// partial products on the bf16 matrix cores, fp32 accumulation -- fp32-grade results, HBM-bound.  wpk = pack_conv_first_split's output (the bias rides in it as a 28th tap).  Cin = 3.
+// Writes the fp32 blob (out, may be nullptr) and / or the bf16 channel-blocked copy (out16, may be nullptr).
+size_t conv_first_split_pack_elems(int Cout);
+void pack_conv_first_split(const float* w /*Cout, Cin, 3, 3*/, const float* bias /*Cout or nullptr*/, int Cout, int Cin, unsigned short* dst);
+bool conv_first_split_ok(int Cin, int Cout, int H, int W);
+hipError_t launch_conv3x3_first_split(const float* x, const unsigned short* wpk, float* out, unsigned short* out16,
+                                      int Cin, int Cout, int H, int W, int relu, hipStream_t s);
 bool conv_dgrad_smallM_ok(int Cout, int Cin);
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
                                        int Cout, int Cin, int H, int W, hipStream_t s);

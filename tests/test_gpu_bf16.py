@@ -65,6 +65,34 @@ def test_single_conv_bf16_forward_and_dgrad(cin, cout, h, w, conv16_cfg):
     assert rel_l2(gpu.backward({'conv1_2': d}), cpu.backward({'conv1_2': d})) <= 5e-5
 
 
+@pytest.mark.parametrize('cout,h,w', [(64, 8, 32), (64, 15, 17), (32, 33, 70), (64, 225, 300), (96, 64, 96), (64, 1, 1)])
+def test_first_conv_on_split_operands_keeps_fp32_accuracy(cout, h, w, monkeypatch):
+    """conv1_1 on the bf16 feature path (conv3x3_first_split.hip): image and weights keep their fp32 precision -- each operand split
+    into three bf16 terms, six exact partial products on the bf16 matrix cores, fp32 sums.  Against the fp32-operand restatement the
+    blob must be as close as the fp32-matrix-core kernel's (ST2_FIRST_SPLIT=0), far below a bf16 rounding of the operands; the
+    bf16 copy the next conv reads is the rounded blob either way."""
+    topo = (('conv', 'conv1_1', 3, cout), ('conv', 'conv1_2', cout, 16))
+    params = oracle.he_init_weights(topo, seed=cout + h, bias_std=0.3)
+    rng = np.random.RandomState(h * w + cout)
+    x = (rng.randint(0, 256, (1, 3, h, w)).astype(F32) - F32(120.0)) + rng.rand(1, 3, h, w).astype(F32)      # image-like, all 24 bits used
+    wgt, b = params['conv1_1']
+    ref = np.maximum(conv3x3_forward(x[0], wgt, b), 0)
+    got = {}
+    for split in ('1', '0'):
+        monkeypatch.setenv('ST2_FIRST_SPLIT', split)
+        gpu = st2.HipModel(params, topology=topo, precision='bf16-full')
+        f = gpu.forward(x, ['conv1_1', 'conv1_2'])
+        got[split] = (f['conv1_1'][0].copy(), f['conv1_2'][0].copy())
+    e_split, e_f32 = rel_l2(got['1'][0], ref), rel_l2(got['0'][0], ref)
+    e_bf16 = rel_l2(np.maximum(conv3x3_forward(bf16_round(x[0]), bf16_round(wgt), b), 0), ref)
+    print('[first conv %dx%d, %d ch] rel-L2 vs fp32 restatement: split %.2e, fp32 matrix cores %.2e, (bf16 operands would be %.2e)' % (
+        h, w, cout, e_split, e_f32, e_bf16))
+    assert e_split <= 3e-7 and e_split <= 2 * e_f32 + 1e-7
+    assert e_bf16 > 100 * e_split
+    # the next conv reads the bf16 copy written by the epilogue: equal blobs up to that rounding => close conv1_2 either way
+    assert rel_l2(got['1'][1], got['0'][1]) <= 2e-4
+
+
 def test_bf16_chain_with_pools_and_injections(conv16_cfg):
     """Multi-layer chain: bf16 copies written by the conv epilogue (out16), repacks after pools and of the
     injected top diff, masks and injections in the bf16 dgrad epilogue."""

@@ -11,6 +11,6 @@ import csv, glob
 f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.DictReader(open(f[0])))
 for r in rows:
-    if "lbfgs" in r["Name"]:
+    if "lbfgs" in r["Name"] or "first" in r["Name"] or "64x128_cc4" in r["Name"]:
         print("%-70s calls %5s avg %8.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
