@@ -18,6 +18,7 @@ LOAD_WIDTH = (
     ('conv3x3_wino_f32_128x128_anyw', 'mixed'),   # activations: dword LDS-DMA pieces; U stream: dwordx4
     ('conv3x3_wino_f32_64x256_anyw', 'mixed'),
     ('conv3x3_wino', 16),                         # raw_ptr_buffer_load_lds x4 (activations) + global_load_dwordx4 (U), float4 epilogue
+    ('conv3x3_first_split_k', 4),                 # the fp32 image, dword loads into the halo tile
     ('conv3x3_mfma', 16),                         # LDS-DMA dwordx4 for weights and activation tiles (fp32 and bf16 kernels)
     ('conv3x3_dgrad_first_f32q', 16), ('conv3x3_dgrad_first_bf16', 16), ('conv3x3_dgrad_first_f32', 4),
     ('conv3x3_dgrad_smallM16', 16), ('conv3x3_dgrad_smallM', 4),
