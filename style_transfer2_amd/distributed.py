@@ -1,7 +1,11 @@
 """Multi-GPU plumbing for the job fan-out (BASELINE config 4): one process per GPU, independent
 jobs, no data-path collective -- exactly how the reference scales (one app/worker pair per GPU,
-config.ini:3-4,10; router.py:67-84).  torch.distributed (RCCL on the GPU box, gloo in CPU tests) is
-used only to line the ranks up around the timed region and to take the max of their clocks."""
+config.ini:3-4,10; router.py:67-84).  torch.distributed is used only to line the ranks up around the
+timed region and to take the max of their clocks: two scalars per block of steps.  That control plane
+runs over gloo (host tensors) by default -- nothing on the data path crosses ranks, the process then
+holds ONE HIP runtime (the engine's; torch.cuda is never initialised), and it is the path the tests
+exercise; ST2_BENCH_BACKEND=nccl puts the same two collectives on RCCL.  The tile-sharded mode, whose
+iteration does exchange data, owns its RCCL communicator inside the engine (csrc/engine_comm.cpp)."""
 
 import os
 
@@ -29,7 +33,7 @@ class Group:
             import torch.distributed as dist
             # a rank that dies before the rendezvous must fail the others within minutes (bench.py's fan-out sets 120 s)
             timeout = datetime.timedelta(seconds=float(os.environ.get('ST2_RENDEZVOUS_TIMEOUT_S', '600')))
-            backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+            backend = backend or os.environ.get('ST2_BENCH_BACKEND', 'gloo')
             if backend == 'nccl':
                 torch.cuda.set_device(self.local_rank)
                 self.device = torch.device('cuda', self.local_rank)
