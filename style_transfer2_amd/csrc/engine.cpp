@@ -489,12 +489,19 @@ int set_input_common(st_ctx* c, int H, int W)
 int content_from_device(st_ctx* c, const float* xdev, int H, int W)
 {
     ST_TRY(act_ensure(c, c->act, H, W));
-    ST_TRY(forward_range(c, c->act, xdev, c->nb - 1));
+    // features of the blobs that carry a content weight NOW (every blob until the first st_set_weights, like worker.py:204-209);
+    // the others come from ensure_content_features if a later weight table asks for them
+    std::vector<char> used(c->nb, 0);
+    int deepest = -1;
+    for (const ActiveLayer& al : c->active) if (al.c) { used[al.blob] = 1; deepest = std::max(deepest, al.blob); }
+    if (deepest > 0) ST_TRY(forward_range(c, c->act, xdev, deepest));
     for (int i = 0; i < c->nb; ++i) {
+        if (!used[i]) { dfree(c->content_feat[i]); continue; }
         const size_t n = (size_t)c->act.C[i] * c->act.h[i] * c->act.w[i];
         if (c->cH != H || c->cW != W || !c->content_feat[i]) { dfree(c->content_feat[i]); ST_TRY(dmalloc(&c->content_feat[i], n)); }
-        HIP_TRY(hipMemcpyAsync(c->content_feat[i], c->act.data[i], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->content_feat[i], i == 0 ? xdev : c->act.data[i], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
     }
+    c->act.valid_to = -1;
     if (xdev != c->content_x) {                 // keep the preprocessed image itself (== blob "data")
         if (c->cH != H || c->cW != W || !c->content_x) { dfree(c->content_x); ST_TRY(dmalloc(&c->content_x, (size_t)3 * H * W)); }
         HIP_TRY(hipMemcpyAsync(c->content_x, xdev, (size_t)3 * H * W * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
@@ -502,6 +509,29 @@ int content_from_device(st_ctx* c, const float* xdev, int H, int W)
     c->cH = H; c->cW = W;
     c->have_content = true;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return ST_OK;
+}
+
+// The reference keeps the content features of EVERY blob (worker.py:204-209) because the weights may change later.  Here
+// st_set_weights drops the features of blobs without a content weight (11 of 12 GB for one window of the 8192^2 / 2x4 job) and
+// the preprocessed image is kept instead: should such a blob gain a content weight afterwards, its features are taken again by
+// the same forward (same kernels, same precision) before the next evaluation.
+int ensure_content_features(st_ctx* c)
+{
+    int need = -1;
+    for (const ActiveLayer& al : c->active) if (al.c && !c->content_feat[al.blob]) need = std::max(need, al.blob);
+    if (need < 0) return ST_OK;
+    if (!c->have_content || !c->content_x) return fail(ST_ERR_STATE, "content image missing");
+    ST_TRY(act_ensure(c, c->act, c->cH, c->cW));
+    if (need > 0) ST_TRY(forward_range(c, c->act, c->content_x, need));
+    for (const ActiveLayer& al : c->active) {
+        const int b = al.blob;
+        if (!al.c || c->content_feat[b]) continue;
+        const size_t n = (size_t)c->act.C[b] * c->act.h[b] * c->act.w[b];
+        ST_TRY(dmalloc(&c->content_feat[b], n));
+        HIP_TRY(hipMemcpyAsync(c->content_feat[b], b == 0 ? c->content_x : c->act.data[b], n * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
+    c->act.valid_to = -1;                      // (the activations are the content image's now)
     return ST_OK;
 }
 }  // namespace st2e

@@ -256,6 +256,7 @@ int stage_upload(st_ctx* c, const void* host, size_t bytes);
 int preprocess_into(st_ctx* c, const void* hwc, int H, int W, int is_u8, float* dst);
 int set_input_common(st_ctx* c, int H, int W);
 int content_from_device(st_ctx* c, const float* xdev, int H, int W);
+int ensure_content_features(st_ctx* c);           // features of content-weighted blobs dropped by st_set_weights: recompute from the kept image
 // ---------------------------------------------------------------------------------------- engine_objective.cpp
 int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad_out, bool adam, float* x_next);
 int read_trace(st_ctx* c, double* trace, float* loss);

@@ -16,6 +16,7 @@ int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad_out, b
         if (al.s && !c->have_style) return fail(ST_ERR_STATE, "style Gram matrices missing");
     }
     const bool lean = c->bf16 && c->lean && !c->tile.on;
+    ST_TRY(ensure_content_features(c));
     ST_TRY(forward_range(c, a, x, last, lean));
 
     std::vector<const float*> inj(c->nb, nullptr);
@@ -195,6 +196,14 @@ int st_set_weights(st_ctx* c, int n_rows, const int* blob_index, const float* co
     c->active.clear();
     for (const ActiveLayer& r : rows) if (r.c || r.s || r.d) c->active.push_back(r);
     c->tv_w = (float)params[0]; c->tv_pow = (float)params[1]; c->p_w = (float)params[2]; c->p_pow = (float)params[3];
+    // content features are kept only where a content weight reads them (ensure_content_features brings back what a later table needs)
+    if (c->have_content) {
+        std::vector<char> used(c->nb, 0);
+        for (const ActiveLayer& al : c->active) if (al.c) used[al.blob] = 1;
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int b = 0; b < c->nb; ++b) if (!used[b]) dfree(c->content_feat[b]);
+    }
     return ST_OK;
 }
 

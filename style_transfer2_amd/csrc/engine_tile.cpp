@@ -110,6 +110,7 @@ int st_tile_forward(st_ctx* c, float** dev_ptr, int* n_floats)
         if (al.c && (!c->have_content || c->cH != c->H || c->cW != c->W)) return fail(ST_ERR_STATE, "content features missing");
         if (al.s && !c->have_style) return fail(ST_ERR_STATE, "style Gram matrices missing");
     }
+    ST_TRY(ensure_content_features(c));
     ST_TRY(tile_ensure(&c->tile.p1, &c->tile.p1_n, std::max<size_t>(n1, 1)));
     HIP_TRY(hipMemsetAsync(c->tile.p1, 0, std::max<size_t>(n1, 1) * sizeof(float), c->stream));
     // bf16 operands: the lean data flow here too -- an fp32 blob / diff is written only where something reads fp32 (the weighted

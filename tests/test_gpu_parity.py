@@ -296,6 +296,34 @@ def test_engine_objective_changed_and_same_shape_input_replacement():
     assert np.mean((idv - io) ** 2) <= 1.0
 
 
+def test_content_features_dropped_by_set_weights_come_back_when_a_later_table_needs_them():
+    """The reference keeps the content features of every blob (worker.py:204-209); the engine keeps those a content weight reads and
+    the content image, and takes the others again when a later SetWeights asks for them (12 -> 0.3 GB at 1024^2 with the default
+    table).  Oracle and device side by side through three weight tables: content on conv2_2, on conv1_2 + conv2_2 + data, on none."""
+    g = load('transfer_tiny.npz')
+    topo, net_params, weights, content, style, init = tiny_setup(g)
+    params = json.loads(str(g['params_json']))
+    names = [l[1] for l in topo]
+    ora = oracle.TransferOracle(oracle.NetOracle(topo, net_params))
+    dev = engine_transfer(g, 'adam', 10, params)
+    ora.set_input(init); ora.set_content(content); ora.set_style(style); ora.reset()
+    ora.set_weights(weights, params); ora.set_optimizer('adam', 10); ora.start()
+    deepest, first = names[-1], names[1]
+    tables = [{'content': {deepest: 0.08}, 'style': {names[0]: 1.0}, 'deepdream': {}},
+              {'content': {first: 0.5, deepest: 0.08, 'data': 0.01}, 'style': {names[0]: 1.0}, 'deepdream': {}},
+              {'content': {}, 'style': {names[0]: 1.0, deepest: 0.5}, 'deepdream': {first: 0.02}},
+              {'content': {first: 0.5}, 'style': {names[0]: 1.0}, 'deepdream': {}}]
+    for k, table in enumerate(tables):
+        ora.set_weights(table, params); dev.set_weights(table, params)
+        ora.reset(); dev.reset()
+        for i in range(2):
+            io, to = ora.step()
+            idv, td = dev.step()
+            assert list(td) == list(to), k
+            assert np.isclose(td['loss'], to['loss'], rtol=2e-4), (k, i, td['loss'], to['loss'])
+        assert np.mean((idv - io) ** 2) <= 1e-2, k
+
+
 # ----------------------------------------------------------------------- full VGG19, small image
 def test_vgg19_gradient_matches_oracle_at_96x128():
     topo = oracle.VGG19_TOPOLOGY
