@@ -882,6 +882,69 @@ def test_fused_tile_step_vgg19_on_the_2x4_grid_matches_the_single_gpu_engine(pre
         assert mse <= (0.25 if precision == 'fp32' else 1.0), (step, mse)
 
 
+def test_configs4_full_size_8192_two_tilings_agree_on_one_gpu():
+    """BASELINE configs[4] itself -- ONE 8192 x 8192 image, VGG19 to conv5_1, cut 2 x 4 into windows of 4176 x 2128 / 4176 x 2208 -- with
+    all eight ranks resident on the one GPU (24.7 GB per fp32 window since the engine keeps content features only where a content
+    weight reads them), one thread per rank, st_tile_step per rank and iteration, transport = ThreadFabric.  No single engine holds an
+    image of this size (conv1 blobs of 17 GB; 32-bit tensor addressing), so the reference for the sharded run is ANOTHER sharding of the
+    same job: the 4 x 2 cut (windows of 2128 / 2208 x 4176), whose seams, aprons and exchange plans share nothing with the first.  Both
+    must give the same loss and the same image after two Adam iterations."""
+    import time
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    import torch
+    free, total = torch.cuda.mem_get_info()
+    if free < 230 * 2 ** 30:
+        pytest.skip('needs 230 GB of free HBM for eight 24.7 GB windows (free: %.0f GB)' % (free / 2 ** 30))
+    h = w = 8192
+    steps = 2
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (96, 80, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
+    weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},
+               'deepdream': {}}
+    params = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+    net_params = oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0)
+    results = {}
+    for rows, cols in ((2, 4), (4, 2)):
+        world = rows * cols
+        grid = tiling.TileGrid(h, w, rows, cols, oracle.VGG19_TOPOLOGY, 17)
+        fabric = ThreadFabric(world, timeout=300.0)
+        backends, ranks = [], []
+        t0 = time.time()
+        for r in range(world):
+            backend = HipTileBackend(net_params, grid, r, content, style, init, weights, params, step_size=10)
+            backend.comm_init_host(r, world, lambda v, r=r: fabric.allreduce(r, v), lambda s, rc, r=r: fabric.exchange(r, s, rc))
+            backends.append(backend)
+            ranks.append(tiled.FusedTiledTransfer(grid, r, backend))
+        t1 = time.time()
+        out = _run_ranks_as_threads(ranks, steps, fabric)
+        t2 = time.time()
+        full = np.zeros((h, w, 3), F32)
+        for r in range(world):
+            t = grid.tiles[r]
+            full[t.y0:t.y1, t.x0:t.x1] = out[r][-1][0]
+            for step in range(steps):
+                assert np.array_equal(np.asarray(out[r][step][1]), np.asarray(out[0][step][1]))
+        results[(rows, cols)] = (full, [out[0][step][1] for step in range(steps)])
+        used = (total - torch.cuda.mem_get_info()[0]) / 2 ** 30
+        print('[configs[4] %dx%d on one GPU] windows %s; build %.1f s, %d iterations %.2f s (eight ranks time-sliced, host-staged exchanges), HBM in use %.0f GB; losses %s'
+              % (rows, cols, sorted({(wd.y1 - wd.y0, wd.x1 - wd.x0) for wd in grid.windows}), t1 - t0, steps, t2 - t1, used,
+                 ['%.9g' % v[-2] for v in results[(rows, cols)][1]]))
+        for b in backends:
+            b.engine.close()
+        del backends, ranks, out
+        __import__('gc').collect()
+    (img_a, tr_a), (img_b, tr_b) = results[(2, 4)], results[(4, 2)]
+    for step in range(steps):
+        assert np.isclose(tr_a[step][-2], tr_b[step][-2], rtol=2e-5), (step, tr_a[step][-2], tr_b[step][-2])
+        assert np.isclose(tr_a[step][-1], tr_b[step][-1], rtol=1e-3), step
+    mse = float(np.mean((img_a.astype(np.float64) - img_b) ** 2))
+    moved = float(np.mean((img_a - init.astype(F32)) ** 2))
+    print('[configs[4] two tilings] image MSE %.3g between them after %d Adam iterations (the image moved by MSE %.3g)' % (mse, steps, moved))
+    assert mse <= 0.25 and moved > 50.0
+
+
 def _tiled_vgg_rank(rank, world, port, steps, h, w, q, fused=False, precision='fp32'):
     import os
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
