@@ -73,7 +73,10 @@ int st_gram(st_ctx* ctx, int index, float* out);
 /* ---- image slots: StyleTransfer.set_input / set_content / set_style (worker.py:191-218) ------- */
 /* preprocess (worker.py:63-66) + upload.  is_u8: 1 = uint8 HWC, 0 = float32 HWC. */
 int st_set_input(st_ctx* ctx, const void* hwc, int H, int W, int is_u8);
-int st_set_content(st_ctx* ctx, const void* hwc, int H, int W, int is_u8);   /* + full forward, keeps all blobs */
+/* st_set_content: + forward; keeps the preprocessed image and the features of the blobs that carry a content weight at the time
+ * (every blob until the first st_set_weights, like worker.py:204-209).  st_set_weights drops the features no content weight reads;
+ * an evaluation whose weight table names a blob without features takes them again from the kept image first (same kernels). */
+int st_set_content(st_ctx* ctx, const void* hwc, int H, int W, int is_u8);
 int st_set_style(st_ctx* ctx, const void* hwc, int H, int W, int is_u8);     /* + full forward, Gram of every blob */
 /* already-preprocessed NCHW variants (resample paths, worker.py:154-170) */
 int st_set_input_nchw(st_ctx* ctx, const float* x, int H, int W);
