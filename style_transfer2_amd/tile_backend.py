@@ -128,6 +128,34 @@ class HipTileBackend:
         self._callbacks = (capi.ALLREDUCE_FN(on_allreduce), capi.EXCHANGE_FN(on_exchange))       # keep the thunks alive
         check(self.lib.st_comm_callbacks(self.ctx, int(rank), int(world), self._callbacks[0], self._callbacks[1], None))
 
+    def comm_init_local(self, rank, world, fabric):
+        """Ranks that are threads of this process on this GPU (tiled.InProcessFabric): the engine's all-reduces and strip exchanges
+        become device-to-device copies between the contexts' buffers -- no host staging."""
+        device = self.device
+
+        def on_allreduce(_user, ptr, n):
+            try:
+                fabric.allreduce(rank, dev_tensor(ptr, (n,), device))
+                torch.cuda.synchronize(device)
+                return 0
+            except Exception:               # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def on_exchange(_user, ns, speer, sbuf, scount, nr, rpeer, rbuf, rcount):
+            try:
+                sends = [(int(speer[i]), dev_tensor(sbuf[i], (scount[i],), device)) for i in range(ns)]
+                recvs = [(int(rpeer[j]), dev_tensor(rbuf[j], (rcount[j],), device)) for j in range(nr)]
+                fabric.exchange(rank, sends, recvs)
+                return 0
+            except Exception:               # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._callbacks = (capi.ALLREDUCE_FN(on_allreduce), capi.EXCHANGE_FN(on_exchange))       # keep the thunks alive
+        check(self.lib.st_comm_callbacks(self.ctx, int(rank), int(world), self._callbacks[0], self._callbacks[1], None))
+
     def comm_init_callbacks(self, dist, rank, world):
         """comm_init_host over a torch.distributed (gloo) group: one process per rank."""
         def allreduce(values):

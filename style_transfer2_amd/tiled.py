@@ -320,6 +320,100 @@ class FusedTiledTransfer:
         return self.backend.tile_image()
 
 
+class InProcessFabric:
+    """Transport between ranks that are THREADS of one process -- every rank an engine context on the same GPU: the way one GPU runs an
+    image no single engine can hold (8192^2: eight windows of 25 GB, time-sliced), and the way the tests run all eight ranks of the
+    2 x 4 layout on a one-GPU box (RCCL refuses two ranks on one device; a box admits six processes on its card).
+    All-reduce = sum in rank order behind a barrier; exchange = one FIFO mailbox per (source, destination).  Payloads are numpy arrays
+    (HipTileBackend.comm_init_host: staged through the host) or torch device tensors (comm_init_local: device-to-device copies; the
+    sender returns only when its messages have been consumed, its pack buffers are reused by the next phase)."""
+
+    def __init__(self, world, timeout=120.0):
+        import threading
+        self.world, self.timeout = world, timeout
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.cond = threading.Condition()
+        self.mail = {}
+        self.pending = [0] * world                 # messages of rank r not yet consumed (device mode)
+        self.reduces = self.messages = 0
+
+    def allreduce(self, rank, values):
+        """values: numpy array or torch tensor, summed over the ranks in place."""
+        is_numpy = isinstance(values, np.ndarray)
+        self.slots[rank] = values.copy() if is_numpy else values.clone()
+        self.barrier.wait(self.timeout)
+        total = self.slots[0].copy() if is_numpy else self.slots[0].clone()
+        for r in range(1, self.world):
+            total += self.slots[r]
+        self.barrier.wait(self.timeout)             # every rank has read the slots before anyone overwrites one
+        if is_numpy:
+            values[:] = total
+        else:
+            values.copy_(total)
+        if rank == 0:
+            self.reduces += 1
+
+    def exchange(self, rank, sends, recvs):
+        """sends = [(peer, array)], recvs = [(peer, array to fill)]; numpy arrays are copied at send time, device tensors are handed
+        over by reference and copied by the receiver."""
+        import time
+        deadline = time.time() + self.timeout
+        with self.cond:
+            for peer, h in sends:
+                by_ref = not isinstance(h, np.ndarray)
+                self.mail.setdefault((rank, peer), []).append(h if by_ref else h.copy())
+                self.pending[rank] += 1 if by_ref else 0
+                self.messages += 1
+            self.cond.notify_all()
+        for peer, h in recvs:
+            with self.cond:
+                while not self.mail.get((peer, rank)):
+                    if not self.cond.wait(max(0.0, deadline - time.time())) and time.time() >= deadline:
+                        raise TimeoutError('rank %d: nothing from rank %d' % (rank, peer))
+                src = self.mail[(peer, rank)].pop(0)
+            if not isinstance(src, np.ndarray):
+                h.copy_(src)
+                import torch
+                torch.cuda.synchronize(h.device)
+                with self.cond:
+                    self.pending[peer] -= 1
+                    self.cond.notify_all()
+            else:
+                h[:] = src
+        with self.cond:                             # device mode: my pack buffers are free again only when my messages were copied
+            while self.pending[rank] > 0:
+                if not self.cond.wait(max(0.0, deadline - time.time())) and time.time() >= deadline:
+                    raise TimeoutError('rank %d: %d message(s) never consumed' % (rank, self.pending[rank]))
+
+
+def run_in_process(ranks, steps, fabric, on_step=None):
+    """`steps` iterations of every FusedTiledTransfer in `ranks`, one thread per rank.  Returns, per rank, the trace values of every step
+    (on_step(rank, step, transfer, values) may collect more, e.g. the tile image)."""
+    import threading
+    world = len(ranks)
+    out, errors = [None] * world, []
+
+    def run(r):
+        try:
+            res = []
+            for k in range(steps):
+                vals = ranks[r].step()
+                res.append(on_step(r, k, ranks[r], vals) if on_step else vals)
+            out[r] = res
+        except Exception as e:          # noqa: BLE001
+            errors.append((r, repr(e)))
+            fabric.barrier.abort()
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(max(300.0, 4 * fabric.timeout))
+    if errors or any(o is None for o in out):
+        raise RuntimeError('in-process ranks failed: %s' % (errors or 'a rank did not finish'))
+    return out
+
+
 def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=120.0):
     """Hands rank 0's 128-byte communicator id to every rank over a plain TCP socket (MASTER_ADDR : MASTER_PORT + 17 of the launcher's
     environment): the control plane of st_comm_init, so that the RCCL path needs neither torch.distributed nor a second HIP runtime."""

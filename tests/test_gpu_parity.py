@@ -728,69 +728,17 @@ def test_tiled_multi_rank_on_one_gpu_matches_oracle(rows, cols, fused):
     assert np.allclose(full, ref[-1][0], rtol=0, atol=0.5) or np.mean(np.abs(full - ref[-1][0]) > 0.5) < 0.02
 
 
-class ThreadFabric:
-    """In-process transport for HipTileBackend.comm_init_host: every rank is a thread of this process (a GPU box admits six
-    processes on its card; BASELINE configs[4] has eight ranks).  All-reduce = sum in rank order behind a barrier; exchange =
-    one FIFO mailbox per (source, destination)."""
-
-    def __init__(self, world, timeout=120.0):
-        import threading
-        self.world, self.timeout = world, timeout
-        self.barrier = threading.Barrier(world)
-        self.slots = [None] * world
-        self.cond = threading.Condition()
-        self.mail = {}
-        self.reduces = self.messages = 0
-
-    def allreduce(self, rank, values):
-        self.slots[rank] = values.copy()
-        self.barrier.wait(self.timeout)
-        total = self.slots[0].copy()
-        for r in range(1, self.world):
-            total += self.slots[r]
-        self.barrier.wait(self.timeout)             # every rank has read the slots before anyone overwrites one
-        values[:] = total
-        if rank == 0:
-            self.reduces += 1
-
-    def exchange(self, rank, sends, recvs):
-        import time
-        with self.cond:
-            for peer, h in sends:
-                self.mail.setdefault((rank, peer), []).append(h.copy())
-                self.messages += 1
-            self.cond.notify_all()
-            deadline = time.time() + self.timeout
-            for peer, h in recvs:
-                while not self.mail.get((peer, rank)):
-                    if not self.cond.wait(max(0.0, deadline - time.time())) and time.time() >= deadline:
-                        raise TimeoutError('rank %d: nothing from rank %d' % (rank, peer))
-                h[:] = self.mail[(peer, rank)].pop(0)
+def ThreadFabric(world, timeout=120.0):
+    """tiled.InProcessFabric: every rank is a thread of this process (a GPU box admits six processes on its card; BASELINE configs[4]
+    has eight ranks)."""
+    from style_transfer2_amd import tiled
+    return tiled.InProcessFabric(world, timeout)
 
 
 def _run_ranks_as_threads(ranks, steps, fabric):
     """`steps` iterations of every FusedTiledTransfer in `ranks`, one thread per rank; [(tile image, trace values)] per rank."""
-    import threading
-    world = len(ranks)
-    out, errors = [None] * world, []
-
-    def run(r):
-        try:
-            res = []
-            for _ in range(steps):
-                vals = ranks[r].step()
-                res.append((ranks[r].tile_image(), vals))
-            out[r] = res
-        except Exception as e:          # noqa: BLE001
-            errors.append((r, repr(e)))
-            fabric.barrier.abort()
-    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(300)
-    assert not errors and all(o is not None for o in out), errors
-    return out
+    from style_transfer2_amd import tiled
+    return tiled.run_in_process(ranks, steps, fabric, on_step=lambda r, k, tt, vals: (tt.tile_image(), vals))
 
 
 @pytest.mark.parametrize('precision,loss_rtol', [('fp32', 1e-4), ('bf16', 5e-3)])
@@ -835,8 +783,8 @@ def test_fused_tile_step_on_the_eight_rank_2x4_grid_matches_oracle(precision, lo
         assert np.mean((full - ref[step][0]) ** 2) <= 1.0, step
 
 
-@pytest.mark.parametrize('precision,loss_rtol', [('fp32', 2e-5), ('bf16', 5e-3)])
-def test_fused_tile_step_vgg19_on_the_2x4_grid_matches_the_single_gpu_engine(precision, loss_rtol):
+@pytest.mark.parametrize('precision,loss_rtol,transport', [('fp32', 2e-5, 'host'), ('fp32', 2e-5, 'device'), ('bf16', 5e-3, 'device')])
+def test_fused_tile_step_vgg19_on_the_2x4_grid_matches_the_single_gpu_engine(precision, loss_rtol, transport):
     """The eight ranks of BASELINE configs[4] with the real network: VGG19 to conv5_1 (80-px aprons), a 2048 x 4096 image cut 2 x 4 --
     windows of 1104 x 1104 (corners) and 1104 x 1184 (the four ranks with neighbours on both sides), eight contexts on the one GPU,
     st_tile_step per rank and iteration, transport = ThreadFabric.  Against the plain engine on the whole image (the largest whose
@@ -867,7 +815,10 @@ def test_fused_tile_step_vgg19_on_the_2x4_grid_matches_the_single_gpu_engine(pre
     ranks = []
     for r in range(world):
         backend = HipTileBackend(net_params, grid, r, content, style, init, weights, params, step_size=10, precision=precision)
-        backend.comm_init_host(r, world, lambda v, r=r: fabric.allreduce(r, v), lambda s, rc, r=r: fabric.exchange(r, s, rc))
+        if transport == 'device':       # device-to-device copies between the contexts' buffers (tiled.py: the one-GPU big-image driver)
+            backend.comm_init_local(r, world, fabric)
+        else:                           # staged through host arrays
+            backend.comm_init_host(r, world, lambda v, r=r: fabric.allreduce(r, v), lambda s, rc, r=r: fabric.exchange(r, s, rc))
         ranks.append(tiled.FusedTiledTransfer(grid, r, backend))
     out = _run_ranks_as_threads(ranks, steps, fabric)
     for step in range(steps):
@@ -914,7 +865,7 @@ def test_configs4_full_size_8192_two_tilings_agree_on_one_gpu():
         t0 = time.time()
         for r in range(world):
             backend = HipTileBackend(net_params, grid, r, content, style, init, weights, params, step_size=10)
-            backend.comm_init_host(r, world, lambda v, r=r: fabric.allreduce(r, v), lambda s, rc, r=r: fabric.exchange(r, s, rc))
+            backend.comm_init_local(r, world, fabric)
             backends.append(backend)
             ranks.append(tiled.FusedTiledTransfer(grid, r, backend))
         t1 = time.time()
@@ -928,7 +879,7 @@ def test_configs4_full_size_8192_two_tilings_agree_on_one_gpu():
                 assert np.array_equal(np.asarray(out[r][step][1]), np.asarray(out[0][step][1]))
         results[(rows, cols)] = (full, [out[0][step][1] for step in range(steps)])
         used = (total - torch.cuda.mem_get_info()[0]) / 2 ** 30
-        print('[configs[4] %dx%d on one GPU] windows %s; build %.1f s, %d iterations %.2f s (eight ranks time-sliced, host-staged exchanges), HBM in use %.0f GB; losses %s'
+        print('[configs[4] %dx%d on one GPU] windows %s; build %.1f s, %d iterations %.2f s (eight ranks time-sliced, device-to-device exchanges), HBM in use %.0f GB; losses %s'
               % (rows, cols, sorted({(wd.y1 - wd.y0, wd.x1 - wd.x0) for wd in grid.windows}), t1 - t0, steps, t2 - t1, used,
                  ['%.9g' % v[-2] for v in results[(rows, cols)][1]]))
         for b in backends:
