@@ -6,6 +6,7 @@
     python bench.py --size 2048 --optimizer lbfgs --precision bf16          # BASELINE configs[2]
     python bench.py --examples                                              # BASELINE configs[0]: the example pair at 256 px, 50 Adam iterations
     python bench.py --gpus 8 --tiled 2x4 --size 8192                        # BASELINE configs[4] (tile-sharded image)
+    python bench.py --tiled 2x4 --size 8192 --steps 5                       # the same job with its eight ranks on ONE GPU (time-sliced)
 
 One "step" = one ``StyleTransfer.step()`` = forward to conv5_1, 1 content + 5 style loss terms, ranged backward,
 TV / p-norm and the optimizer update (reference worker.py:303-310).  Inputs are synthetic (seeded He-normal VGG19
@@ -460,6 +461,13 @@ def main(argv=None):
     elif int(os.environ['WORLD_SIZE']) != args.gpus:
         print('bench.py: --gpus %d but the launcher started %s ranks' % (args.gpus, os.environ['WORLD_SIZE']), file=sys.stderr)
         return 2
+    if args.tiled and args.gpus == 1 and args.tiled != '1x1' and args.optimizer == 'adam':
+        # one GPU, a grid of several ranks: every rank an engine context of this process, time-sliced (tools/bench_tiled_one_gpu.py)
+        import runpy
+        sys.argv = [os.path.join(HERE, 'tools', 'bench_tiled_one_gpu.py'), '--size', str(args.size), '--grid', args.tiled,
+                    '--steps', str(args.steps), '--warmup', str(args.warmup), '--precision', 'bf16' if args.precision == 'bf16' else 'fp32']
+        runpy.run_path(sys.argv[0], run_name='__main__')
+        return 0
     if args.tiled:
         import runpy
         sys.argv = [os.path.join(HERE, 'tools', 'bench_tiled.py'), '--size', str(args.size), '--grid', args.tiled,
