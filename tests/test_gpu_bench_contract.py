@@ -70,3 +70,11 @@ def test_bench_gpus_fan_out_rehearsed_on_one_gpu():
     assert d['n_gpus'] == 2 and d['config']['jobs'] == 2 and d['scaling'] == 'weak'
     assert 'rehearsal' in d['config'] and d['value'] > 0
     assert d['value'] == pytest.approx(2 / (d['ms_per_step'] * 1e-3), rel=1e-6)      # whole-job aggregate: two ranks' steps per unit of time
+
+
+def test_bench_tiled_grid_on_one_gpu_runs_every_rank_in_process():
+    """`bench.py --tiled RxC` with one GPU: every rank of the grid is an engine context of the one process (tools/bench_tiled_one_gpu.py,
+    tiled.InProcessFabric) -- how a single card runs an image no single engine holds; here a 2 x 2 grid over 512 x 512."""
+    d = run_bench('--tiled', '2x2', '--size', '512')
+    assert d['ranks'] == 4 and d['n_gpus'] == 1 and d['grid'] == '2x2' and d['value'] > 0
+    assert d['messages_per_step'] > 0 and 'device-to-device' in d['config']['transport'] and d['loss'] > 0
