@@ -68,3 +68,49 @@ def run_job(transfer, content, style, iterations, size=None, style_size=None, op
             if callback is not None:
                 callback(i + 1, image, trace)
     return image
+
+
+def run_tiled_job(net_params, content, style, iterations, grid, size=None, style_size=None, weights=None, params=None, init=None,
+                  seed=0, device=0, precision='fp32', topology=None, callback=None):
+    """The same job for an image no single engine holds (an 8192 x 8192 image has conv1 blobs of 17 GB each): the image is cut into
+    grid = (rows, cols) tiles, every tile + apron is an engine context of THIS process on the one GPU (tiled.InProcessFabric: one
+    thread per rank, the all-reduces and strip exchanges are device-to-device copies), Adam, st_tile_step per rank and iteration.
+    Same result as run_job where both can run (tests/test_gpu_jobs.py).  Image edges must be multiples of 16 * rows / cols
+    (tiling.TileGrid).  Returns the stitched HxWx3 float32 image; callback(i, trace values) after every iteration."""
+    from . import tiled, tiling
+    from .engine import VGG19_TOPOLOGY
+    from .tile_backend import HipTileBackend
+    topology = topology or VGG19_TOPOLOGY
+    if isinstance(content, Image.Image):
+        content = np.uint8(resize_to_fit(content, size or max(content.size)))
+    if isinstance(style, Image.Image):
+        style = np.uint8(resize_to_fit(style, style_size or size or max(style.size)))
+    if init is None:
+        init = noise_image(content.shape[:2], seed)
+    weights, params = weights or DEFAULT_WEIGHTS, params or DEFAULT_PARAMS
+    rows, cols = grid
+    h, w = content.shape[:2]
+    deepest = max(i for i, layer in enumerate(topology) if any(layer[1] in weights[k] and weights[k][layer[1]] for k in weights))
+    tg = tiling.TileGrid(h, w, rows, cols, topology, deepest + 1)
+    world = rows * cols
+    fabric = tiled.InProcessFabric(world, timeout=600.0)
+    ranks, backends = [], []
+    for r in range(world):
+        b = HipTileBackend(net_params, tg, r, content, style, init, weights, params, step_size=10, topology=topology, device=device,
+                           precision=precision)
+        b.comm_init_local(r, world, fabric)
+        backends.append(b)
+        ranks.append(tiled.FusedTiledTransfer(tg, r, b))
+    try:
+        for i in range(iterations):
+            vals = tiled.run_in_process(ranks, 1, fabric)[0][0]
+            if callback is not None:
+                callback(i + 1, vals)
+        image = np.zeros((h, w, 3), np.float32)
+        for r in range(world):
+            t = tg.tiles[r]
+            image[t.y0:t.y1, t.x0:t.x1] = ranks[r].tile_image()
+    finally:
+        for b in backends:
+            b.engine.close()
+    return image

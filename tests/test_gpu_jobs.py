@@ -129,3 +129,17 @@ def test_stylize_cli_and_bench_examples_mode(tmp_path):
     assert d['cpu_baseline']['kind'] == 'port' and '15 adam' in d['cpu_baseline']['sample'] and d['cpu_baseline']['value'] > 0
     assert d['parity']['image_after'].startswith('15 adam') and d['parity']['image_mse'] <= 0.5 and d['parity']['step_loss_rel'] <= 1e-3
     assert d['value'] > 50 * d['cpu_baseline']['value']
+
+
+def test_run_tiled_job_on_one_gpu_equals_run_job():
+    """jobs.run_tiled_job: the example pair at 256 px cut 2 x 2 into tiles that all live on the one GPU (tiled.InProcessFabric,
+    device-to-device exchanges) against jobs.run_job on the whole image: the same ten Adam iterations."""
+    content, style = _example_pair()
+    params = oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0)
+    whole = jobs.run_job(st2.StyleTransfer(st2.HipModel(params)), content, style, 10, size=256, optimizer='adam', seed=5)
+    seen = []
+    tiles = jobs.run_tiled_job(params, content, style, 10, (2, 2), size=256, seed=5, callback=lambda i, vals: seen.append((i, vals[-2])))
+    assert tiles.shape == whole.shape == (192, 256, 3) and tiles.dtype == F32 and [i for i, _ in seen] == list(range(1, 11))
+    mse = float(np.mean((tiles.astype(np.float64) - whole) ** 2))
+    print('[tiled job 2x2 at 192x256] image MSE %.3g against the whole-image job after 10 Adam iterations' % mse)
+    assert mse <= 0.05 and np.isfinite(seen[-1][1])
