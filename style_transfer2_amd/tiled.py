@@ -387,6 +387,27 @@ class InProcessFabric:
                     raise TimeoutError('rank %d: %d message(s) never consumed' % (rank, self.pending[rank]))
 
 
+class LocalComm:
+    """The Comm interface of the phase-by-phase driver (TiledTransfer: Adam or L-BFGS) over an InProcessFabric: ranks are threads of
+    this process on one GPU, tensors are exchanged by reference and copied device to device."""
+
+    def __init__(self, fabric, rank):
+        self.fabric, self.rank, self.world = fabric, rank, fabric.world
+        self.dist, self.staged = None, False
+
+    def all_reduce(self, t):
+        if self.world == 1 or t is None or t.numel() == 0:
+            return t
+        self.fabric.allreduce(self.rank, t)
+        if t.is_cuda:
+            torch.cuda.synchronize(t.device)
+        return t
+
+    def exchange(self, sends, recvs):
+        if self.world > 1:
+            self.fabric.exchange(self.rank, list(sends), list(recvs))
+
+
 def run_in_process(ranks, steps, fabric, on_step=None):
     """`steps` iterations of every FusedTiledTransfer in `ranks`, one thread per rank.  Returns, per rank, the trace values of every step
     (on_step(rank, step, transfer, values) may collect more, e.g. the tile image)."""

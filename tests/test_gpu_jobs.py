@@ -143,3 +143,15 @@ def test_run_tiled_job_on_one_gpu_equals_run_job():
     mse = float(np.mean((tiles.astype(np.float64) - whole) ** 2))
     print('[tiled job 2x2 at 192x256] image MSE %.3g against the whole-image job after 10 Adam iterations' % mse)
     assert mse <= 0.05 and np.isfinite(seen[-1][1])
+
+
+def test_run_tiled_job_with_lbfgs_on_one_gpu_equals_run_job():
+    """The L-BFGS variant over the sharded image (every utils.dot a per-rank partial + one all-reduce, tiled.TiledTransfer) with its
+    ranks as threads of this process (tiled.LocalComm): four steps -- while the fixed-step iteration contracts -- against run_job."""
+    content, style = _example_pair()
+    params = oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0)
+    whole = jobs.run_job(st2.StyleTransfer(st2.HipModel(params)), content, style, 4, size=256, optimizer='lbfgs', seed=5)
+    tiles = jobs.run_tiled_job(params, content, style, 4, (2, 2), size=256, seed=5, optimizer='lbfgs')
+    mse = float(np.mean((tiles.astype(np.float64) - whole) ** 2))
+    print('[tiled L-BFGS job 2x2 at 192x256] image MSE %.3g against the whole-image job after 4 steps' % mse)
+    assert tiles.shape == whole.shape and mse <= 0.05

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headless stylisation job on one MI355X:  stylize.py content.jpg style.jpg out.png [--size 512] [--iters 500]
 --grid RxC: an image too large for one engine (beyond about 4096 x 4096) is cut into R x C tiles that all live on the one GPU
-(jobs.run_tiled_job; Adam only; the image edges must divide into tiles of multiples of 16 pixels)."""
+(jobs.run_tiled_job; the image edges must divide into tiles of multiples of 16 pixels)."""
 import argparse
 import os
 import sys
@@ -34,7 +34,7 @@ else:
 if args.grid:
     rows, cols = (int(v) for v in args.grid.split('x'))
     image = jobs.run_tiled_job(params, jobs.load_rgb(args.content), jobs.load_rgb(args.style), args.iters, (rows, cols), size=args.size,
-                               style_size=args.style_size or None, device=args.gpu)
+                               style_size=args.style_size or None, device=args.gpu, optimizer=args.optimizer)
 else:
     job = st2.StyleTransfer(st2.HipModel(params, device=args.gpu))
     image = jobs.run_job(job, jobs.load_rgb(args.content), jobs.load_rgb(args.style), args.iters, size=args.size,
