@@ -461,11 +461,12 @@ def main(argv=None):
     elif int(os.environ['WORLD_SIZE']) != args.gpus:
         print('bench.py: --gpus %d but the launcher started %s ranks' % (args.gpus, os.environ['WORLD_SIZE']), file=sys.stderr)
         return 2
-    if args.tiled and args.gpus == 1 and args.tiled != '1x1' and args.optimizer == 'adam':
+    if args.tiled and args.gpus == 1 and args.tiled != '1x1':
         # one GPU, a grid of several ranks: every rank an engine context of this process, time-sliced (tools/bench_tiled_one_gpu.py)
         import runpy
         sys.argv = [os.path.join(HERE, 'tools', 'bench_tiled_one_gpu.py'), '--size', str(args.size), '--grid', args.tiled,
-                    '--steps', str(args.steps), '--warmup', str(args.warmup), '--precision', 'bf16' if args.precision == 'bf16' else 'fp32']
+                    '--steps', str(args.steps), '--warmup', str(args.warmup), '--precision', 'bf16' if args.precision == 'bf16' else 'fp32',
+                    '--optimizer', args.optimizer]
         runpy.run_path(sys.argv[0], run_name='__main__')
         return 0
     if args.tiled:

@@ -23,6 +23,7 @@ ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--precision', default='fp32', choices=('fp32', 'bf16'))
 ap.add_argument('--transport', default='device', choices=('device', 'host'))
+ap.add_argument('--optimizer', default='adam', choices=('adam', 'lbfgs'), help='lbfgs: the phase-by-phase driver with all-reduced dot products')
 args = ap.parse_args()
 sys.stdout.flush()
 json_out = os.fdopen(os.dup(1), 'w')
@@ -51,11 +52,14 @@ fabric = tiled.InProcessFabric(world, timeout=600.0)
 ranks, backends = [], []
 for r in range(world):
     b = HipTileBackend(net, grid, r, content, style, init, WEIGHTS, PARAMS, step_size=10, precision=args.precision)
+    backends.append(b)
+    if args.optimizer == 'lbfgs':
+        ranks.append(tiled.TiledTransfer(grid, r, b, tiled.LocalComm(fabric, r), optimizer='lbfgs', step_size=1))
+        continue
     if args.transport == 'device':
         b.comm_init_local(r, world, fabric)
     else:
         b.comm_init_host(r, world, lambda v, r=r: fabric.allreduce(r, v), lambda s, rc, r=r: fabric.exchange(r, s, rc))
-    backends.append(b)
     ranks.append(tiled.FusedTiledTransfer(grid, r, b))
 tiled.run_in_process(ranks, args.warmup, fabric)
 for b in backends:
@@ -70,8 +74,8 @@ json_out.write(json.dumps({
     'metric': 'tile-sharded style-transfer iters/sec @%sx%s VGG19, every rank on ONE GPU' % (gH, gW), 'value': args.steps / dt, 'unit': 'it/s',
     'n_gpus': 1, 'ranks': world, 'grid': args.grid, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * dt / args.steps,
     'higher_is_better': True, 'vs_baseline': None,
-    'config': {'workload': 'configs[4] job on one GPU: ONE %dx%d image, %s windows %s resident together, adam %s' % (
-        gH, gW, args.grid, sorted({(w.y1 - w.y0, w.x1 - w.x0) for w in grid.windows}), args.precision),
+    'config': {'workload': 'configs[4] job on one GPU: ONE %dx%d image, %s windows %s resident together, %s %s' % (
+        gH, gW, args.grid, sorted({(w.y1 - w.y0, w.x1 - w.x0) for w in grid.windows}), args.optimizer, args.precision),
                'transport': 'in-process, %s' % ('device-to-device copies' if args.transport == 'device' else 'staged through host arrays')},
     'hbm_in_use_GiB': used, 'loss': float(out[0][-1][-2]), 'all_reduces_per_step': fabric.reduces / max(1, args.steps + args.warmup),
     'messages_per_step': fabric.messages / max(1, args.steps + args.warmup),
