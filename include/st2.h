@@ -121,7 +121,8 @@ int st_step_pending(st_ctx* ctx);      /* iterations begun and not yet ended (0.
  * from the next st_step_begin on, the caller may write `head_bytes` in front of and `tail_bytes` behind the image st_step_end hands out
  * (same pinned allocation, same lifetime), so that the pickle's fixed header, the image the GPU copied in and the variable tail form one
  * contiguous buffer the transport sends without a host-side copy.  At most 1 MiB each; the image stays page-aligned.  Buffers replaced
- * by a re-allocation (a larger input, other rooms) stay valid for the views already handed out, for the same five further begins. */
+ * by a re-allocation (a larger input, other rooms) stay valid for the views already handed out, for the same five further begins.
+ * Refused (ST_ERR_STATE) while an iteration is in flight: its slot was sized without the room -- collect with st_step_end first. */
 int st_step_frame_room(st_ctx* ctx, size_t head_bytes, size_t tail_bytes);
 /* Steps so far that ran as a hipGraph replay.  Opt-in (environment ST2_GRAPH=1; ST2_GRAPH_MAX_PX=<edge>, default 768):
  * steady-state Adam steps are captured once per ping-pong parity and replayed, bit-identical to plain launches.  Measured

@@ -137,13 +137,19 @@ static int comm_exchange(st_ctx* c, int phase, float* src, int sh, int sw, float
             if (m.ex(m.user, (int)sp.size(), sp.data(), sb.data(), sc.data(), (int)rp.size(), rp.data(), rb.data(), rc.data()) != 0)
                 return fail(ST_ERR_HIP, "the caller's strip exchange failed");
         } else {
+            // every exit path closes the group: a send / recv that fails inside an open group would leave it open on this thread,
+            // later RCCL calls would never be issued and the peers would wait for ever instead of seeing this rank's error
             RCCL_TRY(g_rccl.group_start());
+            int first = 0;
+            const char* what = "";
             for (auto& p : plan) {
-                if (!remote(p)) continue;
-                if (p.sn) RCCL_TRY(g_rccl.send(p.sbuf, p.sn, kNcclFloat, p.peer, m.comm, c->stream));
-                if (p.rn) RCCL_TRY(g_rccl.recv(p.rbuf, p.rn, kNcclFloat, p.peer, m.comm, c->stream));
+                if (!remote(p) || first) continue;
+                if (p.sn && (first = g_rccl.send(p.sbuf, p.sn, kNcclFloat, p.peer, m.comm, c->stream)) != 0) { what = "ncclSend"; continue; }
+                if (p.rn && (first = g_rccl.recv(p.rbuf, p.rn, kNcclFloat, p.peer, m.comm, c->stream)) != 0) what = "ncclRecv";
             }
-            RCCL_TRY(g_rccl.group_end());
+            const int ended = g_rccl.group_end();
+            if (first) return fail(ST_ERR_HIP, "%s failed inside the strip exchange of phase %d: %s", what, phase, g_rccl.errstr(first));
+            if (ended) return fail(ST_ERR_HIP, "ncclGroupEnd failed in the strip exchange of phase %d: %s", phase, g_rccl.errstr(ended));
         }
     }
     for (auto& p : plan)                    // ascending peer (the plan's order), plan order inside: deterministic sums
@@ -278,7 +284,11 @@ int st_tile_plan(st_ctx* c, int phase, int n_peers, const st_tile_peer* peers)
         if (q.peer == c->comm.rank && p.sn != p.rn) return fail(ST_ERR_ARG, "a local copy must send and receive the same number of pixels");
         if (p.sn > 0x7fffffffu || p.rn > 0x7fffffffu) return fail(ST_ERR_ARG, "a strip message is limited to 2^31 floats");
         if (p.sn) ST_TRY(dmalloc(&p.sbuf, p.sn));
-        if (p.rn && (q.peer != c->comm.rank || c->comm.self_via_rccl)) ST_TRY(dmalloc(&p.rbuf, p.rn));
+        if (p.rn && (q.peer != c->comm.rank || c->comm.self_via_rccl)) {
+            ST_TRY(dmalloc(&p.rbuf, p.rn));
+            // a transport that delivers nothing (the solo-rank timing hook) must leave zeros, not whatever the allocation held
+            HIP_TRY(hipMemset(p.rbuf, 0, p.rn * sizeof(float)));
+        }
         plan.push_back(std::move(p));
     }
     c->comm.planned[phase] = true;

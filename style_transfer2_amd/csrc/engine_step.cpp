@@ -290,6 +290,9 @@ int st_step_frame_room(st_ctx* c, size_t head_bytes, size_t tail_bytes)
 {
     if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
     if (head_bytes > (1u << 20) || tail_bytes > (1u << 20)) return fail(ST_ERR_ARG, "frame room is limited to 1 MiB on either side");
+    // An iteration begun before this call was given a slot WITHOUT the room; collected after it, the caller would assemble its frame
+    // outside that slot's pinned allocation.  Refuse: the caller collects everything in flight first.
+    if (c->pipe.count) return fail(ST_ERR_STATE, "%d iteration(s) in flight: collect them with st_step_end before changing the frame room", c->pipe.count);
     // the image stays page-aligned inside the pinned allocation
     c->pipe.want_head = (head_bytes + 4095) / 4096 * 4096;
     c->pipe.want_tail = tail_bytes;

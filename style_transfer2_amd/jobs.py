@@ -114,6 +114,10 @@ def run_tiled_job(net_params, content, style, iterations, grid, size=None, style
         for r in range(world):
             t = tg.tiles[r]
             image[t.y0:t.y1, t.x0:t.x1] = ranks[r].tile_image()
+    except RuntimeError as err:
+        if getattr(err, 'still_running', False):     # a rank thread is still inside the engine: freeing its context under it would
+            backends = []                            # pull device memory from running kernels -- leak the contexts and report
+        raise
     finally:
         for b in backends:
             b.engine.close()

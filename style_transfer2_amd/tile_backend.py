@@ -172,7 +172,8 @@ class HipTileBackend:
 
     def comm_init_solo(self, rank, world):
         """ONE rank of a larger grid alone on a GPU (timing the per-rank compute of a multi-GPU run): the all-reduces see one rank,
-        what the neighbours would send never arrives (the receive buffers keep whatever they held)."""
+        what the neighbours would send never arrives -- the receive buffers hold the zeros st_tile_plan initialised them with, so the
+        timed update runs on finite data."""
         self._callbacks = (capi.ALLREDUCE_FN(lambda user, ptr, n: 0), capi.EXCHANGE_FN(lambda *a: 0))
         check(self.lib.st_comm_callbacks(self.ctx, int(rank), int(world), self._callbacks[0], self._callbacks[1], None))
 

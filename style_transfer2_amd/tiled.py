@@ -337,6 +337,18 @@ class InProcessFabric:
         self.mail = {}
         self.pending = [0] * world                 # messages of rank r not yet consumed (device mode)
         self.reduces = self.messages = 0
+        self.aborted = False                       # a rank failed: every wait of the others ends at once (abort())
+
+    def abort(self):
+        """A rank raised: wake every rank that waits for it (barrier and mailboxes) instead of letting them run into the timeout."""
+        with self.cond:
+            self.aborted = True
+            self.cond.notify_all()
+        self.barrier.abort()
+
+    def _check(self, rank):
+        if self.aborted:
+            raise RuntimeError('rank %d: another rank failed, the exchange was abandoned' % rank)
 
     def allreduce(self, rank, values):
         """values: numpy array or torch tensor, summed over the ranks in place."""
@@ -369,6 +381,7 @@ class InProcessFabric:
         for peer, h in recvs:
             with self.cond:
                 while not self.mail.get((peer, rank)):
+                    self._check(rank)
                     if not self.cond.wait(max(0.0, deadline - time.time())) and time.time() >= deadline:
                         raise TimeoutError('rank %d: nothing from rank %d' % (rank, peer))
                 src = self.mail[(peer, rank)].pop(0)
@@ -383,6 +396,7 @@ class InProcessFabric:
                 h[:] = src
         with self.cond:                             # device mode: my pack buffers are free again only when my messages were copied
             while self.pending[rank] > 0:
+                self._check(rank)
                 if not self.cond.wait(max(0.0, deadline - time.time())) and time.time() >= deadline:
                     raise TimeoutError('rank %d: %d message(s) never consumed' % (rank, self.pending[rank]))
 
@@ -410,7 +424,9 @@ class LocalComm:
 
 def run_in_process(ranks, steps, fabric, on_step=None):
     """`steps` iterations of every FusedTiledTransfer in `ranks`, one thread per rank.  Returns, per rank, the trace values of every step
-    (on_step(rank, step, transfer, values) may collect more, e.g. the tile image)."""
+    (on_step(rank, step, transfer, values) may collect more, e.g. the tile image).  A rank that raises aborts the fabric, so the others
+    leave their waits at once; if a rank thread is nevertheless still running when this returns (it sits inside the engine), the
+    RuntimeError carries ``still_running = True`` and the caller must NOT free the engine contexts."""
     import threading
     world = len(ranks)
     out, errors = [None] * world, []
@@ -424,14 +440,22 @@ def run_in_process(ranks, steps, fabric, on_step=None):
             out[r] = res
         except Exception as e:          # noqa: BLE001
             errors.append((r, repr(e)))
-            fabric.barrier.abort()
+            fabric.abort() if hasattr(fabric, 'abort') else fabric.barrier.abort()
     threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
         t.join(max(300.0, 4 * fabric.timeout))
-    if errors or any(o is None for o in out):
-        raise RuntimeError('in-process ranks failed: %s' % (errors or 'a rank did not finish'))
+    alive = [r for r, t in enumerate(threads) if t.is_alive()]
+    if alive and hasattr(fabric, 'abort'):
+        fabric.abort()
+        for t in threads:
+            t.join(30.0)
+        alive = [r for r, t in enumerate(threads) if t.is_alive()]
+    if errors or alive or any(o is None for o in out):
+        err = RuntimeError('in-process ranks failed: %s' % (errors or ('rank(s) %s did not finish' % alive)))
+        err.still_running = bool(alive)
+        raise err
     return out
 
 

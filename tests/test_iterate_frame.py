@@ -4,6 +4,8 @@ in (pinned) memory must unpickle to exactly what the reference's ``send_pyobj(It
 from collections import OrderedDict
 import pickle
 import pickletools
+import threading
+import time
 
 import numpy as np
 import pytest
@@ -163,3 +165,104 @@ def test_zero_copy_frames_over_the_workers_own_tcp_sockets(monkeypatch):
     its = got[1:7]
     assert [m.i for m in its] == [1, 2, 3, 4, 5, 6] and [float(m.image[0, 0, 0]) for m in its] == [1, 2, 3, 4, 5, 6]
     assert all(m.image.dtype == F32 and m.image.shape == (2, 2, 3) and type(m.trace) is OrderedDict for m in its)
+
+
+# --------------------------------------------------------------------- a peer that stops reading (libzmq's tracker semantics)
+class NotDone(Exception):
+    """pyzmq's zmq.NotDone: MessageTracker.wait(timeout) expired."""
+
+
+class StallingSockets(FakeSockets):
+    """libzmq releases a tracked zero-copy frame only once a connected peer has taken the bytes.  This outbound socket takes
+    ``alive`` frames and then behaves like an app that died mid-stream: trackers never complete, ``wait(timeout)`` raises
+    NotDone -- until the socket is closed (LINGER 0 frees the frames)."""
+    def __init__(self, inbound, alive):
+        super().__init__(inbound)
+        self.alive, self.raw_sends, self.closed = alive, 0, threading.Event()
+        self.stuck = []
+
+    def send(self, data, copy=True, track=False):
+        assert copy is False and track is True
+        self.raw_sends += 1
+        outer, taken = self, self.raw_sends <= self.alive
+        if taken:
+            outer.sent.append(pickle.loads(bytes(data)))
+        else:
+            outer.stuck.append(data)
+
+        class Tracker:
+            @property
+            def done(self_inner):
+                return taken or outer.closed.is_set()
+
+            def wait(self_inner, timeout=None):
+                if taken:
+                    return
+                if not outer.closed.wait(timeout):
+                    raise NotDone()
+        return Tracker()
+
+    def send_pyobj(self, obj):
+        if self.raw_sends > self.alive:          # the dead peer takes nothing more; libzmq queues small messages below its HWM
+            return
+        super().send_pyobj(obj)
+
+
+@pytest.mark.parametrize('async_iterate', ['0', '1'])
+def test_worker_exits_when_the_peer_disappears_with_a_frame_in_flight(async_iterate, monkeypatch):
+    """with zero-copy iterates a dead app must not hang the worker -- the tracker wait is sliced, Shutdown /
+    SIGHUP bound it by a grace period, queued frames are dropped and Worker.close() is reached (reference worker.py:362-363,
+    429-431: Shutdown is queued and ctx.destroy(0) drops what the peer never took)."""
+    import threading as th
+    monkeypatch.setattr(worker_mod, 'SEND_SLICE_S', 0.02)
+    monkeypatch.setattr(worker_mod, 'SHUTDOWN_GRACE_S', 0.3)
+    img = np.zeros((4, 4, 3), np.uint8)
+    socks = StallingSockets([messages.SetImages(None, img, img, img, True), messages.StartIteration()], alive=2)
+    tr = FakeFramedTransfer(6)
+    wk = worker_mod.Worker({'async_iterate': async_iterate, 'zero_copy_iterate': '1'}, sock_in=socks, sock_out=socks, transfer=tr)
+    if async_iterate == '1':
+        wk.sock_out.grace = 0.3
+    done = th.Event()
+
+    def body():
+        try:
+            wk.run()
+        finally:
+            wk.close()
+            done.set()
+
+    def hang_up():
+        # what the reference's SIGHUP handler does (utils.py:187-190: KeyboardInterrupt in the worker's thread), delivered to the
+        # thread this test runs the worker on; by then it sits in a sliced wait (the tracker's, or the full queue's)
+        import ctypes
+        ctypes.pythonapi.PyThreadState_SetAsyncExc(ctypes.c_ulong(t.ident), ctypes.py_object(KeyboardInterrupt))
+    t = th.Thread(target=body, daemon=True)
+    t0 = time.time()
+    t.start()
+    th.Timer(0.5, hang_up).start()
+    assert done.wait(20.0), 'the worker hung on a frame the dead peer never took'
+    assert time.time() - t0 < 10.0
+    taken = [m for m in socks.sent if isinstance(m, messages.Iterate)]
+    assert [m.i for m in taken] == [1, 2]                       # what the live peer took arrived intact and in order
+    assert len(socks.stuck) >= 1                               # ... and at least one frame really was in flight when it died
+    if async_iterate == '1':
+        assert not wk._raw_out is None and isinstance(wk.sock_out, StallingSockets)     # the sender thread is gone
+        assert not [th_ for th_ in th.enumerate() if th_.name == 'iterate-sender' and th_.is_alive()]
+
+
+def test_async_sender_close_is_bounded_when_nothing_is_taken(monkeypatch):
+    monkeypatch.setattr(worker_mod, 'SEND_SLICE_S', 0.02)
+    socks = StallingSockets([], alive=0)
+    sender = worker_mod.AsyncSender(socks, depth=2, grace=0.2)
+    for k in range(3):                                           # one in flight on the sender thread + two queued
+        sender.send_frame(memoryview(bytearray(pickle.dumps(k))))
+        time.sleep(0.05)
+    t0 = time.time()
+    blocker = threading.Thread(target=lambda: sender.send_frame(memoryview(bytearray(pickle.dumps(9)))), daemon=True)
+    blocker.start()                                              # the queue is full: this put waits (back-pressure) ...
+    time.sleep(0.1)
+    assert blocker.is_alive()
+    sender.close()                                               # ... until close() gives up after the grace period
+    blocker.join(5.0)
+    assert not blocker.is_alive() and not sender.thread.is_alive()
+    assert time.time() - t0 < 5.0 and sender.dropped >= 2 and socks.sent == []

@@ -240,3 +240,33 @@ def test_fused_plans_are_consistent_across_ranks_and_move_the_right_pixels(gh, g
         ring = rings[r]
         assert np.array_equal(ring[:, 0], want[:, 0]) and np.array_equal(ring[:, -1], want[:, -1]), r
         assert np.array_equal(ring[:, :, 0], want[:, :, 0]) and np.array_equal(ring[:, :, -1], want[:, :, -1]), r
+
+
+def test_in_process_fabric_abort_releases_waiting_ranks():
+    """a rank that raises must not leave the others waiting in an exchange until the fabric's timeout (600 s in
+    jobs.run_tiled_job); run_in_process reports whether a rank thread is still running so that the caller does not free a context
+    under it."""
+    import time
+    from style_transfer2_amd import tiled
+
+    fabric = tiled.InProcessFabric(3, timeout=60.0)
+
+    class Rank:
+        def __init__(self, r):
+            self.r = r
+
+        def step(self):
+            if self.r == 0:
+                time.sleep(0.2)
+                raise ValueError('rank 0 broke')
+            if self.r == 1:                                     # waits for a message rank 0 never sends
+                fabric.exchange(1, [], [(0, np.zeros(4, np.float32))])
+            else:                                               # waits at the all-reduce barrier
+                fabric.allreduce(2, np.ones(3, np.float32))
+            return [0.0]
+
+    t0 = time.time()
+    with pytest.raises(RuntimeError) as info:
+        tiled.run_in_process([Rank(r) for r in range(3)], 1, fabric)
+    assert time.time() - t0 < 10.0, 'the other ranks sat out the timeout'
+    assert 'rank 0 broke' in str(info.value) and info.value.still_running is False

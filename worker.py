@@ -18,6 +18,7 @@ import queue
 import signal
 import sys
 import threading
+import time
 
 MODULE_DIR = Path(__file__).parent.resolve()
 sys.path.insert(0, str(MODULE_DIR))
@@ -110,25 +111,59 @@ class _Frame:
         self.buf = buf
 
 
-def send_frame(sock, buf):
+class SendAborted(RuntimeError):
+    """A zero-copy frame was given up: the peer never took it and the worker is shutting down (or the wait timed out)."""
+
+
+SEND_SLICE_S = 0.25          # a tracked send is waited for in slices of this length, so that a stop request is seen
+SHUTDOWN_GRACE_S = 5.0       # how long a shutting-down worker keeps trying to hand its last messages to a peer that is not reading
+
+
+def send_frame(sock, buf, stop=None, timeout=None):
     """One already-pickled message, straight from pinned memory: no copy on this side (pyzmq ``send(copy=False)``).  The
     buffer belongs to the engine and is rewritten a few iterations later, so the call returns only once the transport no
-    longer needs it (``track=True`` + ``MessageTracker.wait``: libzmq has handed the bytes to the kernel)."""
+    longer needs it (``track=True``: libzmq has handed the bytes to a connected peer).  libzmq releases a tracked frame only
+    when a peer takes it -- if the app died mid-stream that is never -- so the wait is taken in bounded slices
+    (``MessageTracker.wait(timeout)`` raises ``zmq.NotDone`` on expiry) and ends with ``SendAborted`` when ``stop`` is set
+    or ``timeout`` seconds have passed; the caller then closes the socket with LINGER 0, which frees the frame."""
     tracker = sock.send(buf, copy=False, track=True)
-    if tracker is not None and hasattr(tracker, 'wait'):
-        tracker.wait()
+    if tracker is None or not hasattr(tracker, 'wait'):
+        return
+    deadline = None if timeout is None else time.monotonic() + timeout
+    while True:
+        try:
+            tracker.wait(SEND_SLICE_S)
+        except TypeError:                 # a tracker without a timeout argument (test doubles): one unbounded wait
+            tracker.wait()
+            return
+        except Exception as err:          # zmq.NotDone: not sent yet
+            if type(err).__name__ != 'NotDone':
+                raise
+        if getattr(tracker, 'done', True):
+            return
+        if (stop is not None and stop.is_set()) or (deadline is not None and time.monotonic() > deadline):
+            raise SendAborted('the peer did not take an Iterate frame')
 
 
 class AsyncSender:
     """Owns the outbound socket on its own thread: pickling + sending an ``Iterate`` (12.6 MB at 1024^2)
     overlaps the next iteration's GPU work instead of stalling it.  Order is
     preserved (one FIFO), every message still goes out exactly once, and the queue is bounded so the
-    worker never runs more than ``depth`` iterates ahead of what the app has been sent."""
+    worker never runs more than ``depth`` iterates ahead of what the app has been sent.
 
-    def __init__(self, sock, depth=2):
+    While the worker iterates, a peer that reads slowly simply holds the worker back (as libzmq's high-water mark does in the
+    reference).  Once ``begin_shutdown`` has been called nothing waits longer than ``grace`` seconds: messages that a dead
+    peer will never take are dropped, the thread ends, and the caller can destroy the context (reference worker.py:362-363,
+    429-431: ``Shutdown`` is queued and ``ctx.destroy(0)`` drops what could not be delivered)."""
+
+    def __init__(self, sock, depth=2, grace=SHUTDOWN_GRACE_S):
         self.sock = sock
         self.q = queue.Queue(maxsize=depth)
         self.error = None
+        self.grace = grace
+        self.stop = threading.Event()          # set: give up on whatever is in flight or queued
+        self.deadline = None                   # set by begin_shutdown
+        self.dropped = 0
         self.thread = threading.Thread(target=self._run, name='iterate-sender', daemon=True)
         self.thread.start()
 
@@ -137,27 +172,68 @@ class AsyncSender:
             msg = self.q.get()
             if msg is None:
                 return
+            if self.stop.is_set():
+                self.dropped += 1
+                continue
             try:
                 if isinstance(msg, _Frame):
-                    send_frame(self.sock, msg.buf)
+                    send_frame(self.sock, msg.buf, stop=self.stop)
                 else:
                     self.sock.send_pyobj(msg)
+            except SendAborted:
+                self.dropped += 1
             except Exception as err:      # surfaced on the worker thread at the next send
                 self.error = err
+
+    def _put(self, item):
+        """Queue one item; False if the sender has been stopped or the shutdown grace period ran out first."""
+        while True:
+            if self.stop.is_set():
+                return False
+            try:
+                self.q.put(item, timeout=SEND_SLICE_S)
+                return True
+            except queue.Full:
+                if self.deadline is not None and time.monotonic() > self.deadline:
+                    self.abort()
+                    return False
 
     def send_pyobj(self, msg):
         if self.error is not None:
             raise self.error
-        self.q.put(msg)
+        if not self._put(msg):
+            self.dropped += 1
 
     def send_frame(self, buf):
         """A finished pickle (iterate_frame.py) that lives in the engine's rotating pinned buffers: sent as it is."""
         self.send_pyobj(_Frame(buf))
 
+    def begin_shutdown(self):
+        """From now on nothing blocks for longer than the grace period."""
+        if self.deadline is None:
+            self.deadline = time.monotonic() + self.grace
+
+    def abort(self):
+        """Give up on everything queued or in flight (the peer is not reading); the thread then drains its queue and ends."""
+        self.stop.set()
+
     def close(self):
-        """Flush everything queued, then stop the thread."""
-        self.q.put(None)
-        self.thread.join()
+        """Flush everything queued -- for at most the grace period -- then stop the thread."""
+        self.begin_shutdown()
+        queued = self._put(None)              # False: the grace period ran out with the queue still full
+        if queued:
+            self.thread.join(max(0.0, self.deadline - time.monotonic()) + SEND_SLICE_S)
+        if self.thread.is_alive():
+            logger.warning('the peer is not reading: dropping the messages still queued')
+            self.abort()                      # the wait on the frame in flight ends within one slice; queued messages are dropped
+            give_up = time.monotonic() + 8 * SEND_SLICE_S
+            while not queued and time.monotonic() < give_up:
+                try:
+                    self.q.put_nowait(None)
+                    queued = True
+                except queue.Full:
+                    time.sleep(0.02)
+            self.thread.join(max(0.0, give_up - time.monotonic()))
         if self.error is not None:
             raise self.error
 
@@ -183,6 +259,7 @@ class Worker:
         self.sock_in = sock_in
         self._raw_out = self.sock_out = sock_out
         self.run_should_stop = False
+        self._shutting_down = False
         try:
             # the model first (it may sys.exit(2): reference worker.py:51-53), the sender thread only once it exists
             self.transfer = transfer if transfer is not None else build_transfer(config)
@@ -223,7 +300,7 @@ class Worker:
             if isinstance(self.sock_out, AsyncSender):
                 self.sock_out.send_frame(frame)
             else:
-                send_frame(self.sock_out, frame)
+                send_frame(self.sock_out, frame, timeout=SHUTDOWN_GRACE_S if self._shutting_down else None)
         else:
             image, trace, index = tr.step_end()
             self.sock_out.send_pyobj(Iterate(image, index, trace))
@@ -245,6 +322,9 @@ class Worker:
         except KeyboardInterrupt:
             pass
         finally:
+            self._shutting_down = True
+            if isinstance(self.sock_out, AsyncSender):       # from here on a peer that is not reading cannot hold the exit up
+                self.sock_out.begin_shutdown()
             try:
                 self._flush_pending()
             except Exception:                 # the reference always reaches Shutdown (worker.py:396-398)
