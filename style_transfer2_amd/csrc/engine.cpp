@@ -20,7 +20,8 @@ int fail(int code, const char* fmt, ...)
 const char* const kProfNames[P_COUNT] = {"conv3x3_fwd_mfma_f32", "conv3x3_dgrad_mfma_f32", "maxpool_fwd", "maxpool_bwd",
                                           "gram_partial_mfma_f32", "gram_reduce", "style_grad_mfma_f32", "layer_elem",
                                           "image_pass", "finalize", "vector_ops", "misc", "conv3x3_fwd_wino_f32", "conv3x3_dgrad_wino_f32",
-                                          "conv3x3_fwd_mfma_bf16", "conv3x3_dgrad_mfma_bf16", "tile_comm"};
+                                          "conv3x3_fwd_mfma_bf16", "conv3x3_dgrad_mfma_bf16", "tile_comm",
+                                          "gram_partial_mfma_bf16", "style_grad_mfma_bf16"};
 
 static const struct { int kind; const char* name; int cin, cout; } kVgg19[] = {
     {0, "conv1_1", 3, 64}, {0, "conv1_2", 64, 64}, {1, "pool1", 0, 0},
@@ -278,7 +279,7 @@ int gram_into(st_ctx* c, const float* F, int C, int hw, const float* target, flo
     const bool use16 = F16 && C % 8 == 0 && hw % 64 == 0 && gram16_ok(C, hw, gram_plan16(C, hw));
     ST_TRY(ensure_gram_bufs(c, C, hw, pl, use16));
     {
-        ProfScope ps(c, P_GRAM, 2.0 * C * C * (double)hw, (use16 ? 2.0 : 4.0) * C * (double)hw);
+        ProfScope ps(c, use16 ? P_GRAM_BF16 : P_GRAM, 2.0 * C * C * (double)hw, (use16 ? 2.0 : 4.0) * C * (double)hw);      // (the class names the matrix core that ran)
         if (use16) HIP_TRY(launch_gram16_partial(F16, c->gram_slabs, C, hw, pl, c->stream));
         else HIP_TRY(launch_gram_partial(F, c->gram_slabs, C, hw, pl, c->stream));
     }

@@ -35,7 +35,7 @@ int fail(int code, const char* fmt, ...);
 // --------------------------------------------------------------------------------------- profiling
 enum ProfClass { P_CONV_FWD, P_CONV_DGRAD, P_POOL_FWD, P_POOL_BWD, P_GRAM, P_GRAM_REDUCE, P_STYLE_GRAD,
                  P_LAYER_ELEM, P_IMAGE_PASS, P_FINALIZE, P_VECTOR, P_MISC, P_CONV_FWD_WINO, P_CONV_DGRAD_WINO,
-                 P_CONV_FWD_BF16, P_CONV_DGRAD_BF16, P_COMM, P_COUNT };
+                 P_CONV_FWD_BF16, P_CONV_DGRAD_BF16, P_COMM, P_GRAM_BF16, P_STYLE_GRAD_BF16, P_COUNT };
 extern const char* const kProfNames[P_COUNT];
 struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
 

@@ -79,7 +79,7 @@ int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad_out, b
             }
             const double fl = 2.0 * C * C * (double)hw;
             auto style_launch = [&](float* dst, int fused, int accumulate) -> int {
-                ProfScope ps(c, P_STYLE_GRAD, fl, n * (s16 ? 6.0 : 8.0));
+                ProfScope ps(c, s16 ? P_STYLE_GRAD_BF16 : P_STYLE_GRAD, fl, n * (s16 ? 6.0 : 8.0));
                 if (s16) HIP_TRY(launch_style_grad16(c->dbuf, conv_mpad(C), c->d16, a.data16[b], dst, c2, fused, al.sw, nrm + 1, accumulate, c->s2_part[b], &cnt[5], C, (size_t)hw, c->stream));
                 else HIP_TRY(launch_style_grad(c->dbuf, a.data[b], dst, c2, fused, al.sw, nrm + 1, accumulate, c->s2_part[b], &cnt[5], C, a.h[b], a.w[b], c->stream));
                 return ST_OK;

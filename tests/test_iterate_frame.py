@@ -220,8 +220,9 @@ def test_worker_exits_when_the_peer_disappears_with_a_frame_in_flight(async_iter
     socks = StallingSockets([messages.SetImages(None, img, img, img, True), messages.StartIteration()], alive=2)
     tr = FakeFramedTransfer(6)
     wk = worker_mod.Worker({'async_iterate': async_iterate, 'zero_copy_iterate': '1'}, sock_in=socks, sock_out=socks, transfer=tr)
-    if async_iterate == '1':
-        wk.sock_out.grace = 0.3
+    sender = wk.sock_out if async_iterate == '1' else None
+    if sender is not None:
+        sender.grace = 0.3
     done = th.Event()
 
     def body():
@@ -246,8 +247,7 @@ def test_worker_exits_when_the_peer_disappears_with_a_frame_in_flight(async_iter
     assert [m.i for m in taken] == [1, 2]                       # what the live peer took arrived intact and in order
     assert len(socks.stuck) >= 1                               # ... and at least one frame really was in flight when it died
     if async_iterate == '1':
-        assert not wk._raw_out is None and isinstance(wk.sock_out, StallingSockets)     # the sender thread is gone
-        assert not [th_ for th_ in th.enumerate() if th_.name == 'iterate-sender' and th_.is_alive()]
+        assert isinstance(wk.sock_out, StallingSockets) and not sender.thread.is_alive()     # the sender thread is gone
 
 
 def test_async_sender_close_is_bounded_when_nothing_is_taken(monkeypatch):

@@ -24,6 +24,7 @@ ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--precision', default='fp32', choices=('fp32', 'bf16'))
 ap.add_argument('--transport', default='device', choices=('device', 'host'))
 ap.add_argument('--optimizer', default='adam', choices=('adam', 'lbfgs'), help='lbfgs: the phase-by-phase driver with all-reduced dot products')
+ap.add_argument('--need-free-gib', type=float, default=0.0, help='print {"skipped": ...} and exit 0 unless this much HBM is free')
 args = ap.parse_args()
 sys.stdout.flush()
 json_out = os.fdopen(os.dup(1), 'w')
@@ -34,6 +35,10 @@ import style_transfer2_amd as st2                                        # noqa:
 from style_transfer2_amd import tiled, tiling, weights as st2_weights    # noqa: E402
 from style_transfer2_amd.tile_backend import HipTileBackend              # noqa: E402
 
+if args.need_free_gib and torch.cuda.mem_get_info()[0] / 2 ** 30 < args.need_free_gib:
+    json_out.write(json.dumps({'skipped': 'only %.0f GiB of HBM free, the eight resident windows need %.0f' % (torch.cuda.mem_get_info()[0] / 2 ** 30, args.need_free_gib)}) + '\n')
+    json_out.flush()
+    sys.exit(0)
 rows, cols = (int(v) for v in args.grid.split('x'))
 gH, gW = (int(v) for v in args.size.split('x')) if 'x' in args.size else (int(args.size), int(args.size))
 WEIGHTS = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1, 'conv5_1': 1},

@@ -43,5 +43,11 @@ for r in it:
         other += (e_ - s_) / 1e3
         print('%-44s %9.1f us gap %6.2f' % (kn.split('(')[0].replace('void st2::', '')[:44], (e_ - s_) / 1e3, gap))
 span = (int(it[-1]['End_Timestamp']) - int(rows[idx[which - 1]]['End_Timestamp'])) / 1e3
+if gaps == 0.0:
+    # rocprofv3's Start_Timestamp of a kernel queued behind another on the same stream is the moment the previous one ended (the
+    # dispatch is already waiting on it), so the ~1.5 us between the last wave of one kernel and the first wave of the next sits
+    # INSIDE the next kernel's duration.  What this does verify: sum of durations == span, i.e. the host never let the stream run dry
+    # (a host-side stall would show as a positive gap).  Compare span with bench.py's ms_per_step to close the loop.
+    print('(gap 0.00 everywhere: back-to-back dispatches -- the inter-kernel bubble is inside each duration; no host-side stall in this iteration)')
 print('kernels other than the matrix-core convs %.1f us; all kernels %.1f us + gaps %.1f us = iteration span %.1f us (%d launches, %.2f us per gap)' % (
     other, busy, gaps, span, len(it), gaps / max(1, len(it))))
