@@ -206,22 +206,28 @@ def fp32_1024():
     aux.forward(net.preprocess(images(1024)[1]), ['conv5_1'])
     g_sty = {n: aux.engine.gram(n) for n in STYLE_LAYERS}
     del aux
-    diffs_b = dict(rec['diffs'])
+    diffs_b, d_rel = dict(rec['diffs']), {}
     for n in STYLE_LAYERS:
         feat = net._blobs[n]                                   # the ORACLE's features (still those of its evaluation at x0)
         c, hw = feat.shape[0], feat.shape[1] * feat.shape[2]
         f2 = feat.reshape(c, hw)
         d_o = oracle.gram(feat[None]) - cpu.grams[n]
         d_e = (g_cur[n] - g_sty[n]).astype(F32)
-        scale = F32(2.0 / (d_o.size * f2.size)) * F32(WEIGHTS['style'][n]) / cpu.norms['s'][n]
-        diffs_b[n] = rec['diffs'][n] + (scale * np.dot(d_e - d_o, f2)).reshape(rec['diffs'][n].shape).astype(F32)
+        # everything downstream of D in the oracle's own arithmetic (worker.py:262-269): S = c2 D F, the first-evaluation norm
+        # N_s = rms(S) -- a function of D too -- and the injected (sw / N_s) S
+        c2, sw = F32(2.0 / (d_o.size * f2.size)), F32(WEIGHTS['style'][n])
+        s_o, s_e = c2 * np.dot(d_o, f2), c2 * np.dot(d_e, f2)
+        n_o, n_e = cpu.norms['s'][n], np.sqrt(np.mean(s_e ** 2))
+        diffs_b[n] = rec['diffs'][n] + ((sw / n_e) * s_e - (sw / n_o) * s_o).reshape(rec['diffs'][n].shape).astype(F32)
+        d_rel[n] = {'D_rel_l2_engine_vs_oracle': rel_l2(d_e, d_o), 'G_over_D': float(np.linalg.norm(g_cur[n]) / np.linalg.norm(d_e)),
+                    'norm_rel': float(abs(n_e - n_o) / n_o)}
     # (a) the oracle's real backward on the diffs of ITS evaluation, masks / arg-max taken from the GPU's forward
     net.adopt_forward_state(blobs)
     go_adopt = go - rec['scd'] + net.backward(rec['diffs'])
     go_adopt_d = go - rec['scd'] + net.backward(diffs_b)
     del blobs
     return dict(net=net, cpu=cpu, dev=dev, lo=lo, go=go, ld=ld, gd=gd, ferr=ferr, flips=flips, relu=relu, pool=pool, total=total,
-                go_adopt=go_adopt, go_adopt_d=go_adopt_d,
+                go_adopt=go_adopt, go_adopt_d=go_adopt_d, d_rel=d_rel,
                 tc=dict(cpu.traces[-1].data), td=dict(dev.traces[-1].data), x0=cpu.input.copy())
 
 
@@ -316,7 +322,7 @@ def test_the_residual_after_adoption_is_the_gram_difference(fp32_1024):
     gd = s['gd']
     err_adopt, err_d = rel_l2(gd, s['go_adopt']), rel_l2(gd, s['go_adopt_d'])
     report('fp32 vgg19 1024 gradient, adopted branches + the engine\'s D in the style terms', {
-        'rel_l2_adopted': err_adopt, 'rel_l2_adopted_with_engine_D': err_d})
+        'rel_l2_adopted': err_adopt, 'rel_l2_adopted_with_engine_D': err_d, 'per_style_layer': s['d_rel']})
     assert err_d <= 5e-6, (err_d, err_adopt)
     assert err_d <= 0.5 * err_adopt, (err_d, err_adopt)
 
