@@ -299,7 +299,9 @@ def test_with_the_gpus_branch_decisions_adopted_the_1024_gradient_agrees_everywh
     objective backward (worker.py:88-106 through oracle.NetOracle.backward, on the diffs its own opfunc injected, worker.py:242-277)
     is run again with the ReLU masks and pool arg-max of the GPU's forward (NetOracle.adopt_forward_state): nothing else changes.
     If flips are the whole story the gradient then agrees EVERYWHERE as well as it did outside the painted fields (1.9e-5).
-    Bar stated before the first run: 2.5e-5 (VERDICT r3 asked for 2e-5; 1.9e-5 was the outside figure, the bar leaves 30 %)."""
+    Bar stated before the first run: 2.5e-5 (VERDICT r3 asked for 2e-5; 1.9e-5 was the outside figure, the bar leaves 30 %).
+    Measured on MI355X: 6.52e-4 plain -> 1.905e-5 with the 66 branch decisions adopted; largest single deviation 2.6e-5 of the
+    largest gradient."""
     s = fp32_1024
     go, gd, ga = s['go'], s['gd'], s['go_adopt']
     err_plain, err_adopt = rel_l2(gd, go), rel_l2(gd, ga)
@@ -317,7 +319,9 @@ def test_the_residual_after_adoption_is_the_gram_difference(fp32_1024):
     """Round 3 ATTRIBUTED the 1.9e-5 that remains to "the fp32 summation order of the million-term Gram sums that enter
     D = G - G_style" (content and style are both noise images here: G is nearly G_style, D a small difference of large sums).
     Asserted: hand the oracle the ENGINE's D in its style terms (same features, same norms, same backward on the adopted state)
-    and the residual must fall below 5e-6 -- a quarter of what it was -- or that sentence is wrong."""
+    and the residual must fall below 5e-6 -- a quarter of what it was -- or that sentence is wrong.
+    Measured on MI355X: 1.905e-5 -> 6.6e-7.  |G| / |D| is 277 (conv1_1) .. 576 (conv3_1) on these inputs, the two D differ by
+    0.9e-4 .. 2.8e-4 in relative L2, the first-evaluation norms N_s by up to 2.6e-5."""
     s = fp32_1024
     gd = s['gd']
     err_adopt, err_d = rel_l2(gd, s['go_adopt']), rel_l2(gd, s['go_adopt_d'])
@@ -544,27 +548,67 @@ def test_image_like_job_fp32_engine_follows_the_oracle_over_five_lbfgs_steps(ima
     assert mse <= 0.05 * moved, (mse, moved)
 
 
+# What "bf16 follows fp32" can mean is set by the arithmetic, not by the kernels: the ROUNDED-OPERAND ORACLE (the same numpy code with
+# every conv operand rounded to bf16) run against its own fp32 self on this job at 192 x 256, 20 L-BFGS steps, drifts by up to 12 % in
+# the per-step loss and ends 10.3 % (MSE) of the move away (measured on the CPU before these tests were written; the first of the
+# tests below re-measures it at 12 steps next to the engine).  The bars first stated for the engine -- 1 % / 5 % -- were tighter than
+# the reference arithmetic itself and failed at 2.6 % / 9.5 %; they are now anchored to that measurement.
+BF16_LOSS_RTOL, BF16_MSE_OF_MOVE = 5e-2, 0.15
+
+
+def test_bf16_engine_drifts_from_fp32_no_more_than_the_rounded_operand_oracle_does():
+    """192 x 256 (the pair fitted to 256 px), 12 L-BFGS steps (through the roll-over at ten pairs), four runs: oracle fp32 / oracle
+    with bf16 conv operands / engine fp32 / engine bf16.  The engine's bf16-vs-fp32 drift (per-step loss, final iterate) must not
+    exceed twice the oracle's own bf16-vs-fp32 drift."""
+    inputs = _image_like(256)
+    content, style, init = inputs
+    topo = oracle.VGG19_TOPOLOGY
+
+    def cpu_run(operands):
+        job = oracle.TransferOracle(oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False, operands=operands))
+        job.set_input(init); job.set_content(content); job.set_style(style); job.reset()
+        job.set_weights(WEIGHTS, PARAMS)
+        job.set_optimizer('lbfgs', 1)
+        assert job.start()
+        losses = []
+        for _ in range(12):
+            img, tr = job.step()
+            losses.append(tr['loss'])
+        return losses, img
+    lo32, io32 = cpu_run('fp32')
+    lo16, io16 = cpu_run('bf16')
+    le32, ke32 = _image_like_engine_run(inputs, 'fp32', 12, (12,))
+    le16, ke16 = _image_like_engine_run(inputs, 'bf16', 12, (12,))
+    rel_o, mse_o, moved_o = _trajectory_report('image-like 192x256, 12 L-BFGS steps: ORACLE bf16 operands vs oracle fp32', lo32, lo16, io32, io16, init)
+    rel_e, mse_e, moved_e = _trajectory_report('image-like 192x256, 12 L-BFGS steps: engine bf16 vs engine fp32', le32, le16, ke32[12], ke16[12], init)
+    rel_x, mse_x, _ = _trajectory_report('image-like 192x256, 12 L-BFGS steps: engine fp32 vs oracle fp32', lo32, le32, io32, ke32[12], init)
+    assert max(rel_x[:5]) <= 1e-4, rel_x                                   # fp32 against fp32: tight while rounding has not been amplified
+    assert max(rel_e) <= 2 * max(rel_o) + 1e-2, (rel_e, rel_o)
+    assert mse_e / moved_e <= 2 * mse_o / moved_o + 0.02, (mse_e, moved_e, mse_o, moved_o)
+
+
 def test_image_like_job_bf16_follows_the_fp32_engine_over_twenty_lbfgs_steps(image_like_1024):
     """configs[2]'s arithmetic (bf16 conv operands, fp32 accumulate / Gram / optimizer; Gram-form L-BFGS) against the fp32 engine
-    on the same image-like job, twenty L-BFGS steps -- through the history roll-over at ten pairs.  Bars stated before the first
-    run: per-step loss rtol 1e-2, final iterate within 5 % (MSE) of how far it moved."""
+    on the same image-like job at 768 x 1024, twenty L-BFGS steps -- through the history roll-over at ten pairs.  Measured on MI355X:
+    per-step loss within 2.6 %, final iterate 9.5 % (MSE) of the move away, final losses 1.274e8 / 1.240e8 from 2.56e9."""
     s = image_like_1024
     lb, kb = _image_like_engine_run(s['inputs'], 'bf16', 20, (20,))
     rel, mse, moved = _trajectory_report('image-like 768x1024, 20 L-BFGS steps: bf16 vs fp32 engine', s['losses'], lb, s['images'][20], kb[20], s['inputs'][2])
-    assert s['losses'][-1] < 0.1 * s['losses'][0] and lb[-1] < 0.1 * lb[0], (s['losses'], lb)
-    assert max(rel) <= 1e-2, rel
-    assert mse <= 0.05 * moved, (mse, moved)
+    assert s['losses'][-1] < 0.1 * s['losses'][0] and lb[-1] < 0.1 * lb[0], (s['losses'], lb)         # both contract by more than 10x
+    assert max(rel) <= BF16_LOSS_RTOL, rel
+    assert mse <= BF16_MSE_OF_MOVE * moved, (mse, moved)
 
 
 def test_image_like_job_bf16_follows_the_fp32_engine_at_2048():
-    """The same at configs[2]'s own size: the pair fitted to 2048 px (content 1536 x 2048), five L-BFGS steps, bf16 against fp32."""
+    """The same at configs[2]'s own size: the pair fitted to 2048 px (content 1536 x 2048), five L-BFGS steps, bf16 against fp32.
+    Measured on MI355X: per-step loss within 3.0 %, final iterate 5.2 % (MSE) of the move away."""
     inputs = _image_like(2048)
     la, ka = _image_like_engine_run(inputs, 'fp32', 5, (5,))
     lb, kb = _image_like_engine_run(inputs, 'bf16', 5, (5,))
     rel, mse, moved = _trajectory_report('image-like 1536x2048, 5 L-BFGS steps: bf16 vs fp32 engine', la, lb, ka[5], kb[5], inputs[2])
     assert la[-1] < 0.5 * la[0] and lb[-1] < 0.5 * lb[0], (la, lb)
-    assert max(rel) <= 1e-2, rel
-    assert mse <= 0.05 * moved, (mse, moved)
+    assert max(rel) <= BF16_LOSS_RTOL, rel
+    assert mse <= BF16_MSE_OF_MOVE * moved, (mse, moved)
 
 
 # ------------------------------------------------------------------------------ weights with trained-like statistics
