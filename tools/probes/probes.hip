@@ -498,13 +498,14 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     HIP_TRY(hipMemcpy(din, hin.data(), n_in * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dw, pk.data(), pk.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(db, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
-    if (dgrad_epilogue) {
-        ST_TRY(dmalloc(&dmask, n_out)); ST_TRY(dmalloc(&dinj, n_out));
-        for (size_t off = 0; off < n_out; off += n_in) {      // reuse the random input as mask / inject data
-            const size_t n = std::min(n_in, n_out - off);
-            HIP_TRY(hipMemcpy(dmask + off, din, n * 4, hipMemcpyDeviceToDevice));
-            HIP_TRY(hipMemcpy(dinj + off, din, n * 4, hipMemcpyDeviceToDevice));
-        }
+    // dgrad_epilogue: 1 = ReLU mask + injected diff, 2 = mask only, 3 = injected diff only, 4 = neither (a data gradient's bare store)
+    const bool want_mask = dgrad_epilogue == 1 || dgrad_epilogue == 2, want_inj = dgrad_epilogue == 1 || dgrad_epilogue == 3;
+    if (want_mask) ST_TRY(dmalloc(&dmask, n_out));
+    if (want_inj) ST_TRY(dmalloc(&dinj, n_out));
+    for (size_t off = 0; off < n_out && dgrad_epilogue; off += n_in) {      // reuse the random input as mask / inject data
+        const size_t n = std::min(n_in, n_out - off);
+        if (want_mask) HIP_TRY(hipMemcpy(dmask + off, din, n * 4, hipMemcpyDeviceToDevice));
+        if (want_inj) HIP_TRY(hipMemcpy(dinj + off, din, n * 4, hipMemcpyDeviceToDevice));
     }
     ConvProblem p{};
     p.in = din; p.wpack = dw; p.bias = dgrad_epilogue ? nullptr : db; p.out = dout; p.mask_src = dmask; p.inject = dinj;

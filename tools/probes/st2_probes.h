@@ -13,7 +13,8 @@ const char* st_probe_last_error(void);
  * data).  cfg < 0: the engine's own tile choice (returned in *cfg_used); cfg >= 100: the Winograd kernel (100: its own
  * choice incl. split-K, 101: 128 ch x 4x32 px, 102: 64 ch x 8x32 px, 104: 64 ch x 8x32 px position-split,
  * 103 / 106 / 105: those with cycle stamps).
- * dgrad_epilogue != 0 adds the ReLU-mask + injected-diff epilogue of the backward pass. */
+ * dgrad_epilogue: 0 = forward (bias + ReLU); 1 = the backward pass's ReLU mask + injected diff, 2 = mask only, 3 = injected diff
+ * only, 4 = neither -- what the mask / inject loads of an epilogue cost, as an upper bound on what any cheaper mask can give back. */
 int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_epilogue, int iters,
                   double* avg_ms, int* cfg_used);
 int st_conv_num_configs(void);
