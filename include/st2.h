@@ -199,7 +199,10 @@ int st_tile_strips(st_ctx* ctx, void* tensor_dev, int C, int wh, int ww, int n, 
  * (periodic TV).  The geometry and the exchange plan come from the caller (style_transfer2_amd/tiling.py). */
 #define ST_COMM_ID_BYTES 128
 int st_comm_unique_id(char out_id[ST_COMM_ID_BYTES]);                       /* ncclGetUniqueId: on rank 0, then handed to every rank */
-int st_comm_init(st_ctx* ctx, const char id[ST_COMM_ID_BYTES], int rank, int world);      /* ncclCommInitRank on the context's device */
+/* ncclCommInitRank on the context's device.  Preflight first, so that a mis-launch is an error here and not a hang in the first
+ * collective: RCCL >= 2.7 (grouped send / recv), every peer of a plan already handed over < world (world = rows x cols of the grid);
+ * devices without direct peer access are reported on stderr. */
+int st_comm_init(st_ctx* ctx, const char id[ST_COMM_ID_BYTES], int rank, int world);
 /* A caller-supplied transport in place of RCCL (the tests run several ranks on ONE GPU, which RCCL refuses): allreduce sums `n` floats
  * in place over the ranks; exchange sends send_buf[i] (send_count[i] floats) to send_peer[i] and fills recv_buf[j] from recv_peer[j].
  * All buffers are device memory; the engine has synchronised its stream before the call and the data must be in place on return. */
@@ -216,10 +219,16 @@ int st_comm_barrier(st_ctx* ctx);                                            /* 
 enum { ST_TILE_PLAN_OVERLAP = 0, ST_TILE_PLAN_RING = 1, ST_TILE_PLAN_REFRESH = 2 };
 typedef struct st_tile_peer { int peer; int n_send; const int* send_rects; int n_recv; const int* recv_rects; } st_tile_peer;
 int st_tile_plan(st_ctx* ctx, int phase, int n_peers, const st_tile_peer* peers);
-/* One Adam iteration of the tile-sharded image (after st_tile_configure, st_comm_init / st_comm_callbacks and the three st_tile_plan
- * calls): forward -> all-reduce -> losses (first evaluation: style gradients raw -> all-reduce) -> backward -> overlap-add exchange ->
- * ring exchange -> TV / p-norm / Adam on the tile -> all-reduce -> apron refresh exchange -> swap.  trace: st_trace_len(ctx) values,
- * the layout of st_step's. */
+/* One iteration of the tile-sharded image with the optimizer st_optimizer_reset chose (after st_tile_configure, st_comm_init /
+ * st_comm_callbacks and the three st_tile_plan calls).
+ * Adam (optimizers.py:20-27): forward -> all-reduce -> losses (first evaluation: style gradients raw -> all-reduce) -> backward ->
+ * overlap-add exchange -> ring exchange -> TV / p-norm / Adam on the tile -> all-reduce -> apron refresh exchange -> swap.
+ * L-BFGS (optimizers.py:62-108, the reference's default: worker.py:135-136): every rank keeps its tile of x, of the gradient and of the
+ * <= 10 curvature pairs; the direction is formed in the Gram form (coefficients from the matrix of inner products of {s_i, y_i, g}):
+ * apply s = -step * H g to the tile -> apron refresh exchange -> the evaluation above with the combined gradient in place of the Adam
+ * update -> ONE all-reduce of this step's 2 (2 k + 3) new inner products -> the s.y > 1e-10 gate, eviction and the next coefficients,
+ * identically on every rank.  The first step after a reset evaluates twice (optimizers.py:64-65).
+ * trace: st_trace_len(ctx) values, the layout of st_step's; NULL: nothing is read back and the call does not wait for the GPU. */
 int st_tile_step(st_ctx* ctx, double* trace);
 int st_tile_get_tile(st_ctx* ctx, float* out_hwc);                           /* this rank's tile of the current iterate, (th, tw, 3) deprocessed */
 

@@ -625,7 +625,7 @@ int st_destroy(st_ctx* c)
     for (auto& p : c->sfuse_w) dfree16(p);
     dfree(c->diffA); dfree(c->diffB); dfree(c->stmp); dfree(c->gram_slabs); dfree(c->gram_fold); dfree(c->dbuf); dfree16(c->d16); dfree(c->conv_scratch);
     comm_free(c);
-    dfree(c->tile.p1); dfree(c->tile.p2); dfree(c->tile.p3); dfree(c->tile.pd); dfree(c->tile.wgrad);
+    dfree(c->tile.p1); dfree(c->tile.p2); dfree(c->tile.p3); dfree(c->tile.pd); dfree(c->tile.wgrad); dfree(c->tile.lb_x); dfree(c->tile.lb_sums);
     dfree(c->norms); dfree(c->image_part); dfree(c->trace_dev); dfree(c->lb_part); dfree(c->hwc_dev);
     if (c->lb_dev) (void)hipFree(c->lb_dev);
     if (c->lb_gram) (void)hipFree(c->lb_gram);

@@ -182,6 +182,9 @@ struct st_ctx {
         bool s2_in_p2 = false;
         float* wgrad = nullptr;                    // window gradient (3, wh, ww)
         bool fused = false;                        // inside st_tile_step: the phases do not synchronise the stream on their own
+        // fused L-BFGS over the sharded image (engine_comm.cpp): this rank's tile of x as a compact (3, th, tw) vector, the sums of
+        // one inner-product pass (all-reduced), and the global image size the unit-RMS first direction divides by
+        float* lb_x = nullptr; float* lb_sums = nullptr; size_t lb_n = 0;
     } tile;
     // communicator of the tile-sharded mode (engine_comm.cpp): RCCL over xGMI, or caller-supplied transport functions (tests)
     struct Comm {
@@ -262,6 +265,7 @@ int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad_out, b
 int read_trace(st_ctx* c, double* trace, float* loss);
 // ---------------------------------------------------------------------------------------- engine_step.cpp
 int lbfgs_alloc(st_ctx* c);
+LbfgsArgs lbfgs_args(st_ctx* c, int apply);
 // ---------------------------------------------------------------------------------------- engine_comm.cpp
 void comm_free(st_ctx* c);
 }  // namespace st2e

@@ -20,10 +20,12 @@ typedef const char* (*fn_errstr)(int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_sendrecv)(void*, size_t, int, int, void*, hipStream_t);
 typedef int (*fn_group)(void);
+typedef int (*fn_version)(int*);
 static struct Rccl {
     void* lib = nullptr;
     fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_destroy destroy = nullptr; fn_errstr errstr = nullptr;
     fn_allreduce allreduce = nullptr; fn_sendrecv send = nullptr, recv = nullptr; fn_group group_start = nullptr, group_end = nullptr;
+    fn_version version = nullptr;
 } g_rccl;
 constexpr int kNcclFloat = 7, kNcclSum = 0;        // ncclFloat32, ncclSum (rccl.h)
 
@@ -40,6 +42,7 @@ static int rccl_load()
     r.destroy = (fn_destroy)dlsym(lib, "ncclCommDestroy"); r.errstr = (fn_errstr)dlsym(lib, "ncclGetErrorString");
     r.allreduce = (fn_allreduce)dlsym(lib, "ncclAllReduce"); r.send = (fn_sendrecv)dlsym(lib, "ncclSend"); r.recv = (fn_sendrecv)dlsym(lib, "ncclRecv");
     r.group_start = (fn_group)dlsym(lib, "ncclGroupStart"); r.group_end = (fn_group)dlsym(lib, "ncclGroupEnd");
+    r.version = (fn_version)dlsym(lib, "ncclGetVersion");
     if (!r.get_id || !r.init_rank || !r.destroy || !r.errstr || !r.allreduce || !r.send || !r.recv || !r.group_start || !r.group_end) {
         dlclose(lib);
         return fail(ST_ERR_HIP, "librccl.so lacks an entry point this engine needs");
@@ -220,6 +223,28 @@ int st_comm_init(st_ctx* c, const char id[ST_COMM_ID_BYTES], int rank, int world
     if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(ST_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     ST_TRY(rccl_load());
+    // Preflight: everything that would otherwise show up as a hang inside the first collective is checked here and reported.
+    if (g_rccl.version) {                        // grouped ncclSend / ncclRecv (the strip exchanges) exist since 2.7
+        int v = 0;
+        if (g_rccl.version(&v) == 0 && v < 2700) return fail(ST_ERR_HIP, "librccl reports version %d: the strip exchanges need ncclSend / ncclRecv (>= 2.7)", v);
+    }
+    if (c->tile.on && c->comm.planned[0]) {      // plans handed over before the communicator: their peers must exist in this world
+        for (int ph = 0; ph < 3; ++ph)
+            for (const auto& p : c->comm.plan[ph])
+                if (p.peer >= world) return fail(ST_ERR_ARG, "the exchange plan of phase %d names rank %d but the communicator has %d ranks (world must equal rows x cols of the tile grid)", ph, p.peer, world);
+    }
+    {   // xGMI is point to point: a peer this device cannot reach directly makes RCCL stage through the host -- legal, slow, worth a line
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 1) {
+            int unreachable = 0;
+            for (int d = 0; d < ndev; ++d) {
+                int ok = 1;
+                if (d != c->device && hipDeviceCanAccessPeer(&ok, c->device, d) == hipSuccess && !ok) ++unreachable;
+            }
+            if (unreachable) fprintf(stderr, "st_comm_init: device %d has no direct peer access to %d of the %d visible devices (RCCL will stage through host memory)\n", c->device, unreachable, ndev - 1);
+        }
+        (void)hipGetLastError();
+    }
     if (c->comm.comm) { (void)g_rccl.destroy(c->comm.comm); c->comm.comm = nullptr; }
     RcclId uid;
     memcpy(uid.internal, id, ST_COMM_ID_BYTES);
@@ -275,6 +300,8 @@ int st_tile_plan(st_ctx* c, int phase, int n_peers, const st_tile_peer* peers)
         const st_tile_peer& q = peers[i];
         if (q.n_send < 0 || q.n_recv < 0 || (q.n_send && !q.send_rects) || (q.n_recv && !q.recv_rects)) return fail(ST_ERR_ARG, "peer %d: bad rectangle lists", i);
         if (i && q.peer <= peers[i - 1].peer) return fail(ST_ERR_ARG, "peers must be listed in ascending order, once each");
+        if (q.peer < 0 || (comm_ready(c) && c->comm.world > 1 && q.peer >= c->comm.world))
+            return fail(ST_ERR_ARG, "peer %d does not exist in a communicator of %d ranks (world must equal rows x cols of the tile grid)", q.peer, c->comm.world);
         st_ctx::Comm::Peer p;
         p.peer = q.peer;
         p.send.assign(q.send_rects, q.send_rects + 4 * q.n_send);
@@ -295,25 +322,22 @@ int st_tile_plan(st_ctx* c, int phase, int n_peers, const st_tile_peer* peers)
     return ST_OK;
 }
 
-int st_tile_step(st_ctx* c, double* trace)
+// One objective evaluation of the sharded image at x[cur] (worker.py:231-301 over all ranks): forward -> all-reduce of the phase-1 sums
+// -> losses (first evaluation: raw style gradients -> all-reduce) -> ranged backward -> overlap-add of the window gradients -> the
+// torus ring of the TV stencil -> image-space pass.  adam: that pass is the fused TV / p-norm / Adam update into x[cur ^ 1]; else it
+// leaves the combined gradient of the tile's pixels in c->grad (window layout).  The phase-3 sums are all-reduced either way.
+struct TileEval { float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; int n1 = 0, n2 = 0, n3 = 0; };
+static int tile_evaluate(st_ctx* c, bool adam, TileEval& e)
 {
-    if (c) c->epoch++;
-    if (!c || !c->tile.on) return fail(ST_ERR_STATE, "st_tile_configure first");
-    if (!comm_ready(c)) return fail(ST_ERR_STATE, "st_comm_init (or st_comm_callbacks) first");
-    if (c->opt_kind != ST_OPT_ADAM) return fail(ST_ERR_STATE, "the fused tile-sharded iteration implements Adam");
-    HIP_TRY(hipSetDevice(c->device));
     st_ctx::Tile& t = c->tile;
     const int wh = c->H, ww = c->W, th = t.ty1 - t.ty0, tw = t.tx1 - t.tx0;
-    struct Unfuse { st_ctx* c; ~Unfuse() { c->tile.fused = false; } } unfuse{c};
-    t.fused = true;
-    float* p1 = nullptr; float* p2 = nullptr; float* p3 = nullptr; float* wgrad = nullptr;
-    int n1 = 0, n2 = 0, n3 = 0;
-    ST_TRY(st_tile_forward(c, &p1, &n1));                                       // phase 1: forward, region sums + raw Gram sums
-    ST_TRY(comm_allreduce(c, p1, n1));
-    ST_TRY(st_tile_losses(c, &p2, &n2));                                        // phase 2: norms (first evaluation: raw style gradients)
-    if (n2) {
+    float* wgrad = nullptr;
+    ST_TRY(st_tile_forward(c, &e.p1, &e.n1));                                   // phase 1: forward, region sums + raw Gram sums
+    ST_TRY(comm_allreduce(c, e.p1, e.n1));
+    ST_TRY(st_tile_losses(c, &e.p2, &e.n2));                                    // phase 2: norms (first evaluation: raw style gradients)
+    if (e.n2) {
         ST_TRY(st_tile_style_raw(c));
-        ST_TRY(comm_allreduce(c, p2, n2));
+        ST_TRY(comm_allreduce(c, e.p2, e.n2));
     }
     ST_TRY(st_tile_losses_finish(c));
     ST_TRY(st_tile_backward(c, &wgrad));                                        // phase 3: ranged backward on the window
@@ -322,23 +346,111 @@ int st_tile_step(st_ctx* c, double* trace)
     if (ring_n > c->comm.ring_cap) { HIP_TRY(hipStreamSynchronize(c->stream)); dfree(c->comm.ring); c->comm.ring_cap = 0; ST_TRY(dmalloc(&c->comm.ring, ring_n)); c->comm.ring_cap = ring_n; }
     HIP_TRY(hipMemsetAsync(c->comm.ring, 0, ring_n * sizeof(float), c->stream));
     ST_TRY(comm_exchange(c, ST_TILE_PLAN_RING, c->x[c->cur], wh, ww, c->comm.ring, th + 2, tw + 2, false));
-    ST_TRY(st_tile_update(c, c->comm.ring, &p3, &n3));                          // phase 4: TV / p-norm / Adam on the tile
-    ST_TRY(comm_allreduce(c, p3, n3));
-    ST_TRY(comm_exchange(c, ST_TILE_PLAN_REFRESH, c->x[c->cur ^ 1], wh, ww, c->x[c->cur ^ 1], wh, ww, false));
-    // the trace: the reduced sums cross PCIe (a few KB + the Gram sums), the scalars are finished on the host
+    if (adam) ST_TRY(st_tile_update(c, c->comm.ring, &e.p3, &e.n3));            // phase 4: TV / p-norm / Adam on the tile
+    else ST_TRY(st_tile_gradient(c, c->comm.ring, &e.p3, &e.n3));               //          or the combined gradient only
+    ST_TRY(comm_allreduce(c, e.p3, e.n3));
+    return ST_OK;
+}
+
+// the trace of the evaluation just enqueued: the reduced sums cross PCIe (a few KB + the Gram sums), the scalars are finished on the host
+static int tile_read_trace(st_ctx* c, const TileEval& e, double* trace)
+{
     int n_style = 0;
     for (const ActiveLayer& al : c->active) n_style += al.s;
-    std::vector<float> h1(std::max(n1, 1)), h2(std::max(n_style, 1)), h3(6 + kMaxTraceLayers), hd(std::max(n_style, 1)), hn((size_t)c->nb * 3);
-    if (trace) {
-        if (n1) HIP_TRY(hipMemcpyAsync(h1.data(), p1, (size_t)n1 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        if (n2) HIP_TRY(hipMemcpyAsync(h2.data(), p2, (size_t)n2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(h3.data(), p3, (size_t)n3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        if (n_style) HIP_TRY(hipMemcpyAsync(hd.data(), t.pd, (size_t)n_style * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(hn.data(), c->norms, hn.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    std::vector<float> h1(std::max(e.n1, 1)), h2(std::max(n_style, 1)), h3(6 + kMaxTraceLayers), hd(std::max(n_style, 1)), hn((size_t)c->nb * 3);
+    if (e.n1) HIP_TRY(hipMemcpyAsync(h1.data(), e.p1, (size_t)e.n1 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (e.n2) HIP_TRY(hipMemcpyAsync(h2.data(), e.p2, (size_t)e.n2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h3.data(), e.p3, (size_t)e.n3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    if (n_style) HIP_TRY(hipMemcpyAsync(hd.data(), c->tile.pd, (size_t)n_style * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(hn.data(), c->norms, hn.size() * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    tile_trace(c, h1.data(), e.n2 ? h2.data() : h3.data() + 6, h3.data(), hd.data(), hn.data(), trace);
+    return ST_OK;
+}
+
+// LBFGSOptimizer.step (optimizers.py:62-108) over the sharded image, fused: every rank keeps its TILE of x, of the gradient and of
+// the <= 10 curvature pairs as compact (3, th, tw) vectors and runs the Gram form of the recursion (lbfgs.hip): the direction is a
+// linear combination of {s_i, y_i, g} whose coefficients follow from the matrix of their inner products.  One pass over the tile's
+// vectors yields this rank's share of the 2 (2k + 3) inner products a new pair and a new gradient add; ONE all-reduce of that
+// 2 kLbNB-vector replaces the <= 2k + 3 scalar all-reduces of the chain form (tiled.TiledTransfer), after which every rank runs the same
+// bookkeeping (the s.y > 1e-10 gate, eviction) and coefficient recursion on the same numbers.  Per step: 2 all-reduces + 3 exchanges
+// for the evaluation, 1 all-reduce for the pair, 1 apron refresh.
+static int tile_lbfgs_step(st_ctx* c, TileEval& e)
+{
+    st_ctx::Tile& t = c->tile;
+    const int wh = c->H, ww = c->W, th = t.ty1 - t.ty0, tw = t.tx1 - t.tx0;
+    const size_t n_t = (size_t)3 * th * tw;
+    ST_TRY(lbfgs_alloc(c));                                                     // (window-sized vectors: the tile's fit)
+    if (t.lb_n != n_t) {
         HIP_TRY(hipStreamSynchronize(c->stream));
-        tile_trace(c, h1.data(), n2 ? h2.data() : h3.data() + 6, h3.data(), hd.data(), hn.data(), trace);
+        dfree(t.lb_x); dfree(t.lb_sums);
+        ST_TRY(dmalloc(&t.lb_x, n_t)); ST_TRY(dmalloc(&t.lb_sums, (size_t)lbfgs_gram_rows()));
+        HIP_TRY(hipMemset(c->lb_gpart, 0, (size_t)lbfgs_gram_rows() * kMaxPartials * sizeof(float)));      // rows of dead ids are summed too (never used)
+        t.lb_n = n_t;
     }
-    c->cur ^= 1;                                                                // st_tile_swap
+    hipStream_t s = c->stream;
+    const std::vector<int> tile_rect = {t.ty0 - t.wy0, t.tx0 - t.wx0, th, tw};
+    auto args = [&](int apply) {
+        LbfgsArgs a = lbfgs_args(c, apply);
+        a.n = n_t; a.n_global = (size_t)3 * t.gH * t.gW; a.x = t.lb_x; a.gsums = t.lb_sums;
+        return a;
+    };
+    if (c->lb_clear) {              // objective_changed / a new optimizer: sy = [], ss = [], ys = [] (optimizers.py:121-125)
+        HIP_TRY(hipMemsetAsync(c->lb_dev, 0, sizeof(LbfgsDev), s));
+        HIP_TRY(hipMemsetAsync(c->lb_gram, 0, sizeof(LbfgsGram), s));
+        c->lb_clear = false;
+        c->lb_gram_form = true;
+        c->have_cur = false;
+    }
+    if (!c->lb_gram_form) return fail(ST_ERR_STATE, "the history was built by the chain form: reset the optimizer before the fused tile-sharded L-BFGS");
+    if (!c->have_cur) {             // optimizers.py:64-65: loss, grad at the starting point
+        ST_TRY(tile_evaluate(c, false, e));
+        ST_TRY(strips(c, c->grad, 3, wh, ww, tile_rect, c->g_cur, 0));
+        { ProfScope ps(c, P_VECTOR, 0, 4.0 * n_t);
+          HIP_TRY(launch_lbfgs_gram_pass_local(args(1), nullptr, 0, s)); }
+        ST_TRY(comm_allreduce(c, t.lb_sums, lbfgs_gram_rows()));
+        HIP_TRY(launch_lbfgs_gram_commit_global(args(1), 0, s));
+        c->have_cur = true;
+    }
+    {   // s = -step * inv_hv(grad); x += s on the tile (optimizers.py:68-69, 89-108), then the neighbours' aprons follow
+        ST_TRY(strips(c, c->x[c->cur], 3, wh, ww, tile_rect, t.lb_x, 0));
+        { ProfScope ps(c, P_VECTOR, 0, 4.0 * n_t * (2.0 * kLbfgsCorr + 4.0));
+          HIP_TRY(launch_lbfgs_gram_apply(args(1), s)); }
+        ST_TRY(strips(c, c->x[c->cur], 3, wh, ww, tile_rect, t.lb_x, 1));
+        ST_TRY(comm_exchange(c, ST_TILE_PLAN_REFRESH, c->x[c->cur], wh, ww, c->x[c->cur], wh, ww, false));
+    }
+    ST_TRY(tile_evaluate(c, false, e));                                         // loss, grad = opfunc(x)           (optimizers.py:72)
+    ST_TRY(strips(c, c->grad, 3, wh, ww, tile_rect, c->pvec, 0));               // this rank's tile of the new gradient
+    {   // y = grad - self.grad; store_curvature_pair(s, y)                                                         (optimizers.py:73-87)
+        { ProfScope ps(c, P_VECTOR, 0, 4.0 * n_t * (2.0 * kLbfgsCorr + 4.0));
+          HIP_TRY(launch_lbfgs_gram_pass_local(args(1), c->pvec, 1, s)); }
+        ST_TRY(comm_allreduce(c, t.lb_sums, lbfgs_gram_rows()));
+        HIP_TRY(launch_lbfgs_gram_commit_global(args(1), 1, s));
+    }
+    std::swap(c->g_cur, c->pvec);
+    return ST_OK;
+}
+
+int st_tile_step(st_ctx* c, double* trace)
+{
+    if (c) c->epoch++;
+    if (!c || !c->tile.on) return fail(ST_ERR_STATE, "st_tile_configure first");
+    if (!comm_ready(c)) return fail(ST_ERR_STATE, "st_comm_init (or st_comm_callbacks) first");
+    if (c->opt_kind != ST_OPT_ADAM && c->opt_kind != ST_OPT_LBFGS) return fail(ST_ERR_STATE, "no optimizer: call st_optimizer_reset first");
+    HIP_TRY(hipSetDevice(c->device));
+    const int wh = c->H, ww = c->W;
+    struct Unfuse { st_ctx* c; ~Unfuse() { c->tile.fused = false; } } unfuse{c};
+    c->tile.fused = true;
+    TileEval e;
+    if (c->opt_kind == ST_OPT_LBFGS) {
+        ST_TRY(tile_lbfgs_step(c, e));
+        if (trace) ST_TRY(tile_read_trace(c, e, trace));                        // (x was updated in place: no swap)
+    } else {
+        ST_TRY(tile_evaluate(c, true, e));
+        ST_TRY(comm_exchange(c, ST_TILE_PLAN_REFRESH, c->x[c->cur ^ 1], wh, ww, c->x[c->cur ^ 1], wh, ww, false));
+        if (trace) ST_TRY(tile_read_trace(c, e, trace));
+        c->cur ^= 1;                                                            // st_tile_swap
+    }
     c->comm.steps += 1;
     return ST_OK;
 }

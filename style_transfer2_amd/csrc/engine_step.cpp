@@ -38,6 +38,7 @@ LbfgsArgs lbfgs_args(st_ctx* c, int apply)
     a.gm = c->lb_gram; a.gpart = c->lb_gpart;
     a.g = c->g_cur; a.p = c->pvec; a.x = c->x[c->cur];
     a.n = (size_t)3 * c->H * c->W; a.step = (float)c->step_size; a.apply = apply;
+    a.gsums = nullptr; a.n_global = 0;
     return a;
 }
 

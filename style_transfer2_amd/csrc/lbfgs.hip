@@ -408,14 +408,21 @@ __device__ void lbfgs_gram_recursion(GramShared& g, size_t n, int lane)
 
 // ---- bookkeeping after pass 1 (one workgroup): B rows of the candidate pair and of the new gradient, gate / commit / eviction
 //      (optimizers.py:79-87, as lbfgs_commit_k), then the coefficients of the next direction
-__global__ __launch_bounds__(256) void lbfgs_gram_commit_k(const LbfgsArgs a, const int mode)
+__global__ __launch_bounds__(256) void lbfgs_gram_commit_k(const LbfgsArgs a, const int mode_arg)
 {
     __shared__ GramShared g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     LbfgsDev* st = a.st;
     LbfgsGram* gm = a.gm;
     static_assert(kLbGrid == 1024, "a lane takes four 16-byte pieces of a row of partial sums");
-    if (mode != 2) {                            // partial sums: wave w takes rows w, w + 4, ...; every load first, then the (fixed-order) sums
+    // mode 3 (tile-sharded): this rank's sums only -> a.gsums, no bookkeeping; modes 4 / 5: modes 0 / 1 on sums the caller has
+    // all-reduced into a.gsums
+    const bool from_sums = mode_arg >= 4;
+    const bool sums_only = mode_arg == 3;
+    const int mode = from_sums ? mode_arg - 4 : sums_only ? 0 : mode_arg;
+    if (from_sums) {
+        for (int r = tid; r < kLbGramRows; r += 256) g.sums[r] = (double)a.gsums[r];
+    } else if (mode != 2) {                     // partial sums: wave w takes rows w, w + 4, ...; every load first, then the (fixed-order) sums
         constexpr int kRowsPerWave = (kLbGramRows + 3) / 4;
         double racc[kRowsPerWave];
 #pragma unroll
@@ -437,6 +444,11 @@ __global__ __launch_bounds__(256) void lbfgs_gram_commit_k(const LbfgsArgs a, co
             for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
             if (lane == 0 && r < kLbGramRows) g.sums[r] = acc;
         }
+    }
+    if (sums_only) {                            // (uniform) this rank's share of every inner product, rounded to fp32 as sdot returns it
+        __syncthreads();
+        for (int r = tid; r < kLbGramRows; r += 256) a.gsums[r] = (float)g.sums[r];
+        return;
     }
     for (int i = tid; i < kLbNB * kLbNB; i += 256) g.B[i / kLbNB][i % kLbNB] = gm->B[i / kLbNB][i % kLbNB];
     if (tid < kLbNB) g.delta[tid] = gm->delta[tid];
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(256) void lbfgs_gram_commit_k(const LbfgsArgs a, co
         if (mode != 2) g.B[kIdG][kIdG] = G[kIdG];
     }                                           // mode 2: B was loaded whole (lbfgs_gram_load_k)
     __syncthreads();
-    if (wave == 0) lbfgs_gram_recursion(g, a.n, lane);
+    if (wave == 0) lbfgs_gram_recursion(g, a.n_global ? a.n_global : a.n, lane);
     __syncthreads();
     for (int i = tid; i < kLbNB * kLbNB; i += 256) gm->B[i / kLbNB][i % kLbNB] = g.B[i / kLbNB][i % kLbNB];
     if (tid < kLbNB) gm->delta[tid] = g.delta[tid];
@@ -571,6 +583,21 @@ hipError_t launch_lbfgs_gram_pass(const LbfgsArgs& a, const float* g_new, int mo
     lbfgs_gram_commit_k<<<1, 256, 0, s>>>(a, mode);
     return hipGetLastError();
 }
+
+hipError_t launch_lbfgs_gram_pass_local(const LbfgsArgs& a, const float* g_new, int mode, hipStream_t s)
+{
+    lbfgs_gram_pass_k<<<kLbGrid, 256, 0, s>>>(a, g_new, mode);
+    lbfgs_gram_commit_k<<<1, 256, 0, s>>>(a, 3);
+    return hipGetLastError();
+}
+
+hipError_t launch_lbfgs_gram_commit_global(const LbfgsArgs& a, int mode, hipStream_t s)
+{
+    lbfgs_gram_commit_k<<<1, 256, 0, s>>>(a, 4 + mode);
+    return hipGetLastError();
+}
+
+int lbfgs_gram_rows() { return kLbGramRows; }
 
 hipError_t launch_lbfgs_gram_apply(const LbfgsArgs& a, hipStream_t s)
 {

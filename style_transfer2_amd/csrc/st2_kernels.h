@@ -315,6 +315,9 @@ struct LbfgsArgs {
     size_t n;
     float step;
     int apply;              // 1: the last link forms s = -step p and x += s; 0 (test hook): p = H g is left in `p`
+    // tile-sharded mode (Gram form only): the vectors are this rank's TILE of the image, the inner products are summed over the ranks
+    float* gsums;           // [kLbGramRows] this rank's sums of the pass (launch_lbfgs_gram_pass_local), all-reduced by the caller
+    size_t n_global;        // elements of the WHOLE image (the unit-RMS first direction divides by it); 0: n
 };
 // p = inv_hv(g) by the two-loop recursion, every link one launch (axpy_i fused with dot_{i+1}); 24 launches, those
 // beyond the current pair count return at once
@@ -328,6 +331,12 @@ hipError_t launch_lbfgs_pair(const LbfgsArgs& a, const float* g_new, int mode, h
 // launch_lbfgs_gram_apply: p = sum delta b, then s = -step p into the free slot and x += s (a.apply) or p left in a.p.
 hipError_t launch_lbfgs_gram_pass(const LbfgsArgs& a, const float* g_new, int mode, hipStream_t s);
 hipError_t launch_lbfgs_gram_apply(const LbfgsArgs& a, hipStream_t s);
+// The same pass in two halves for a vector that is sharded over ranks: _local leaves this rank's kLbGramRows sums in a.gsums
+// (fp32, as sdot returns them) instead of doing the bookkeeping; the caller all-reduces them; _global then runs the bookkeeping and
+// the coefficient recursion on the summed values -- identically on every rank, so every rank derives the same direction.
+hipError_t launch_lbfgs_gram_pass_local(const LbfgsArgs& a, const float* g_new, int mode, hipStream_t s);
+hipError_t launch_lbfgs_gram_commit_global(const LbfgsArgs& a, int mode, hipStream_t s);
+int lbfgs_gram_rows();      // kLbGramRows
 // test hook support: B from a table of all pairwise inner products (float [kLbNB][kLbNB], row-major), then the recursion
 hipError_t launch_lbfgs_gram_load(const LbfgsArgs& a, const float* dots, hipStream_t s);
 // z = a*x + b*y  (host scalars; y may be nullptr)

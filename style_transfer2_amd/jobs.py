@@ -74,8 +74,8 @@ def run_tiled_job(net_params, content, style, iterations, grid, size=None, style
                   seed=0, device=0, precision='fp32', topology=None, callback=None, optimizer='adam', step_size=None):
     """The same job for an image no single engine holds (an 8192 x 8192 image has conv1 blobs of 17 GB each): the image is cut into
     grid = (rows, cols) tiles, every tile + apron is an engine context of THIS process on the one GPU (tiled.InProcessFabric: one
-    thread per rank, the all-reduces and strip exchanges are device-to-device copies); Adam: st_tile_step per rank and iteration;
-    L-BFGS: the phase-by-phase driver with all-reduced dot products (tiled.TiledTransfer over tiled.LocalComm).
+    thread per rank, the all-reduces and strip exchanges are device-to-device copies); one st_tile_step per rank and iteration, Adam or
+    L-BFGS (the Gram form: one all-reduce of the new inner products per step).
     Same result as run_job where both can run (tests/test_gpu_jobs.py).  Image edges must be multiples of 16 * rows / cols
     (tiling.TileGrid).  Returns the stitched HxWx3 float32 image; callback(i, trace values) after every iteration."""
     from . import tiled, tiling
@@ -97,14 +97,11 @@ def run_tiled_job(net_params, content, style, iterations, grid, size=None, style
     fabric = tiled.InProcessFabric(world, timeout=600.0)
     ranks, backends = [], []
     for r in range(world):
-        b = HipTileBackend(net_params, tg, r, content, style, init, weights, params, step_size=step_size or 10, topology=topology,
-                           device=device, precision=precision)
+        b = HipTileBackend(net_params, tg, r, content, style, init, weights, params, step_size=step_size or {'adam': 10, 'lbfgs': 1}[optimizer],
+                           topology=topology, device=device, precision=precision, optimizer=optimizer)
         backends.append(b)
-        if optimizer == 'adam':
-            b.comm_init_local(r, world, fabric)
-            ranks.append(tiled.FusedTiledTransfer(tg, r, b))
-        else:
-            ranks.append(tiled.TiledTransfer(tg, r, b, tiled.LocalComm(fabric, r), optimizer=optimizer, step_size=step_size or 1))
+        b.comm_init_local(r, world, fabric)
+        ranks.append(tiled.FusedTiledTransfer(tg, r, b))
     try:
         for i in range(iterations):
             vals = tiled.run_in_process(ranks, 1, fabric)[0][0]

@@ -9,7 +9,7 @@ import numpy as np
 
 from . import capi
 from .capi import check
-from .engine import Engine, OPT_ADAM
+from .engine import Engine, OPT_ADAM, OPT_LBFGS
 from .tiling import blob_geometry
 from .transfer import weight_table, LOSS_NAMES, SCALAR_LOSS_NAMES, EPS
 
@@ -40,7 +40,7 @@ torch = _LazyTorch()
 
 class HipTileBackend:
     def __init__(self, net_params, grid, rank, content, style, init, weights, params, step_size=10,
-                 topology=None, device=0, precision='fp32', use_torch=True):
+                 topology=None, device=0, precision='fp32', use_torch=True, optimizer='adam'):
         # torch bundles its own copy of the HIP runtime; when both live in one process torch's must come up FIRST.
         # The phase-by-phase driver and the host-staged test transport need torch; the in-engine iteration over RCCL
         # (comm_init_rccl + tiled.FusedTiledTransfer) does not: pass use_torch=False and the process never loads it.
@@ -64,7 +64,11 @@ class HipTileBackend:
         rows, cells = weight_table(weights)
         cols = [[cells[k][r] for r in rows] for k in LOSS_NAMES]
         self.engine.set_weights(rows, cols[0], cols[1], cols[2], [params[k] for k in SCALAR_LOSS_NAMES])
-        self.engine.optimizer_reset(OPT_ADAM, step_size)
+        # optimizer: what the fused iteration (st_tile_step) runs -- Adam, or L-BFGS in its Gram form with one all-reduce of the new inner
+        # products per step; the phase-by-phase driver (tiled.TiledTransfer) brings its own L-BFGS and only uses Adam's fused update
+        if optimizer not in ('adam', 'lbfgs'):
+            raise ValueError('optimizer must be adam or lbfgs')
+        self.engine.optimizer_reset(OPT_LBFGS if optimizer == 'lbfgs' else OPT_ADAM, step_size)
         self.engine.clear_norms()
         check(self.lib.st_tile_configure(self.ctx, grid.gH, grid.gW, w.y0, w.x0, t.y0, t.x0, t.y1, t.x1))
         self.params = params
@@ -192,10 +196,17 @@ class HipTileBackend:
         check(self.lib.st_tile_plan(self.ctx, int(phase), len(peers), arr))
 
     def step_fused(self):
-        """One Adam iteration, every phase and collective enqueued by the engine; returns the trace values."""
+        """One iteration (Adam or L-BFGS, as the backend was built), every phase and collective enqueued by the engine; returns the
+        trace values."""
         trace = np.zeros(self.engine.trace_len(), np.float64)
         check(self.lib.st_tile_step(self.ctx, trace.ctypes.data_as(c_void_p)))
         return trace
+
+    def step_fused_async(self):
+        """The same iteration without its trace: nothing is read back, so the call returns as soon as the launches and collectives
+        are enqueued (over RCCL the host then runs ahead of the GPU, as Engine.step(want_trace=False) does on one GPU); the
+        reduced sums stay on the device."""
+        check(self.lib.st_tile_step(self.ctx, None))
 
     def barrier(self):
         check(self.lib.st_comm_barrier(self.ctx))

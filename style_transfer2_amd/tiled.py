@@ -301,9 +301,11 @@ def fused_plans(grid, rank):
 
 
 class FusedTiledTransfer:
-    """The tile-sharded Adam iteration with the communication INSIDE the engine (st_tile_step): the backend owns an RCCL communicator
-    (or, in tests, a host-staged transport), the exchange plans are handed over once, and a step is one call -- every compute phase,
-    all-reduce and strip exchange is enqueued on the engine's stream, the host synchronises once per iteration for the trace."""
+    """The tile-sharded iteration -- Adam, or L-BFGS (HipTileBackend(optimizer='lbfgs'): the Gram form, ONE all-reduce of the new inner
+    products per step) -- with the communication INSIDE the engine (st_tile_step): the backend owns an RCCL communicator (or, in tests,
+    a host-staged transport), the exchange plans are handed over once, and a step is one call -- every compute phase, all-reduce and
+    strip exchange is enqueued on the engine's stream, the host synchronises once per iteration for the trace.
+    TiledTransfer (above) remains as the backend-agnostic statement of the plan: the CPU / gloo tests run it over the oracle."""
 
     def __init__(self, grid, rank, backend):
         self.grid, self.rank, self.backend = grid, rank, backend
@@ -315,6 +317,11 @@ class FusedTiledTransfer:
     def step(self):
         self.t += 1
         return self.backend.step_fused()
+
+    def step_async(self):
+        """One iteration with nothing read back (no trace, no host synchronisation): the device loop of a headless job."""
+        self.t += 1
+        self.backend.step_fused_async()
 
     def tile_image(self):
         return self.backend.tile_image()
@@ -459,45 +466,64 @@ def run_in_process(ranks, steps, fabric, on_step=None):
     return out
 
 
-def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=120.0):
+def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=None):
     """Hands rank 0's 128-byte communicator id to every rank over a plain TCP socket (MASTER_ADDR : MASTER_PORT + 17 of the launcher's
-    environment): the control plane of st_comm_init, so that the RCCL path needs neither torch.distributed nor a second HIP runtime."""
+    environment): the control plane of st_comm_init, so that the RCCL path needs neither torch.distributed nor a second HIP runtime.
+    Every wait is bounded by `timeout` seconds (default: ST2_RENDEZVOUS_TIMEOUT_S, else 120) and ends in a TimeoutError that names the
+    rank and what it was waiting for -- a rank that never arrives must not leave the others hanging in ncclCommInitRank."""
     import os
     import socket
     import time
     if world == 1:
         return make_id()
+    if timeout is None:
+        timeout = float(os.environ.get('ST2_RENDEZVOUS_TIMEOUT_S', '120'))
     addr = addr or os.environ.get('MASTER_ADDR', '127.0.0.1')
     port = int(port if port is not None else int(os.environ.get('MASTER_PORT', '29500')) + 17)
+    deadline = time.time() + timeout
     if rank == 0:
         uid = make_id()
         srv = socket.socket()
         srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
         srv.bind((addr, port))
         srv.listen(world)
-        srv.settimeout(timeout)
-        for _ in range(world - 1):
-            conn, _ = srv.accept()
-            conn.sendall(uid)
-            conn.close()
-        srv.close()
+        served = 0
+        try:
+            while served < world - 1:
+                srv.settimeout(max(0.05, deadline - time.time()))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise TimeoutError('rank 0: only %d of %d ranks fetched the communicator id from %s:%d within %g s'
+                                       % (served, world - 1, addr, port, timeout)) from None
+                conn.settimeout(10.0)
+                conn.sendall(uid)
+                conn.close()
+                served += 1
+        finally:
+            srv.close()
         return uid
-    deadline = time.time() + timeout
     while True:
         try:
             conn = socket.create_connection((addr, port), timeout=5.0)
             break
         except OSError:
             if time.time() > deadline:
-                raise
+                raise TimeoutError('rank %d: rank 0 never opened the communicator-id rendezvous at %s:%d within %g s' % (rank, addr, port, timeout)) from None
             time.sleep(0.2)
     uid = b''
-    while len(uid) < 128:
-        chunk = conn.recv(128 - len(uid))
-        if not chunk:
-            raise ConnectionError('rank 0 closed the rendezvous early')
-        uid += chunk
-    conn.close()
+    try:
+        while len(uid) < 128:
+            conn.settimeout(max(0.05, deadline - time.time()))
+            try:
+                chunk = conn.recv(128 - len(uid))
+            except socket.timeout:
+                raise TimeoutError('rank %d: the communicator id did not arrive from %s:%d within %g s' % (rank, addr, port, timeout)) from None
+            if not chunk:
+                raise ConnectionError('rank 0 closed the rendezvous early')
+            uid += chunk
+    finally:
+        conn.close()
     return uid
 
 

@@ -783,6 +783,76 @@ def test_fused_tile_step_on_the_eight_rank_2x4_grid_matches_oracle(precision, lo
         assert np.mean((full - ref[step][0]) ** 2) <= 1.0, step
 
 
+@pytest.mark.parametrize('h,w', [(32, 48), (75, 100)])
+def test_fused_tile_lbfgs_on_a_1x1_grid_follows_the_engine_lbfgs(h, w, monkeypatch):
+    """st_tile_step with an L-BFGS backend on a 1 x 1 grid (every all-reduce sees one rank, the ring is the image's own periodic wrap)
+    against the plain engine's device-resident L-BFGS in the SAME (Gram) form: the same lbfgs.hip recursion, once on the window's
+    vectors with the bookkeeping in one kernel, once on the compact tile vector with the sums handed through the all-reduce buffer
+    (rounded to fp32 there, as sdot returns them).  12 steps: the pair memory (10) rolls over (optimizers.py:62-108)."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    monkeypatch.setenv('ST2_LBFGS_FORM', 'gram')
+    content, style, init = _tiled_images(h, w)
+    params = oracle.he_init_weights(TILED_TOPO, 0, 0.1)
+    grid = tiling.TileGrid(h, w, 1, 1, TILED_TOPO, 5)
+    backend = HipTileBackend(params, grid, 0, content, style, init, TILED_WEIGHTS, TILED_PARAMS, step_size=1, topology=TILED_TOPO,
+                             optimizer='lbfgs')
+    backend.comm_init_solo(0, 1)
+    ft = tiled.FusedTiledTransfer(grid, 0, backend)
+    ref = st2.StyleTransfer(st2.HipModel(params, topology=TILED_TOPO))
+    ref.set_input(init); ref.set_content(content); ref.set_style(style); ref.reset()
+    ref.set_weights(TILED_WEIGHTS, TILED_PARAMS)
+    ref.optimizer_cls = st2.LBFGSOptimizer; ref.set_step_size(1); ref.reset()
+    assert ref.start()
+    for i in range(12):
+        vals = ft.step()
+        img, tr = ref.step()
+        assert np.isclose(vals[-2], tr['loss'], rtol=1e-5 if i < 3 else 5e-3), (i, vals[-2], tr['loss'])
+        assert np.mean((ft.tile_image() - img) ** 2) <= (1e-4 if i < 3 else 0.1), i
+
+
+@pytest.mark.parametrize('rows,cols', [(1, 2), (2, 4)])
+def test_fused_tile_lbfgs_on_in_process_grids_follows_the_oracle(rows, cols):
+    """The reference's default optimizer (worker.py:135-136) over the sharded image, fused: every rank one st_tile_step per iteration,
+    the Gram-form recursion on its tile's vectors, ONE all-reduce of the new inner products per step (two on the first), every
+    rank deriving the same coefficients.  Against the single-process CPU oracle (chain form, optimizers.py:62-108), 12 steps."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    h, w, steps = 64, 128, 12
+    world = rows * cols
+    content, style, init = _tiled_images(h, w)
+    net_params = oracle.he_init_weights(TILED_TOPO, 0, 0.1)
+    cpu = oracle.TransferOracle(oracle.NetOracle(TILED_TOPO, net_params))
+    cpu.set_input(init); cpu.set_content(content); cpu.set_style(style); cpu.reset()
+    cpu.set_weights(TILED_WEIGHTS, TILED_PARAMS); cpu.set_optimizer('lbfgs', 1)
+    assert cpu.start()
+    ref = []
+    for _ in range(steps):
+        img, tr = cpu.step()
+        ref.append((np.asarray(img, F32).copy(), dict(tr)))
+    grid = tiling.TileGrid(h, w, rows, cols, TILED_TOPO, 5)
+    fabric = ThreadFabric(world)
+    ranks = []
+    for r in range(world):
+        backend = HipTileBackend(net_params, grid, r, content, style, init, TILED_WEIGHTS, TILED_PARAMS, step_size=1, topology=TILED_TOPO,
+                                 optimizer='lbfgs')
+        backend.comm_init_local(r, world, fabric)
+        ranks.append(tiled.FusedTiledTransfer(grid, r, backend))
+    out = _run_ranks_as_threads(ranks, steps, fabric)
+    # per step: 2 (first evaluation: 3) all-reduces of the objective's sums + 1 of the inner products; the first step evaluates twice
+    assert fabric.reduces <= 4 * steps + 4, fabric.reduces
+    for step in range(steps):
+        full = np.zeros_like(ref[step][0])
+        for r in range(world):
+            t = grid.tiles[r]
+            full[t.y0:t.y1, t.x0:t.x1] = out[r][step][0]
+            assert np.array_equal(np.asarray(out[r][step][1]), np.asarray(out[0][step][1]))    # every rank derives the same trace
+        loss = out[0][step][1][-2]
+        # two fp32 implementations of a quasi-Newton path (chain form on the CPU, Gram form here): tight while the history is short
+        assert np.isclose(loss, ref[step][1]['loss'], rtol=1e-4 if step < 3 else 2e-2), (step, loss, ref[step][1]['loss'])
+        assert np.mean((full - ref[step][0]) ** 2) <= (1e-3 if step < 3 else 1.0), step
+
+
 @pytest.mark.parametrize('precision,loss_rtol,transport', [('fp32', 2e-5, 'host'), ('fp32', 2e-5, 'device'), ('bf16', 5e-3, 'device')])
 def test_fused_tile_step_vgg19_on_the_2x4_grid_matches_the_single_gpu_engine(precision, loss_rtol, transport):
     """The eight ranks of BASELINE configs[4] with the real network: VGG19 to conv5_1 (80-px aprons), a 2048 x 4096 image cut 2 x 4 --

@@ -270,3 +270,28 @@ def test_in_process_fabric_abort_releases_waiting_ranks():
         tiled.run_in_process([Rank(r) for r in range(3)], 1, fabric)
     assert time.time() - t0 < 10.0, 'the other ranks sat out the timeout'
     assert 'rank 0 broke' in str(info.value) and info.value.still_running is False
+
+
+def test_communicator_id_rendezvous_times_out_with_a_clear_error():
+    """VERDICT r3 (tile mode, engineering): the raw-socket rendezvous of the RCCL communicator id needs its own bounded wait -- a rank
+    that never arrives must fail the others with a message, not leave them in accept() / ncclCommInitRank."""
+    import socket
+    import time
+    from style_transfer2_amd import tiled
+    with socket.socket() as sck:
+        sck.bind(('127.0.0.1', 0))
+        port = sck.getsockname()[1]
+    t0 = time.time()
+    with pytest.raises(TimeoutError, match='only 0 of 1 ranks'):
+        tiled.rendezvous_unique_id(0, 2, lambda: b'x' * 128, addr='127.0.0.1', port=port, timeout=0.5)
+    with pytest.raises(TimeoutError, match='rank 1: rank 0 never opened'):
+        tiled.rendezvous_unique_id(1, 2, None, addr='127.0.0.1', port=port, timeout=0.5)
+    assert time.time() - t0 < 10
+    # and the working case: both ranks, one thread each
+    import threading
+    got = {}
+    th = threading.Thread(target=lambda: got.setdefault(1, tiled.rendezvous_unique_id(1, 2, None, addr='127.0.0.1', port=port, timeout=10)))
+    th.start()
+    got[0] = tiled.rendezvous_unique_id(0, 2, lambda: bytes(range(128)), addr='127.0.0.1', port=port, timeout=10)
+    th.join(10)
+    assert got[0] == got[1] == bytes(range(128))

@@ -39,12 +39,13 @@ rows, cols = (int(v) for v in args.grid.split('x'))
 gH, gW = (int(v) for v in args.size.split('x')) if 'x' in args.size else (int(args.size), int(args.size))
 rank, local, world = int(os.environ.get('RANK', 0)), int(os.environ.get('LOCAL_RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
 solo = args.solo_rank >= 0
-assert solo or world == rows * cols, 'world size %d != grid %s' % (world, args.grid)
+if not solo and world != rows * cols:       # preflight: a clear error instead of ranks waiting for peers that do not exist
+    sys.exit('bench_tiled.py: the launcher started %d rank(s) but the %s grid needs %d (one rank per tile)' % (world, args.grid, rows * cols))
 if solo:
     assert world == 1 and args.solo_rank < rows * cols
     rank = args.solo_rank
 dist = None
-use_engine = args.driver == 'engine' and args.optimizer == 'adam'
+use_engine = args.driver == 'engine'
 if world > 1 and not use_engine:
     import torch
     import torch.distributed as dist
@@ -87,8 +88,8 @@ class WindowView:
 
 style = np.random.RandomState(2).randint(0, 256, (args.style_size, args.style_size, 3)).astype(np.uint8)
 backend = HipTileBackend(st2_weights.he_normal(topo, seed=0), grid, rank, WindowView(window_image(1)), style,
-                         WindowView(window_image(3)), WEIGHTS, PARAMS, step_size=10, device=local, precision=args.precision,
-                         use_torch=not use_engine)
+                         WindowView(window_image(3)), WEIGHTS, PARAMS, step_size={'adam': 10, 'lbfgs': 1}[args.optimizer], device=local,
+                         precision=args.precision, use_torch=not use_engine, optimizer=args.optimizer)
 
 
 class SoloComm(tiled.Comm):
@@ -121,8 +122,11 @@ for _ in range(args.warmup):
 backend.engine.sync()
 barrier()
 t0 = time.perf_counter()
-for _ in range(args.steps):
-    vals = tt.step()
+for k in range(args.steps):
+    if use_engine and k + 1 < args.steps:
+        tt.step_async()                     # nothing read back: the host enqueues ahead of the GPU; the last step brings the trace
+    else:
+        vals = tt.step()
 backend.engine.sync()
 barrier()
 dt = time.perf_counter() - t0

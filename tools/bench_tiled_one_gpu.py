@@ -23,7 +23,8 @@ ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--warmup', type=int, default=2)
 ap.add_argument('--precision', default='fp32', choices=('fp32', 'bf16'))
 ap.add_argument('--transport', default='device', choices=('device', 'host'))
-ap.add_argument('--optimizer', default='adam', choices=('adam', 'lbfgs'), help='lbfgs: the phase-by-phase driver with all-reduced dot products')
+ap.add_argument('--optimizer', default='adam', choices=('adam', 'lbfgs'), help='lbfgs: the fused Gram-form step (one all-reduce of the new inner products per step)')
+ap.add_argument('--driver', default='engine', choices=('engine', 'phases'), help='phases: tiled.TiledTransfer between the st_tile_* phases (chain-form L-BFGS with scalar all-reduces)')
 ap.add_argument('--need-free-gib', type=float, default=0.0, help='print {"skipped": ...} and exit 0 unless this much HBM is free')
 args = ap.parse_args()
 sys.stdout.flush()
@@ -56,10 +57,11 @@ free0, total = torch.cuda.mem_get_info()
 fabric = tiled.InProcessFabric(world, timeout=600.0)
 ranks, backends = [], []
 for r in range(world):
-    b = HipTileBackend(net, grid, r, content, style, init, WEIGHTS, PARAMS, step_size=10, precision=args.precision)
+    b = HipTileBackend(net, grid, r, content, style, init, WEIGHTS, PARAMS, step_size={'adam': 10, 'lbfgs': 1}[args.optimizer],
+                       precision=args.precision, optimizer=args.optimizer)
     backends.append(b)
-    if args.optimizer == 'lbfgs':
-        ranks.append(tiled.TiledTransfer(grid, r, b, tiled.LocalComm(fabric, r), optimizer='lbfgs', step_size=1))
+    if args.driver == 'phases':                  # the phase-by-phase driver (torch tensors between the st_tile_* phases): the A/B reference
+        ranks.append(tiled.TiledTransfer(grid, r, b, tiled.LocalComm(fabric, r), optimizer=args.optimizer, step_size={'adam': 10, 'lbfgs': 1}[args.optimizer]))
         continue
     if args.transport == 'device':
         b.comm_init_local(r, world, fabric)
@@ -81,7 +83,8 @@ json_out.write(json.dumps({
     'higher_is_better': True, 'vs_baseline': None,
     'config': {'workload': 'configs[4] job on one GPU: ONE %dx%d image, %s windows %s resident together, %s %s' % (
         gH, gW, args.grid, sorted({(w.y1 - w.y0, w.x1 - w.x0) for w in grid.windows}), args.optimizer, args.precision),
-               'transport': 'in-process, %s' % ('device-to-device copies' if args.transport == 'device' else 'staged through host arrays')},
+               'transport': 'in-process, %s' % ('device-to-device copies' if args.transport == 'device' else 'staged through host arrays'),
+               'driver': 'st_tile_step (fused)' if args.driver == 'engine' else 'phase by phase (tiled.TiledTransfer)'},
     'hbm_in_use_GiB': used, 'loss': float(out[0][-1][-2]), 'all_reduces_per_step': fabric.reduces / max(1, args.steps + args.warmup),
     'messages_per_step': fabric.messages / max(1, args.steps + args.warmup),
     'dtype': 'f32' if args.precision == 'fp32' else 'bf16 conv operands, f32 accumulate/Gram/optimizer', 'data': 'synthetic'}) + '\n')
