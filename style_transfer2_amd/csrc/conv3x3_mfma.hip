@@ -403,6 +403,7 @@ ST2_CONV_KERNEL(conv3x3_mfma_f32_64x64_cc4, 64, 2, 2, 2, 4, 0, 4)
     __global__ __launch_bounds__(NTHREADS, WPE) void NAME##_w(const ConvKArgs a) { conv3x3_body<BM, ROWS, WM, WN, CCK, false, 0, 1, EPI_STYLE>(a); }
 ST2_STYLE_KERNEL(style_grad_mfma_f32_128x128_cc32, 128, 4, 2, 2, 32, 2)
 ST2_STYLE_KERNEL(style_grad_mfma_f32_64x256_cc16, 64, 8, 1, 4, 16, 3)
+ST2_STYLE_KERNEL(style_grad_mfma_f32_64x128_cc32, 64, 4, 1, 4, 32, 3)
 
 typedef void (*conv_kernel_t)(const ConvKArgs);
 
@@ -504,12 +505,22 @@ hipError_t launch_conv3x3(const ConvProblem& p, hipStream_t s)
 }
 
 // Style gradient S = c2 * (D @ F) on the conv pipeline (TAPS = 1).  Dp is D laid out [C][MPad].
-static void style_tile(int C, int* bm, int* rows) { if (C > 64) { *bm = 128; *rows = 4; } else { *bm = 64; *rows = 8; } }
+// Tile of the style-gradient launch: 128 channels x 128 pixels for C > 64 -- unless that leaves fewer than one workgroup per CU
+// (conv5_1 at 1024^2: 64 x 64 pixels, 4 channel tiles x 32 pixel tiles = 128 workgroups on 256 CUs), then 64 channels x 128 pixels;
+// 64 x 256 pixels for C <= 64 (one channel tile).  ST2_STYLE_SMALL=0 keeps the large tile everywhere (read per launch: A/B runs).
+static void style_tile(int C, int H, int W, int* bm, int* rows)
+{
+    if (C <= 64) { *bm = 64; *rows = 8; return; }
+    *bm = 128; *rows = 4;
+    const long long blocks = (long long)((W + 31) / 32) * ((H + 3) / 4) * (conv_mpad(C) / 128);
+    const char* e = getenv("ST2_STYLE_SMALL");
+    if (blocks < 256 && conv_mpad(C) % 64 == 0 && !(e && *e == '0')) *bm = 64;
+}
 
 int style_grad_blocks(int C, int H, int W)
 {
     int bm, rows;
-    style_tile(C, &bm, &rows);
+    style_tile(C, H, W, &bm, &rows);
     return ((W + 31) / 32) * ((H + rows - 1) / rows) * (conv_mpad(C) / bm);
 }
 
@@ -522,7 +533,10 @@ hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float 
     ConvKArgs st{};
     st.c2 = c2; st.sw = sw; st.norm = norm; st.fused = fused; st.accumulate = accumulate; st.partial = partial;
     st.ry0 = roi ? roi->y0 : 0; st.rx0 = roi ? roi->x0 : 0; st.ry1 = roi ? roi->y1 : H; st.rx1 = roi ? roi->x1 : W;
-    if (C > 64) return run(p, 128, 4, 32, style_grad_mfma_f32_128x128_cc32_q, style_grad_mfma_f32_128x128_cc32_w, s, &st, n_partial);
+    int bm, rows;
+    style_tile(C, H, W, &bm, &rows);
+    if (bm == 128) return run(p, 128, 4, 32, style_grad_mfma_f32_128x128_cc32_q, style_grad_mfma_f32_128x128_cc32_w, s, &st, n_partial);
+    if (rows == 4) return run(p, 64, 4, 32, style_grad_mfma_f32_64x128_cc32_q, style_grad_mfma_f32_64x128_cc32_w, s, &st, n_partial);
     return run(p, 64, 8, 16, style_grad_mfma_f32_64x256_cc16_q, style_grad_mfma_f32_64x256_cc16_w, s, &st, n_partial);
 }
 
@@ -730,6 +744,109 @@ hipError_t launch_conv3x3_dgrad_smallM16(const unsigned short* dy16, const float
     return hipGetLastError();
 }
 
+// The same sum with the activation tile staged by LDS-DMA (round 4).  The kernel above fetches its 4-channel tile element by element
+// (21 four-byte global loads per thread and chunk, an index division each) into registers, then stores them to LDS between two
+// barriers: at 1024^2 it read the 268 MB diff at 2.2 TB/s (124 us), bound by those loads, not by its 3.6 GFLOP.  Here a chunk's tile is
+// 4 channels x 10 rows x 34 ALIGNED quads (columns x0 - 4 .. x0 + 131), copied global -> LDS as 16-byte pieces of 64 lanes
+// (buffer_load ... lds; quads outside the image get an out-of-range offset = hardware zero fill = the padding) through a ring of three
+// buffers -- two chunks in flight while one is consumed, a counted vmcnt and one barrier per chunk; a thread reads its 6 columns of a
+// row as b32 + b128 + b32.  Same sum in the same order as the kernel above (the compiler contracts the two differently: equal to
+// an ulp, tests/test_gpu_parity.py).  Measured at 1024^2: 124 -> 100 us (double-buffered: 105); a v_pk_fma_f32 form of the inner
+// product (two pixels per instruction) was slower (112 us) and is not kept: the bound is neither the loads nor the multiply-adds.  Needs W % 4 == 0, a 16-byte aligned diff < 4 GiB.
+constexpr int SD_QROW = SM_TX / 4 + 2;                  // 34 quads per staged row
+constexpr int SD_ROW = 4 * SD_QROW;                     // 136 floats
+constexpr int SD_TH = SM_TY + 2;                        // 10 rows
+constexpr int SD_NQ = SM_CH * SD_TH * SD_QROW;          // 1360 quads per chunk
+constexpr int SD_PIECES = (SD_NQ + 63) / 64;            // 22 wave-DMAs
+constexpr int SD_PPW = (SD_PIECES + 3) / 4;             // per wave
+constexpr int SD_BUF = SD_PIECES * 256;                 // floats per buffer
+constexpr int SD_NBUF = 3;                              // ring: two chunks in flight while one is consumed (67.5 KiB: two workgroups per CU)
+
+template <int M>
+__global__ __launch_bounds__(256) void conv3x3_dgrad_smallM_dma(const float* __restrict__ dy, unsigned dy_bytes, const float* __restrict__ w,
+                                                                float* __restrict__ dx, const float* __restrict__ inject,
+                                                                int Cout, int H, int W)
+{
+    typedef __attribute__((address_space(3))) void* sd_lptr_t;
+    __shared__ __attribute__((aligned(16))) float t_s[SD_NBUF][SD_BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * SM_TX, y0 = blockIdx.y * SM_TY;
+    const int lx = (tid & 31) * SM_PX, ly = tid >> 5;
+    const unsigned plane = (unsigned)H * (unsigned)W;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+    unsigned qoff[SD_PPW];                   // byte offset of this lane's quad inside chunk 0 (channel c of the chunk included), or out of range
+    int qch[SD_PPW];
+#pragma unroll
+    for (int t = 0; t < SD_PPW; ++t) {
+        const int qi = (wave + 4 * t) * 64 + lane;
+        const int c = qi / (SD_TH * SD_QROW), rem = qi - c * (SD_TH * SD_QROW), rr = rem / SD_QROW, qc = rem - rr * SD_QROW;
+        const int gy = y0 - 1 + rr, gx = x0 - 4 + 4 * qc;
+        const bool ok = wave + 4 * t < SD_PIECES && qi < SD_NQ && gy >= 0 && gy < H && gx >= 0 && gx + 3 < W;
+        qoff[t] = ok ? ((unsigned)c * plane + (unsigned)gy * W + gx) * 4u : 0xffffffffu;
+        qch[t] = c;
+    }
+    auto dma = [&](int c0, int buf) {
+        const unsigned coff = (unsigned)c0 * plane * 4u;
+#pragma unroll
+        for (int t = 0; t < SD_PPW; ++t) {
+            if (wave + 4 * t >= SD_PIECES) continue;                   // wave-uniform
+            const unsigned vo = (qoff[t] == 0xffffffffu || c0 + qch[t] >= Cout) ? 0xffffffffu : qoff[t] + coff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (sd_lptr_t)(t_s[buf] + (wave + 4 * t) * 256), 16, vo, 0, 0, 0);
+        }
+    };
+    float acc[SM_PX][M];
+#pragma unroll
+    for (int q = 0; q < SM_PX; ++q)
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[q][m] = 0.f;
+
+    dma(0, 0);
+    if (SM_CH < Cout) dma(SM_CH, 1);
+    int buf = 0;
+    for (int c0 = 0; c0 < Cout; c0 += SM_CH) {
+        // this chunk has landed (the NEXT chunk's pieces of this wave -- 6 for waves 0 and 1, 5 for waves 2 and 3 -- may still be in flight)
+        if (c0 + SM_CH < Cout) {
+            if (wave < (SD_PIECES & 3)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SD_PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SD_PPW - 1) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // ... for every wave; the buffer consumed in the previous iteration is free again
+        if (c0 + 2 * SM_CH < Cout) dma(c0 + 2 * SM_CH, buf >= 1 ? buf - 1 : SD_NBUF - 1);
+        const float* tile = t_s[buf];
+#pragma unroll
+        for (int c = 0; c < SM_CH; ++c) {
+            if (c0 + c < Cout) {
+                const float* wc = w + (size_t)(c0 + c) * M * 9;      // uniform -> s_load
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    // source pixel (y - ky + 1, x - kx + 1) -> staged row ly + 2 - ky, staged column lx + q + 5 - kx (column 0 = pixel x0 - 4)
+                    const float* row = tile + (c * SD_TH + (ly + 2 - ky)) * SD_ROW + lx;
+                    float g[SM_PX + 2];
+                    const float4 mid = *reinterpret_cast<const float4*>(row + 4);
+                    g[0] = row[3]; g[1] = mid.x; g[2] = mid.y; g[3] = mid.z; g[4] = mid.w; g[5] = row[8];
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int q = 0; q < SM_PX; ++q)
+#pragma unroll
+                            for (int m = 0; m < M; ++m) acc[q][m] += wc[m * 9 + ky * 3 + kx] * g[q + 2 - kx];
+                }
+            }
+        }
+        buf = buf + 1 == SD_NBUF ? 0 : buf + 1;
+    }
+    const int gy = y0 + ly, gx = x0 + lx;
+    if (gy < H && gx < W) {                      // W % 4 == 0: the thread's four pixels are inside together
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const size_t idx = (size_t)m * plane + (size_t)gy * W + gx;
+            float4 o = make_float4(acc[0][m], acc[1][m], acc[2][m], acc[3][m]);
+            if (inject) { const float4 ij = *reinterpret_cast<const float4*>(inject + idx); o.x += ij.x; o.y += ij.y; o.z += ij.z; o.w += ij.w; }
+            *reinterpret_cast<float4*>(dx + idx) = o;
+        }
+    }
+}
+
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
                                        int Cout, int Cin, int H, int W, hipStream_t s)
 {
@@ -737,6 +854,20 @@ hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* d
     if (conv_dgrad_first_quad_ok(Cout, Cin, H, W, dy)) return launch_conv3x3_dgrad_first_quad(dy, w, dx, inject, Cout, Cin, H, W, s);        // matrix cores, quads
     if (conv_dgrad_first_ok(Cout, Cin, H, W, false)) return launch_conv3x3_dgrad_first(dy, w, dx, inject, Cout, Cin, H, W, s);              // matrix cores
     dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);
+    {   // LDS-DMA staging where the layout allows it (ST2_DGRAD_SMALLM_DMA=0: the register-staged kernel; read per launch: A/B runs)
+        const char* e = getenv("ST2_DGRAD_SMALLM_DMA");
+        const unsigned long long bytes = 4ull * Cout * H * W;
+        if (!(e && *e == '0') && W % 4 == 0 && bytes < 0xfffffff0ull && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(dx) & 15) == 0 && (!inject || (reinterpret_cast<uintptr_t>(inject) & 15) == 0)) {
+            switch (Cin) {
+            case 1: conv3x3_dgrad_smallM_dma<1><<<grid, dim3(256), 0, s>>>(dy, (unsigned)bytes, w, dx, inject, Cout, H, W); break;
+            case 2: conv3x3_dgrad_smallM_dma<2><<<grid, dim3(256), 0, s>>>(dy, (unsigned)bytes, w, dx, inject, Cout, H, W); break;
+            case 3: conv3x3_dgrad_smallM_dma<3><<<grid, dim3(256), 0, s>>>(dy, (unsigned)bytes, w, dx, inject, Cout, H, W); break;
+            default: conv3x3_dgrad_smallM_dma<4><<<grid, dim3(256), 0, s>>>(dy, (unsigned)bytes, w, dx, inject, Cout, H, W); break;
+            }
+            return hipGetLastError();
+        }
+    }
     switch (Cin) {
     case 1: conv3x3_dgrad_smallM<1><<<grid, dim3(256), 0, s>>>(dy, w, dx, inject, Cout, H, W); break;
     case 2: conv3x3_dgrad_smallM<2><<<grid, dim3(256), 0, s>>>(dy, w, dx, inject, Cout, H, W); break;

@@ -26,8 +26,15 @@ GramPlan gram_plan(int C, int hw)
     p.bt = C > 64 ? 128 : 64;
     const int t = (C + p.bt - 1) / p.bt;
     p.tiles = t * (t + 1) / 2;                             // G is symmetric: upper-triangular tiles only, mirrored on store
-    static const int target_blocks = [] { const char* e = getenv("ST2_GRAM_BLOCKS"); return e && *e ? atoi(e) : 512; }();
-    int want = (target_blocks + p.tiles - 1) / p.tiles;    // ~2 workgroups per CU (swept: tools/gram_blocks_sweep.sh)
+    // 128-row tiles (C > 64) are matrix-core bound and two workgroups fill a CU (64 KiB of LDS each): the launch must be ONE round of
+    // at most 512 workgroups -- rounding the split count UP put 513 (C = 256) and 520 (C = 512) of them on 512 slots, and the one
+    // left over ran a second round alone on an idle chip (conv3_1: 72 us for 41 us of matrix work).  64-row tiles (C <= 64) are
+    // HBM-bound (conv1_1: 268 MB for 8.6 GFLOP) and small (32 KiB of LDS): more workgroups per CU keep more bytes in flight.
+    // ST2_GRAM_BLOCKS / ST2_GRAM_BLOCKS64 override the two targets (read per call: A/B runs in one process).
+    const char* e128 = getenv("ST2_GRAM_BLOCKS");
+    const char* e64 = getenv("ST2_GRAM_BLOCKS64");
+    const int target128 = e128 && *e128 ? atoi(e128) : 512, target64 = e64 && *e64 ? atoi(e64) : 1024;
+    int want = p.bt == 128 ? target128 / p.tiles : (target64 + p.tiles - 1) / p.tiles;
     const int max_splits = (hw + 4 * GKT - 1) / (4 * GKT); // at least 128 K per slab
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;

@@ -90,6 +90,30 @@ def test_first_conv_data_gradient_on_the_matrix_cores(precision, kernel, cout, h
         assert err <= (5e-5 if precision == 'bf16' else 2e-6), (names, err)
 
 
+@pytest.mark.parametrize('cout,h,w', [(64, 64, 96), (64, 75, 100), (64, 8, 32), (24, 12, 20), (64, 23, 132), (62, 40, 260), (64, 256, 512)])
+def test_first_conv_data_gradient_lds_dma_staging_equals_the_register_staged_kernel(cout, h, w, monkeypatch):
+    """conv3x3_dgrad_smallM_dma (round 4: the 4-channel tile staged as aligned quads by LDS-DMA, one barrier per chunk) against the
+    register-staged kernel it replaces where the width allows: the same sum in the same order (the compiler contracts multiply-adds
+    differently in the two: equal to an ulp, not bit for bit) -- tiles cut by the right / bottom edge, a channel count that is not a
+    multiple of the chunk (62), several tiles in x."""
+    monkeypatch.setenv('ST2_DGRAD_FIRST_Q', '0')
+    monkeypatch.setenv('ST2_DGRAD_FIRST', '0')
+    topo = (('conv', 'conv1_1', 3, cout),)
+    params = oracle.he_init_weights(topo, seed=cout + h, bias_std=0.2)
+    gpu = st2.HipModel(params, topology=topo)
+    rng = np.random.RandomState(h * w + cout)
+    x = (rng.randn(1, 3, h, w) * 40).astype(F32)
+    f = gpu.forward(x, ['conv1_1'])
+    got = {}
+    for names in (['conv1_1'], ['conv1_1', 'data']):
+        diffs = {n: rng.randn(*(f[n].shape if n != 'data' else x.shape)).astype(F32) for n in names}
+        for dma in ('1', '0'):
+            monkeypatch.setenv('ST2_DGRAD_SMALLM_DMA', dma)
+            got[dma] = gpu.backward(diffs)
+        assert rel_l2(got['1'], got['0']) <= 3e-7, (names, rel_l2(got['1'], got['0']))
+        assert np.isfinite(got['1']).all() and np.abs(got['1']).max() > 0
+
+
 def test_ranged_backward_injection_rules():
     """worker.py:88-106: unmasked at the start blob, masked from above, pool and data blobs too."""
     topo = oracle.tiny_topology((8, 16), (2, 2), final_pool=True)
