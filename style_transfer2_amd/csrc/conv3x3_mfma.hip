@@ -428,7 +428,11 @@ static hipError_t run(const ConvProblem& p, int BM, int ROWS, int CCK, conv_kern
     const unsigned long long in_bytes = 4ull * p.K * p.H * p.W;
     const unsigned long long w_bytes = style ? 4ull * p.K * p.MPad : 4ull * conv_pack_floats(p.K, p.M);
     const unsigned long long out_bytes = 4ull * p.M * p.H * p.W;
-    if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull || out_bytes >= 0xfffffff0ull) return hipErrorInvalidValue;
+    // (the input tile is staged through 32-bit BYTE offsets; the output, ReLU mask and injected diff by 32-bit ELEMENT offsets:
+    //  conv1_1's 17 GB blob of an 8192 x 8192 image -- 2^32 elements -- is addressable, a 4 GiB input is not)
+    (void)out_bytes;
+    if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull || (unsigned long long)p.M * p.H * p.W > 0x100000000ull) return hipErrorInvalidValue;
+    if (p.out16 && out_bytes >= 0xfffffff0ull) return hipErrorInvalidValue;
     k.in_bytes = (unsigned)in_bytes; k.w_bytes = (unsigned)w_bytes;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
@@ -508,6 +512,8 @@ hipError_t launch_conv3x3(const ConvProblem& p, hipStream_t s)
 // Tile of the style-gradient launch: 128 channels x 128 pixels for C > 64 -- unless that leaves fewer than one workgroup per CU
 // (conv5_1 at 1024^2: 64 x 64 pixels, 4 channel tiles x 32 pixel tiles = 128 workgroups on 256 CUs), then 64 channels x 128 pixels;
 // 64 x 256 pixels for C <= 64 (one channel tile).  ST2_STYLE_SMALL=0 keeps the large tile everywhere (read per launch: A/B runs).
+constexpr int SB_M = 64, SB_N = 128, SB_K = 32, SB_LDA = SB_K + 1, SB_LDB = SB_N + 4, SB_GRID = 2048;      // style_grad_big_k (below)
+static bool style_big(int C, int H, int W);
 static void style_tile(int C, int H, int W, int* bm, int* rows)
 {
     if (C <= 64) { *bm = 64; *rows = 8; return; }
@@ -519,9 +525,86 @@ static void style_tile(int C, int H, int W, int* bm, int* rows)
 
 int style_grad_blocks(int C, int H, int W)
 {
+    if (style_big(C, H, W)) return SB_GRID;                 // style_grad_big_k: one partial sum per workgroup of its fixed grid
     int bm, rows;
     style_tile(C, H, W, &bm, &rows);
     return ((W + 31) / 32) * ((H + rows - 1) / rows) * (conv_mpad(C) / bm);
+}
+
+// The style gradient for a blob of 4 GiB or more (conv1_1 .. conv3_1 of an 8192 x 8192 image in ONE engine): the kernels above stage F
+// through a buffer resource (32-bit byte offsets).  This one addresses with 64-bit pointers: register-staged tiles of 64 channels x 128
+// pixels, 32 channels of K per step, a grid-stride loop over the tiles (one partial sum per workgroup).  Same contract as
+// launch_style_grad (whole blob, hw % 4 == 0); slower per FLOP than the LDS-DMA kernels -- it exists so that the large image runs at all.
+__global__ __launch_bounds__(256) void style_grad_big_k(const float* __restrict__ Dp, int ld, const float* __restrict__ F, float* __restrict__ dst,
+                                                        float c2, int fused, float sw, const float* __restrict__ norm, int accumulate,
+                                                        float* __restrict__ partial, int C, size_t hw)
+{
+    __shared__ float As[SB_M * SB_LDA];
+    __shared__ float Bs[SB_K * SB_LDB];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, khalf = lane >> 5;
+    const size_t n_ptiles = (hw + SB_N - 1) / SB_N;
+    const size_t n_tiles = n_ptiles * ((C + SB_M - 1) / SB_M);
+    const float coef = fused ? sw / *norm : 0.f;
+    float ss = 0.f;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int m0 = (int)(tile / n_ptiles) * SB_M;
+        const size_t p0 = (tile % n_ptiles) * SB_N;
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int k0 = 0; k0 < C; k0 += SB_K) {
+            __syncthreads();                     // the previous step's operands are consumed
+#pragma unroll
+            for (int i = 0; i < SB_M * SB_K / 256; ++i) {            // D tile: As[m][k]
+                const int e = tid + i * 256, m = e / SB_K, k = e - m * SB_K;
+                As[m * SB_LDA + k] = (m0 + m < C && k0 + k < C) ? Dp[(size_t)(m0 + m) * ld + k0 + k] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < SB_K * SB_N / 4 / 256; ++i) {        // F tile: Bs[k][p], 16 bytes per load (hw % 4 == 0)
+                const int q = tid + i * 256, k = q / (SB_N / 4), pq = q - k * (SB_N / 4);
+                const size_t p = p0 + 4 * (size_t)pq;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k0 + k < C && p < hw) v = *reinterpret_cast<const float4*>(F + (size_t)(k0 + k) * hw + p);
+                *reinterpret_cast<float4*>(Bs + k * SB_LDB + 4 * pq) = v;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < SB_K / 2; ++ks) {
+                const float av = As[(wm * 32 + l31) * SB_LDA + 2 * ks + khalf];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float bv = Bs[(2 * ks + khalf) * SB_LDB + wn * 64 + j * 32 + l31];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const size_t p = p0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (m >= C || p >= hw) continue;
+                const float v = acc[j][e] * c2;
+                ss += v * v;
+                const size_t o = (size_t)m * hw + p;
+                dst[o] = fused ? coef * v + (accumulate ? dst[o] : 0.f) : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    if (tid == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+static bool style_big(int C, int H, int W)
+{
+    const char* fb = getenv("ST2_STYLE_FORCE_BIG");         // test hook: =1 runs the 64-bit-addressed kernel on blobs of any size
+    return 4ull * C * H * W >= 0xfffffff0ull || (fb && *fb == '1' && ((size_t)H * W) % 4 == 0);
 }
 
 hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float c2, int fused, float sw, const float* norm,
@@ -533,6 +616,13 @@ hipError_t launch_style_grad(const float* Dp, const float* F, float* dst, float 
     ConvKArgs st{};
     st.c2 = c2; st.sw = sw; st.norm = norm; st.fused = fused; st.accumulate = accumulate; st.partial = partial;
     st.ry0 = roi ? roi->y0 : 0; st.rx0 = roi ? roi->x0 : 0; st.ry1 = roi ? roi->y1 : H; st.rx1 = roi ? roi->x1 : W;
+    if (style_big(C, H, W)) {
+        const size_t hw = (size_t)H * W;
+        if (roi || hw % 4 != 0 || (reinterpret_cast<uintptr_t>(F) & 15) != 0) return hipErrorInvalidValue;
+        style_grad_big_k<<<SB_GRID, 256, 0, s>>>(Dp, conv_mpad(C), F, dst, c2, fused, sw, norm, accumulate, partial, C, hw);
+        if (n_partial) *n_partial = SB_GRID;
+        return hipGetLastError();
+    }
     int bm, rows;
     style_tile(C, H, W, &bm, &rows);
     if (bm == 128) return run(p, 128, 4, 32, style_grad_mfma_f32_128x128_cc32_q, style_grad_mfma_f32_128x128_cc32_w, s, &st, n_partial);

@@ -47,7 +47,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // one row (DPP) so that every lane loads / stores 16 bytes; bias / ReLU / ReLU-mask / injected diff as in the direct
 // kernel; optionally the 2x2 max-pool of the output (a tile is one pooling window).  Launches with few workgroups
 // split K (wino_combine_k finishes them).
-// Requirements (else the caller uses the direct kernel): K % 8 == 0, >= 48 output channels, tensors < 4 GiB.
+// Requirements (else the caller uses the direct kernel): K % 8 == 0, >= 48 output channels; tensors of 4 GiB and more: the BIG builds.
 // ===========================================================================================================
 
 constexpr int WN_CH = 8;                         // input channels per chunk (4 k-pairs)
@@ -134,9 +134,14 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 //                transform of a 4x4 tile reads its 3x3 pooling windows: d[i][j] = (slot of window == position of (i, j) in it, and the
 //                maximum was positive) ? pooled diff : 0 -- exactly the values maxpool_bwd_amap_k stores, so the result is the same bit
 //                for bit, and that kernel, its 4x larger output and this launch's read of it are gone.
-template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false, bool H4 = false, bool UNPOOL = false>
+// BIG = true (QUAD, one tile group): tensors of 4 GiB and more (one engine on an 8192 x 8192 image: conv1 blobs of 17 GB).  Buffer addressing is
+//                a 32-bit byte offset from the resource's base, so the base moves instead: the activation resource is rebuilt per chunk at
+//                channel (c_first + ch) * 8 (a 64-bit scalar add; a chunk's 8 planes must stay below 4 GiB: H * W < 2^27) and the lane offsets are
+//                relative to the chunk.  The epilogue's 32-bit ELEMENT offsets already reach 2^32 elements (64 x 8192 x 8192 exactly).
+template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false, bool H4 = false, bool UNPOOL = false, bool BIG = false>
 __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
+    static_assert(!BIG || (QUAD && TG == 1 && !PS && !W8 && DIAG == 0), "big tensors: aligned widths, one tile group, four waves");
     static_assert(!UNPOOL || (QUAD && TG == 1 && !PS && !W8), "unpool: aligned widths, one tile group, four waves");
     static_assert(H4 || (WM * TG == 4 && (TG == 1 || TG == 2)), "4 waves");
     static_assert(!PS || (WM == 2 && TG == 2), "position split: 2 channel slices x 2 position halves");
@@ -213,7 +218,8 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
             const int col = rem - rr * UP_COLS;
             const int gy = (y0 >> 1) - 1 + rr, gx = (x0 >> 1) - 4 + col;
             const bool ok = piece < UP_FQ + UP_AQ && gy >= 0 && gy < a.ph && gx >= 0 && gx + 3 < a.pw;
-            ioff[t] = ok ? ((unsigned)(c_first * WN_CH + c) * pplane + (unsigned)gy * a.pw + gx) * (bytes ? 1u : 4u) : kOOB;
+            // (BIG: the floats are addressed from the chunk's own base; the map bytes -- a quarter of the size -- keep the tensor's)
+            ioff[t] = ok ? ((unsigned)((BIG && !bytes ? 0 : c_first * WN_CH) + c) * pplane + (unsigned)gy * a.pw + gx) * (bytes ? 1u : 4u) : kOOB;
         }
     } else if (QUAD) {
 #pragma unroll
@@ -225,31 +231,34 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
             const int col = rem - rr * IW;
             const int gy = y0 - 1 + rr, gx = x0 - 4 + col;
             const bool ok = e < N_RAW && gy >= 0 && gy < a.H && gx >= 0 && gx + 3 < a.W;
-            ioff[t] = ok ? ((unsigned)(c_first * WN_CH + c) * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
+            ioff[t] = ok ? ((unsigned)((BIG ? 0 : c_first * WN_CH) + c) * plane + (unsigned)gy * a.W + gx) * 4u : kOOB;
         }
     } else {
         const int gx = x0 - 1 + lane;                                  // lane = staged column
         ioff[0] = (lane < 34 && gx >= 0 && gx < a.W) ? (unsigned)gx * 4u : kOOB;
     }
     auto dma_raw = [&](int ch, int buf) {
+        // BIG: this chunk's 8 planes behind a resource of their own (a.in_bytes = the bytes of ONE chunk)
+        const __amdgpu_buffer_rsrc_t rs_c = BIG ? __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.in + (size_t)(c_first + ch) * WN_CH * (UNPOOL ? pplane : plane)), 0, a.in_bytes, 0x00020000) : rs_i;
         if (UNPOOL) {
 #pragma unroll
             for (int t = 0; t < I_PER_WAVE; ++t) {
                 const int piece = wave + NW * t;                           // wave-uniform
                 if (piece < UP_FQ) {
-                    const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + (unsigned)ch * WN_CH * pplane * 4u;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s[buf] + piece * 256), 16, vo, 0, 0, 0);
+                    const unsigned vo = (ioff[t] == kOOB || BIG) ? ioff[t] : ioff[t] + (unsigned)ch * WN_CH * pplane * 4u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (lptr_t)(raw_s[buf] + piece * 256), 16, vo, 0, 0, 0);
                 } else if (piece < UP_FQ + UP_AQ) {
                     const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + (unsigned)ch * WN_CH * pplane;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lptr_t)(raw_s[buf] + UP_F + (piece - UP_FQ) * 64), 4, vo, 0, 0, 0);
                 }
             }
         } else if (QUAD) {
-            const unsigned coff = (unsigned)ch * WN_CH * plane * 4u;
+            const unsigned coff = BIG ? 0u : (unsigned)ch * WN_CH * plane * 4u;
 #pragma unroll
             for (int t = 0; t < I_PER_WAVE; ++t) {
                 const unsigned vo = ioff[t] == kOOB ? kOOB : ioff[t] + coff;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(raw_s[buf] + (wave + NW * t) * 256), 16, vo, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_c, (lptr_t)(raw_s[buf] + (wave + NW * t) * 256), 16, vo, 0, 0, 0);
             }
         } else {
 #pragma unroll
@@ -696,6 +705,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128(const WinoK
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 1, 1, true, false, false, true>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_unpool(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, false, false, true>(a); }
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_unpool(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true, true>(a); }
+// tensors of 4 GiB and more (per-chunk buffer resources): the 128-channel and the half-tile kernel, plain and unpooling
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_big(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, false, false, false, true>(a); }
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_big(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true, false, true>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_unpool_big(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, false, false, true, true>(a); }
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_unpool_big(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true, true, true>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_stamped(const WinoKArgs a) { conv3x3_wino_body<4, 1, 1>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_64x256_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 2, 1>(a); }
 
@@ -765,15 +779,27 @@ bool conv_wino_can_unpool(int K, int M, int H, int W)
 {
     const char* e = getenv("ST2_WINO_UNPOOL");               // =0: keep maxpool_bwd_amap_k (read per launch: the tests compare both)
     if ((e && *e == '0') || !conv_wino_ok(K, M, H, W) || W % 32 != 0 || H % 2 != 0) return false;
-    if (4ull * K * (H / 2) * (W / 2) >= 0xfffffff0ull) return false;
     const int v = wino_default_variant(M, W);
-    return v == 0 || v == 8;
+    return v == 0 || v == 8;                                 // (a pooled diff of 4 GiB or more: the BIG builds, conv_wino_ok has checked the sizes)
+}
+
+// a tensor of 4 GiB or more on either side: the BIG builds (aligned widths, the 128-channel or the half-tile variant) take it while one
+// chunk of 8 planes stays below 4 GiB (32-bit byte offsets from the chunk's base) and the output below 2^32 elements (32-bit element offsets)
+static bool wino_needs_big(int K, int M, int H, int W) { return 4ull * K * H * W >= 0xfffffff0ull || 4ull * M * H * W >= 0xfffffff0ull; }
+static bool wino_big_ok(int K, int M, int H, int W)
+{
+    const char* e = getenv("ST2_WINO_BIG");                  // =0: refuse tensors >= 4 GiB as before (read per call)
+    if (e && *e == '0') return false;
+    const int v = wino_default_variant(M, W);
+    (void)K;                                                 // (the input is addressed chunk by chunk: any depth)
+    return W % 4 == 0 && (v == 0 || v == 8) && 32ull * H * W < 0xfffffff0ull && (unsigned long long)M * H * W <= 0x100000000ull;
 }
 
 bool conv_wino_ok(int K, int M, int H, int W)
 {
     static const bool anyw = [] { const char* e = getenv("ST2_WINO_ANYW"); return !(e && *e == '0'); }();
-    return K >= 8 && K % 8 == 0 && (W % 4 == 0 || anyw) && W >= 1 && M >= 48 && H >= 1 && 4ull * K * H * W < 0xfffffff0ull && 4ull * M * H * W < 0xfffffff0ull;
+    if (!(K >= 8 && K % 8 == 0 && (W % 4 == 0 || anyw) && W >= 1 && M >= 48 && H >= 1)) return false;
+    return !wino_needs_big(K, M, H, W) || wino_big_ok(K, M, H, W);
 }
 
 // variant: 0 = 128 channels x 4x32 pixels, 1 = 64 channels x 8x32 pixels (tile groups split over the waves),
@@ -819,12 +845,19 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     k.mask_src = p.mask_src; k.inject = p.inject;
     k.K = p.K; k.M = p.M; k.H = p.H; k.W = p.W; k.nch = p.K / WN_CH;
     k.tiles_x = (p.W + 31) / 32; k.tiles_y = (p.H + prows - 1) / prows; k.n_mtiles = (p.M + bm - 1) / bm; k.relu = p.relu;
-    k.in_bytes = (unsigned)(4ull * p.K * p.H * p.W);
+    bool big = wino_needs_big(p.K, p.M, p.H, p.W);
+    if (big && (!wino_big_ok(p.K, p.M, p.H, p.W) || !(variant == 0 || variant == 8) || !quad)) return hipErrorInvalidValue;
+    {   // test hook: ST2_WINO_FORCE_BIG=1 runs the BIG builds on tensors of any size (tests/test_gpu_winograd.py compares them bit for bit)
+        const char* fb = getenv("ST2_WINO_FORCE_BIG");
+        if (fb && *fb == '1' && quad && (variant == 0 || variant == 8) && wino_big_ok(p.K, p.M, p.H, p.W)) big = true;
+    }
+    k.in_bytes = big ? (unsigned)(4ull * WN_CH * p.H * p.W) : (unsigned)(4ull * p.K * p.H * p.W);      // BIG: the bytes of one chunk
     const bool unpool = p.unpool_amap != nullptr;
     if (unpool) {
         if (!(variant == 0 || variant == 8) || !quad || p.W % 32 != 0 || p.H % 2 != 0 || p.pool_out) return hipErrorInvalidValue;
         k.unpool_amap = p.unpool_amap; k.ph = p.H / 2; k.pw = p.W / 2;
-        k.in_bytes = (unsigned)(4ull * p.K * k.ph * k.pw);
+        k.in_bytes = big ? (unsigned)(4ull * WN_CH * k.ph * k.pw) : (unsigned)(4ull * p.K * k.ph * k.pw);
+        if ((unsigned long long)p.K * k.ph * k.pw >= 0xfffffff0ull) return hipErrorInvalidValue;
         k.amap_bytes = (unsigned)((unsigned long long)p.K * k.ph * k.pw);
     }
     k.u_bytes = (unsigned)(4ull * wino_pack_floats(p.K, p.M));
@@ -843,7 +876,8 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     if (k.splits > 1 && p.pool_out) return hipErrorInvalidValue;              // the caller asks conv_wino_can_pool() first
     const dim3 g((unsigned)(nblk * k.splits)), b(256);
     switch (variant) {
-    case 0: if (unpool) conv3x3_wino_f32_128x128_unpool<<<g, b, 0, s>>>(k);
+    case 0: if (big) { if (unpool) conv3x3_wino_f32_128x128_unpool_big<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_128x128_big<<<g, b, 0, s>>>(k); }
+            else if (unpool) conv3x3_wino_f32_128x128_unpool<<<g, b, 0, s>>>(k);
             else if (quad) conv3x3_wino_f32_128x128<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_128x128_anyw<<<g, b, 0, s>>>(k); break;
     case 1: if (quad) conv3x3_wino_f32_64x256<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_64x256_anyw<<<g, b, 0, s>>>(k); break;
     case 3: conv3x3_wino_f32_ps64x256<<<g, b, 0, s>>>(k); break;
@@ -851,7 +885,9 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     case 4: conv3x3_wino_f32_ps64x256_stamped<<<g, b, 0, s>>>(k); break;
     case 6: conv3x3_wino_f32_w8_128x128<<<g, dim3(512), 0, s>>>(k); break;
     case 7: conv3x3_wino_f32_w8_128x128_stamped<<<g, dim3(512), 0, s>>>(k); break;
-    case 8: if (unpool) conv3x3_wino_f32_h4_64x128_unpool<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128<<<g, b, 0, s>>>(k); break;
+    case 8: if (big) { if (unpool) conv3x3_wino_f32_h4_64x128_unpool_big<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128_big<<<g, b, 0, s>>>(k); }
+            else if (unpool) conv3x3_wino_f32_h4_64x128_unpool<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128<<<g, b, 0, s>>>(k);
+            break;
     case 9: conv3x3_wino_f32_h4_64x128_stamped<<<g, b, 0, s>>>(k); break;
     default: conv3x3_wino_f32_64x256_stamped<<<g, b, 0, s>>>(k); break;
     }

@@ -231,6 +231,36 @@ def test_image_terms_with_integral_and_fractional_exponents(p_power, tv_power):
         x = x + 3.0 * np.sign(go).astype(F32)
 
 
+@pytest.mark.parametrize('h,w', [(64, 96), (50, 72), (18, 22)])
+def test_big_style_gradient_kernel_matches_the_lds_dma_kernels(h, w, monkeypatch):
+    """style_grad_big_k (64-bit addressing, register-staged: the style gradient of a blob of 4 GiB or more -- conv1_1 .. conv3_1 of an
+    8192 x 8192 image in one engine) forced at test size (ST2_STYLE_FORCE_BIG=1) against the LDS-DMA kernels it stands in for: the
+    whole objective twice (first evaluation: raw S and the norm; second: the fused saxpy, accumulated onto a content term), tiles cut
+    by the last pixels, channel counts 64 / 128 / 256."""
+    topo = oracle.VGG19_TOPOLOGY[:7]
+    net_params = oracle.he_init_weights(topo, seed=5, bias_std=0.1)
+    weights = {'content': {'conv2_1': 0.3}, 'style': {'conv1_1': 1, 'conv2_1': 0.7, 'conv3_1': 1.5}, 'deepdream': {}}
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (h, w, 3)).astype(np.uint8), rs(2).randint(0, 256, (40, 36, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (h, w, 3)).astype(np.uint8))
+    got = {}
+    for big in ('0', '1'):
+        monkeypatch.setenv('ST2_STYLE_FORCE_BIG', big)
+        dev = st2.StyleTransfer(st2.HipModel(net_params, topology=topo))
+        dev.set_input(init); dev.set_content(content); dev.set_style(style); dev.reset()
+        dev.set_weights(weights, TILED_PARAMS)
+        l1, g1 = dev.opfunc()
+        x2 = dev.engine.get_input_nchw() + F32(2.0) * np.sign(g1)
+        l2, g2 = dev.opfunc(x2)
+        got[big] = (l1, g1, l2, g2, dict(dev.traces[-1].data))
+    a, b = got['0'], got['1']
+    assert np.isclose(a[0], b[0], rtol=1e-6) and np.isclose(a[2], b[2], rtol=1e-6)
+    assert rel_l2(b[1], a[1]) <= 2e-6 and rel_l2(b[3], a[3]) <= 2e-6, (rel_l2(b[1], a[1]), rel_l2(b[3], a[3]))
+    for k in a[4]:
+        if k != 'time':
+            assert np.isclose(b[4][k], a[4][k], rtol=1e-5, atol=1e-12), (k, b[4][k], a[4][k])
+
+
 @pytest.mark.parametrize('weights', [
     {'content': {}, 'style': {}, 'deepdream': {}},                                     # image terms only: no layer is visited
     {'content': {}, 'style': {}, 'deepdream': {'conv1_1': 0.3}},                       # the shallowest blob only
@@ -927,13 +957,14 @@ def test_fused_tile_step_vgg19_on_the_2x4_grid_matches_the_single_gpu_engine(pre
         assert mse <= (0.25 if precision == 'fp32' else 1.0), (step, mse)
 
 
-def test_configs4_full_size_8192_two_tilings_agree_on_one_gpu():
+def test_configs4_full_size_8192_sharded_run_equals_one_engine_on_the_whole_image():
     """BASELINE configs[4] itself -- ONE 8192 x 8192 image, VGG19 to conv5_1, cut 2 x 4 into windows of 4176 x 2128 / 4176 x 2208 -- with
-    all eight ranks resident on the one GPU (24.7 GB per fp32 window since the engine keeps content features only where a content
-    weight reads them), one thread per rank, st_tile_step per rank and iteration, transport = ThreadFabric.  No single engine holds an
-    image of this size (conv1 blobs of 17 GB; 32-bit tensor addressing), so the reference for the sharded run is ANOTHER sharding of the
-    same job: the 4 x 2 cut (windows of 2128 / 2208 x 4176), whose seams, aprons and exchange plans share nothing with the first.  Both
-    must give the same loss and the same image after two Adam iterations."""
+    all eight ranks resident on the one GPU (24.7 GB per fp32 window), one thread per rank, st_tile_step per rank and iteration,
+    transport = ThreadFabric, against an INDEPENDENT reference: the plain engine on the whole image.  Round 3 had none (conv1 blobs of
+    17 GB against 32-bit buffer offsets) and compared two shardings of the same code; since round 4 one engine addresses tensors of
+    4 GiB and more (per-chunk buffer resources in the Winograd kernels, 32-bit element offsets up to 2^32 elements, a 64-bit-addressed
+    style gradient), so the sharded run -- aprons, overlap-add, torus ring, all-reduced Gram sums -- is checked against a run that has
+    none of them: same loss (rtol 2e-5) and the same image (MSE <= 0.25) after two Adam iterations."""
     import time
     from style_transfer2_amd import tiled, tiling
     from style_transfer2_amd.tile_backend import HipTileBackend
@@ -950,43 +981,61 @@ def test_configs4_full_size_8192_two_tilings_agree_on_one_gpu():
                'deepdream': {}}
     params = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
     net_params = oracle.he_init_weights(oracle.VGG19_TOPOLOGY, seed=0)
-    results = {}
-    for rows, cols in ((2, 4), (4, 2)):
-        world = rows * cols
-        grid = tiling.TileGrid(h, w, rows, cols, oracle.VGG19_TOPOLOGY, 17)
-        fabric = ThreadFabric(world, timeout=300.0)
-        backends, ranks = [], []
-        t0 = time.time()
-        for r in range(world):
-            backend = HipTileBackend(net_params, grid, r, content, style, init, weights, params, step_size=10)
-            backend.comm_init_local(r, world, fabric)
-            backends.append(backend)
-            ranks.append(tiled.FusedTiledTransfer(grid, r, backend))
-        t1 = time.time()
-        out = _run_ranks_as_threads(ranks, steps, fabric)
-        t2 = time.time()
-        full = np.zeros((h, w, 3), F32)
-        for r in range(world):
-            t = grid.tiles[r]
-            full[t.y0:t.y1, t.x0:t.x1] = out[r][-1][0]
-            for step in range(steps):
-                assert np.array_equal(np.asarray(out[r][step][1]), np.asarray(out[0][step][1]))
-        results[(rows, cols)] = (full, [out[0][step][1] for step in range(steps)])
-        used = (total - torch.cuda.mem_get_info()[0]) / 2 ** 30
-        print('[configs[4] %dx%d on one GPU] windows %s; build %.1f s, %d iterations %.2f s (eight ranks time-sliced, device-to-device exchanges), HBM in use %.0f GB; losses %s'
-              % (rows, cols, sorted({(wd.y1 - wd.y0, wd.x1 - wd.x0) for wd in grid.windows}), t1 - t0, steps, t2 - t1, used,
-                 ['%.9g' % v[-2] for v in results[(rows, cols)][1]]))
-        for b in backends:
-            b.engine.close()
-        del backends, ranks, out
-        __import__('gc').collect()
-    (img_a, tr_a), (img_b, tr_b) = results[(2, 4)], results[(4, 2)]
+    # ---- one engine on the whole image (the weights first: content features are then kept for conv4_2 only, 2 GB instead of 90)
+    t0 = time.time()
+    ref = st2.StyleTransfer(st2.HipModel(net_params))
+    ref.set_weights(weights, params)
+    ref.set_input(init); ref.set_content(content); ref.set_style(style)
+    ref.optimizer_cls = st2.AdamOptimizer; ref.set_step_size(10); ref.reset()
+    assert ref.start()
+    t1 = time.time()
+    want = []
+    for _ in range(steps):
+        img, tr = ref.step()
+        want.append((img, dict(tr)))
+    t2 = time.time()
+    used = (total - torch.cuda.mem_get_info()[0]) / 2 ** 30
+    print('[configs[4] one engine, 8192 x 8192] build %.1f s, %d iterations %.2f s, HBM in use %.0f GB; losses %s'
+          % (t1 - t0, steps, t2 - t1, used, ['%.9g' % tr['loss'] for _, tr in want]))
+    ref_img = np.asarray(want[-1][0], F32).copy()
+    ref.engine.close()
+    del ref, img
+    __import__('gc').collect()
+    # ---- the 2 x 4 sharding
+    rows, cols = 2, 4
+    world = rows * cols
+    grid = tiling.TileGrid(h, w, rows, cols, oracle.VGG19_TOPOLOGY, 17)
+    fabric = ThreadFabric(world, timeout=300.0)
+    backends, ranks = [], []
+    t0 = time.time()
+    for r in range(world):
+        backend = HipTileBackend(net_params, grid, r, content, style, init, weights, params, step_size=10)
+        backend.comm_init_local(r, world, fabric)
+        backends.append(backend)
+        ranks.append(tiled.FusedTiledTransfer(grid, r, backend))
+    t1 = time.time()
+    out = _run_ranks_as_threads(ranks, steps, fabric)
+    t2 = time.time()
+    full = np.zeros((h, w, 3), F32)
+    for r in range(world):
+        t = grid.tiles[r]
+        full[t.y0:t.y1, t.x0:t.x1] = out[r][-1][0]
+        for step in range(steps):
+            assert np.array_equal(np.asarray(out[r][step][1]), np.asarray(out[0][step][1]))
+    traces = [out[0][step][1] for step in range(steps)]
+    used = (total - torch.cuda.mem_get_info()[0]) / 2 ** 30
+    print('[configs[4] 2x4 on one GPU] windows %s; build %.1f s, %d iterations %.2f s (eight ranks time-sliced, device-to-device exchanges), HBM in use %.0f GB; losses %s'
+          % (sorted({(wd.y1 - wd.y0, wd.x1 - wd.x0) for wd in grid.windows}), t1 - t0, steps, t2 - t1, used, ['%.9g' % v[-2] for v in traces]))
+    for b_ in backends:
+        b_.engine.close()
+    del backends, ranks, out
+    __import__('gc').collect()
     for step in range(steps):
-        assert np.isclose(tr_a[step][-2], tr_b[step][-2], rtol=2e-5), (step, tr_a[step][-2], tr_b[step][-2])
-        assert np.isclose(tr_a[step][-1], tr_b[step][-1], rtol=1e-3), step
-    mse = float(np.mean((img_a.astype(np.float64) - img_b) ** 2))
-    moved = float(np.mean((img_a - init.astype(F32)) ** 2))
-    print('[configs[4] two tilings] image MSE %.3g between them after %d Adam iterations (the image moved by MSE %.3g)' % (mse, steps, moved))
+        assert np.isclose(traces[step][-2], want[step][1]['loss'], rtol=2e-5), (step, traces[step][-2], want[step][1]['loss'])
+        assert np.isclose(traces[step][-1], want[step][1]['grad'], rtol=1e-3), step
+    mse = float(np.mean((full.astype(np.float64) - ref_img) ** 2))
+    moved = float(np.mean((ref_img - init.astype(F32)) ** 2))
+    print('[configs[4] sharded vs one engine] image MSE %.3g after %d Adam iterations (the image moved by MSE %.3g)' % (mse, steps, moved))
     assert mse <= 0.25 and moved > 50.0
 
 

@@ -119,3 +119,29 @@ def test_pool_backward_through_the_arg_max_map_is_the_classic_one_bit_for_bit(h,
     r2 = np.random.RandomState(7)
     diffs = {n: r2.randn(*out['11'][0][n].shape).astype(F32) for n in ('conv3_1', 'conv2_1')}
     assert rel_l2(out['11'][1], cpu.backward(diffs)) <= 3e-5
+
+
+@pytest.mark.parametrize('h,w', [(64, 96), (66, 100), (64, 128), (70, 256), (8, 32)])
+def test_big_tensor_builds_equal_the_plain_builds_bit_for_bit(h, w, monkeypatch):
+    """Tensors of 4 GiB and more (one engine on an 8192 x 8192 image) take the BIG builds of the 128-channel and the half-tile kernel,
+    plain and unpooling: the activation buffer resource is rebuilt per chunk at the chunk's own base (32-bit byte offsets stay below
+    4 GiB), everything else is the same code.  ST2_WINO_FORCE_BIG=1 runs them at test size: forward blobs (with the fused pools and
+    their arg-max maps) and the image gradient through conv1_2 (half tile), conv2_2 (128 channels) and the unpooling data gradients
+    must equal the plain builds bit for bit.  The direct kernel's output check (32-bit ELEMENT offsets) is exercised by conv1_1; the
+    64-bit-addressed style gradient (ST2_STYLE_FORCE_BIG=1) by test_big_style_gradient_kernel_matches_the_lds_dma_kernels."""
+    topo = oracle.VGG19_TOPOLOGY[:7]                    # conv1_1 conv1_2 pool1 conv2_1 conv2_2 pool2 conv3_1
+    params = oracle.he_init_weights(topo, seed=3, bias_std=0.3)
+    rng = np.random.RandomState(h + w)
+    x = (rng.randn(1, 3, h, w) * 40).astype(F32)
+    out = {}
+    for big in ('0', '1'):
+        monkeypatch.setenv('ST2_WINO_FORCE_BIG', big)
+        gpu = st2.HipModel(params, topology=topo)
+        f = gpu.forward(x, ['conv1_2', 'pool1', 'conv2_1', 'conv2_2', 'pool2', 'conv3_1'])
+        r2 = np.random.RandomState(7)
+        diffs = {n: r2.randn(*f[n].shape).astype(F32) for n in ('conv3_1', 'conv2_1', 'conv1_2')}
+        out[big] = (f, gpu.backward(diffs))
+    for n in out['0'][0]:
+        assert np.array_equal(out['0'][0][n], out['1'][0][n]), n
+    assert np.array_equal(out['0'][1], out['1'][1])
+    assert float(np.abs(out['0'][1]).max()) > 0
