@@ -97,10 +97,10 @@ def make_job(inputs, optimizer, device, precision='fp32'):
     content, style, init, weights, params = inputs
     model = st2.HipModel(st2_weights.he_normal(st2.VGG19_TOPOLOGY, seed=0), device=device, precision=precision)
     job = st2.StyleTransfer(model)
+    job.set_weights(weights, params)         # first: the engine then keeps content features only where a content weight reads them
     job.set_input(init)
     job.set_content(content)
     job.set_style(style)
-    job.set_weights(weights, params)
     job.optimizer_cls = {'adam': st2.AdamOptimizer, 'lbfgs': st2.LBFGSOptimizer}[optimizer]
     job.set_step_size(STEP_SIZES[optimizer])
     job.reset()
@@ -504,7 +504,23 @@ def extra_configs(args, device):
         leg['leg_seconds'] = time.perf_counter() - t0
         leg['note'] = 'configs[4] asks for 8 GPUs; this is the same job with its eight ranks resident on ONE GPU (in-process transport): unmeasured on a multi-GPU node'
         return leg
+    def one_engine_8192():
+        # the same 8192 x 8192 job in ONE engine (tensors of 4 GiB and more: the BIG Winograd builds, 64-bit-addressed style gradient):
+        # the independent reference of the sharded run (tests/test_gpu_parity.py) and what one MI355X does with the image un-sharded
+        import ctypes
+        free = ctypes.c_size_t()
+        total = ctypes.c_size_t()
+        hip = ctypes.CDLL('libamdhip64.so')
+        if hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0 and free.value < 200 * 2 ** 30:
+            return {'skipped': 'only %.0f GiB of HBM free, the un-sharded 8192 x 8192 job needs 175' % (free.value / 2 ** 30)}
+        rs = np.random.RandomState
+        content = rs(1).randint(0, 256, (8192, 8192, 3)).astype(np.uint8)
+        init = rs(3).randint(0, 256, (8192, 8192, 3)).astype(np.uint8)
+        style = rs(2).randint(0, 256, (1024, 1024, 3)).astype(np.uint8)
+        return extra_config_leg('configs[4] image un-sharded: 8192x8192 in ONE engine (style image 1024x1024), Adam step 10, fp32',
+                                (content, style, init, WEIGHTS, PARAMS), 'adam', 'fp32', 3, 2, 2, device)
     if os.environ.get('ST2_BENCH_SKIP_8192') != '1':
+        guarded('8192x8192 one engine adam fp32', one_engine_8192)
         guarded('configs[4] 8192x8192 2x4 tiles, eight ranks on one GPU', tiled_8192)
     out['_seconds'] = time.perf_counter() - t_all
     return out
