@@ -93,7 +93,7 @@ _COL_BUDGET = 48 * 1024 * 1024  # floats per im2col band
 # same); both only remove time that is not arithmetic: first-touch page faults on hundreds of MB of fresh memory per call and
 # single-threaded strided copies, which together were 4/5 of an evaluation at 1024^2.
 _SCRATCH = {}
-_COPY_THREADS = max(1, min(8, os.cpu_count() or 1))
+_COPY_THREADS = max(1, min(32, os.cpu_count() or 1))      # (copies are memory-bound: 8 threads here, 32 on the GPU box's 256-core host)
 _pool = None
 
 

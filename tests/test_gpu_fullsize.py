@@ -331,18 +331,15 @@ def test_the_residual_after_adoption_is_the_gram_difference(fp32_1024):
     assert err_d <= 0.5 * err_adopt, (err_d, err_adopt)
 
 
-def test_second_evaluation_with_frozen_norms_and_three_adam_steps_at_1024(fp32_1024):
-    """worker.py:303-310 + optimizers.py:20-27 at the headline size: after the norm-capturing evaluation, a second evaluation at a
-    moved image (frozen norms), then three Adam iterations from the initial image on both sides -- per-step loss and the ITERATE
-    itself (north_star: "output pixels match the reference CPU worker ... within a stated fp32 MSE tolerance")."""
+def test_three_adam_steps_with_frozen_norms_at_1024(fp32_1024):
+    """worker.py:303-310 + optimizers.py:20-27 at the headline size: three Adam iterations from the initial image on both sides (the
+    first captures the norms, the others evaluate with them frozen) -- per-step loss and the ITERATE itself (north_star: "output
+    pixels match the reference CPU worker ... within a stated fp32 MSE tolerance")."""
     s = fp32_1024
     cpu, dev, go = s['cpu'], s['dev'], s['go']
-    x2 = s['x0'] + F32(2.0) * np.sign(go)
-    lo2, go2 = cpu.opfunc(x2)
-    ld2, gd2 = dev.opfunc(x2)
-    assert np.isclose(ld2, lo2, rtol=1e-5)
-    assert rel_l2(gd2, go2) <= 3e-3
-    report('fp32 vgg19 1024 second eval', {'loss_rel': float(abs(ld2 - lo2) / abs(lo2)), 'grad_rel_l2': rel_l2(gd2, go2)})
+    # (the second evaluation with frozen norms at a moved image is covered at this size by the Adam steps below -- every step after the
+    #  first evaluates with frozen norms -- and at 96 x 128 / in the golden vectors by the dedicated tests; evaluating it separately
+    #  here cost 7 s of oracle time)
     # three Adam iterations (SetOptimizer resets the state and the norms on both sides, worker.py:387-391,172-175)
     cpu.input[:] = s['x0']
     dev.engine.set_input_nchw(s['x0'])
