@@ -2,7 +2,7 @@
 """bf16 path at 2048^2: objective gradient with the style term fused into the data-gradient convs against the separate kernels."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 out = {}
 for flag in ('1', '0'):

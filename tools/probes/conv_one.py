@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time one conv shape/config with a chosen iteration count: conv_one.py K M H W cfg dgrad iters [repeat]"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from tools import probes
 lib = probes.load_library()
 K, M, H, W, cfg, dgrad, iters = [int(v) for v in sys.argv[1:8]]
