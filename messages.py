@@ -7,7 +7,7 @@ names/types -- they do (pinned by tests/golden/message_pickles.json, produced by
 classes).  ``app.py`` / ``router.py`` of the reference run against this module unchanged.
 """
 
-import inspect
+import sys
 import logging
 
 import numpy as np
@@ -28,13 +28,9 @@ class Message:
     def _set(self, **attrs):
         self.__dict__.update(attrs)
         if self.debug:
-            frame = inspect.currentframe()
-            try:
-                site = frame.f_back.f_back
-                logger.debug('%s created on line %d of %s: %s', type(self).__name__, site.f_lineno,
-                             site.f_code.co_filename, self)
-            finally:
-                del frame
+            # who constructed the message: two frames up (the constructor called _set); same log line as the reference's -dd output
+            site = sys._getframe(2)
+            logger.debug('%s created on line %d of %s: %s', type(self).__name__, site.f_lineno, site.f_code.co_filename, self)
 
     def __repr__(self):
         inner = ', '.join('%s=%s' % (k, _short(v)) for k, v in sorted(vars(self).items()))
