@@ -138,9 +138,15 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 //                a 32-bit byte offset from the resource's base, so the base moves instead: the activation resource is rebuilt per chunk at
 //                channel (c_first + ch) * 8 (a 64-bit scalar add; a chunk's 8 planes must stay below 4 GiB: H * W < 2^27) and the lane offsets are
 //                relative to the chunk.  The epilogue's 32-bit ELEMENT offsets already reach 2^32 elements (64 x 8192 x 8192 exactly).
-template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false, bool H4 = false, bool UNPOOL = false, bool BIG = false>
+// NOOUT = true (forward launches with the fused pool AND its arg-max map): the full-resolution blob is not written -- nothing reads it when
+//                the layer is pooled and carries no weight (the next conv reads the pooled blob, the pool's backward the map with the ReLU
+//                sign in it): the row exchange, bias / ReLU of the four pixels and the 16-byte store of every accumulator row are gone.
+//                A build of its own because the 512-register kernels have no register for a run-time flag (it spilled).
+template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false, bool H4 = false, bool UNPOOL = false, bool BIG = false,
+          bool NOOUT = false>
 __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
+    static_assert(!NOOUT || (QUAD && TG == 1 && !PS && !W8 && !UNPOOL && !BIG && DIAG == 0), "no-output builds: the builds that write the arg-max map");
     static_assert(!BIG || (QUAD && TG == 1 && !PS && !W8 && DIAG == 0), "big tensors: aligned widths, one tile group, four waves");
     static_assert(!UNPOOL || (QUAD && TG == 1 && !PS && !W8), "unpool: aligned widths, one tile group, four waves");
     static_assert(H4 || (WM * TG == 4 && (TG == 1 || TG == 2)), "4 waves");
@@ -661,6 +667,7 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
                     a.pool_out[po] = pm;
                 }
             }
+            if constexpr (NOOUT) continue;         // only the pooled blob and its arg-max map are wanted: nothing reads this one
             // give away the row this lane does not keep, receive the partner's part of the row it keeps (quad_perm 1,0,3,2)
             const float s0 = odd ? y00 : y10, s1 = odd ? y01 : y11;
             const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xf, 0xf, true));
@@ -705,6 +712,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128(const WinoK
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_stamped(const WinoKArgs a) { conv3x3_wino_body<2, 1, 1, true, false, false, true>(a); }
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_unpool(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, false, false, true>(a); }
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_unpool(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true, true>(a); }
+// forward launches that write only the pooled blob and its arg-max map
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_noout(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, false, false, false, false, true>(a); }
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_noout(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true, false, false, true>(a); }
 // tensors of 4 GiB and more (per-chunk buffer resources): the 128-channel and the half-tile kernel, plain and unpooling
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_big(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, false, false, false, true>(a); }
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_big(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true, false, true>(a); }
@@ -738,6 +748,7 @@ __global__ __launch_bounds__(256) void wino_combine_k(const float* __restrict__ 
 
 static int wino_default_variant(int M, int W);
 static bool wino_variant_small(int variant);
+static bool wino_needs_big(int K, int M, int H, int W);
 bool conv_wino_ok(int K, int M, int H, int W);
 
 // Split-K factor for a launch that would leave most CUs idle (conv5_1 at 1024^2: 128 workgroups on 256 CUs)
@@ -771,6 +782,14 @@ bool conv_wino_pool_amap_ok(int K, int M, int H, int W)
     if (!conv_wino_can_pool(K, M, H, W) || W % 4 != 0 || H % 2 != 0) return false;
     const int v = wino_default_variant(M, W);
     return v == 0 || v == 6 || v == 8;
+}
+
+// may a forward launch of this shape with the fused pool skip its full-resolution blob (ConvProblem::out == nullptr)?
+bool conv_wino_can_skip_out(int K, int M, int H, int W)
+{
+    if (!conv_wino_pool_amap_ok(K, M, H, W) || wino_needs_big(K, M, H, W)) return false;
+    const int v = wino_default_variant(M, W);
+    return v == 0 || v == 8;
 }
 
 // may a data-gradient launch of this shape read the pooled diff + the arg-max map of the pool above its input (ConvProblem::unpool_amap)?
@@ -874,9 +893,14 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     const bool stamped = variant == 2 || variant == 4 || variant == 5 || variant == 7 || variant == 9;
     if (stamped && (!quad || k.splits > 1)) return hipErrorInvalidValue;      // the stamped builds are quad-only, one pass
     if (k.splits > 1 && p.pool_out) return hipErrorInvalidValue;              // the caller asks conv_wino_can_pool() first
+    // out == nullptr: only with the fused pool AND its arg-max map (variants 0 and 8 on aligned widths), one pass, no mask / inject
+    const bool noout = !p.out;
+    if (noout && (!k.pool_out || !k.pool_amap || k.splits > 1 || !quad || p.mask_src || p.inject || big || unpool || !(variant == 0 || variant == 8)))
+        return hipErrorInvalidValue;
     const dim3 g((unsigned)(nblk * k.splits)), b(256);
     switch (variant) {
-    case 0: if (big) { if (unpool) conv3x3_wino_f32_128x128_unpool_big<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_128x128_big<<<g, b, 0, s>>>(k); }
+    case 0: if (noout) conv3x3_wino_f32_128x128_noout<<<g, b, 0, s>>>(k);
+            else if (big) { if (unpool) conv3x3_wino_f32_128x128_unpool_big<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_128x128_big<<<g, b, 0, s>>>(k); }
             else if (unpool) conv3x3_wino_f32_128x128_unpool<<<g, b, 0, s>>>(k);
             else if (quad) conv3x3_wino_f32_128x128<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_128x128_anyw<<<g, b, 0, s>>>(k); break;
     case 1: if (quad) conv3x3_wino_f32_64x256<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_64x256_anyw<<<g, b, 0, s>>>(k); break;
@@ -885,7 +909,8 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     case 4: conv3x3_wino_f32_ps64x256_stamped<<<g, b, 0, s>>>(k); break;
     case 6: conv3x3_wino_f32_w8_128x128<<<g, dim3(512), 0, s>>>(k); break;
     case 7: conv3x3_wino_f32_w8_128x128_stamped<<<g, dim3(512), 0, s>>>(k); break;
-    case 8: if (big) { if (unpool) conv3x3_wino_f32_h4_64x128_unpool_big<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128_big<<<g, b, 0, s>>>(k); }
+    case 8: if (noout) conv3x3_wino_f32_h4_64x128_noout<<<g, b, 0, s>>>(k);
+            else if (big) { if (unpool) conv3x3_wino_f32_h4_64x128_unpool_big<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128_big<<<g, b, 0, s>>>(k); }
             else if (unpool) conv3x3_wino_f32_h4_64x128_unpool<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128<<<g, b, 0, s>>>(k);
             break;
     case 9: conv3x3_wino_f32_h4_64x128_stamped<<<g, b, 0, s>>>(k); break;

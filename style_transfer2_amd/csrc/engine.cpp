@@ -221,6 +221,10 @@ int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
                               const size_t pn = act16_elems(a.C[i + 1], (size_t)a.h[i + 1] * a.w[i + 1]);
                               if (!a.amap[i + 1]) HIP_TRY(hipMalloc((void**)&a.amap[i + 1], pn));
                               p.pool_amap = a.amap[i + 1]; a.amap_ok[i + 1] = 2;      // 2: the fp32 layout [C][ph][pw]
+                              // lean (inside an iteration): the full-resolution blob of a pooled, un-weighted layer is dead -- the next conv
+                              // reads the pooled blob, the pool's backward the arg-max map (with the ReLU sign in it) -- so it is not
+                              // written (conv1_2 at 1024^2: 268 MB and a quarter of the epilogue's instructions); same values everywhere else
+                              if (lean && !c->bf16 && !blob_active(c, i) && conv_wino_can_skip_out(p.K, p.M, p.H, p.W)) { p.out = nullptr; a.has32[i] = 0; }
                           }
                       }
                       HIP_TRY(launch_conv3x3_wino(p, c->stream));
@@ -768,7 +772,7 @@ int st_get_blob(st_ctx* c, int index, float* out)
 {
     if (!c || index < 0 || index >= c->nb || !out) return fail(ST_ERR_ARG, "bad argument");
     if (index > c->act.valid_to) return fail(ST_ERR_STATE, "blob %d was not computed by the last forward", index);
-    if (!c->act.has32[index]) return fail(ST_ERR_STATE, "blob %d (%s) is not materialised in fp32 by the lean bf16 evaluation (st_set_precision(ctx, 2) keeps every blob)", index, c->blob_names[index].c_str());
+    if (!c->act.has32[index]) return fail(ST_ERR_STATE, "blob %d (%s) is not materialised in fp32 by the lean evaluation of an iteration (st_opfunc / st_forward write every fp32 blob; bf16: st_set_precision(ctx, 2))", index, c->blob_names[index].c_str());
     const size_t n = (size_t)c->act.C[index] * c->act.h[index] * c->act.w[index];
     HIP_TRY(hipMemcpy(out, c->act.data[index], n * sizeof(float), hipMemcpyDeviceToHost));
     return ST_OK;

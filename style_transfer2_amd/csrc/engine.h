@@ -73,6 +73,7 @@ struct st_ctx {
     hipStream_t stream = nullptr;
     bool bf16 = false;                             // conv operands in bf16 (BASELINE config 3)
     bool lean = false;                             // bf16 objective evaluations skip the fp32 tensors only bf16 convs would read
+    bool in_step = false;                          // inside step_enqueue: objective evaluations may skip fp32 blobs nothing reads (lean fp32)
     bool wino = true;                              // Winograd F(2x2,3x3) for the eligible fp32 convs (ST2_WINO=0 disables)
     unsigned short *diff16A = nullptr, *diff16B = nullptr;
     std::vector<Layer> topo;

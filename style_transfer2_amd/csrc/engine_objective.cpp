@@ -15,9 +15,14 @@ int eval_objective(st_ctx* c, const float* x, bool want_grad, float* grad_out, b
             return fail(ST_ERR_STATE, "content features missing or of a different size than the input");
         if (al.s && !c->have_style) return fail(ST_ERR_STATE, "style Gram matrices missing");
     }
-    const bool lean = c->bf16 && c->lean && !c->tile.on;
+    // lean data flow: tensors nothing reads are not written.  bf16: the whole evaluation (st_set_precision(ctx, 1)); fp32: inside an
+    // iteration (st_step / st_step_begin), where no caller can ask for a blob afterwards -- st_opfunc keeps every blob for the test hooks.
+    // Identical values either way.  ST2_LEAN32=0 switches the fp32 part off (read per evaluation: A/B runs).
+    const bool lean = c->bf16 && c->lean && !c->tile.on;         // the bf16 data flow (forward AND backward)
+    bool lean32 = false;                                          // fp32: the forward only (dead pooled-layer blobs)
+    if (!c->bf16 && c->in_step && !c->tile.on) { const char* e = getenv("ST2_LEAN32"); lean32 = !(e && *e == '0'); }
     ST_TRY(ensure_content_features(c));
-    ST_TRY(forward_range(c, a, x, last, lean));
+    ST_TRY(forward_range(c, a, x, last, lean || lean32));
 
     std::vector<const float*> inj(c->nb, nullptr);
     std::fill(c->cnt.begin(), c->cnt.end(), 0);

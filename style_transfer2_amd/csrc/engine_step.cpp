@@ -127,6 +127,7 @@ int step_graph_capture(st_ctx* c, int par)
 // the optimizer step itself: everything st_step launches before the iterate is read back
 int step_enqueue(st_ctx* c)
 {
+    struct InStep { st_ctx* c; InStep(st_ctx* x) : c(x) { c->in_step = true; } ~InStep() { c->in_step = false; } } in_step(c);
     if (c->opt_kind == ST_OPT_ADAM) {
         c->items1 += 1; c->items2 += 1;          // DecayingMean.__call__(item), utils.py:58-61
         bool replayed = false;

@@ -115,7 +115,10 @@ int st_tile_forward(st_ctx* c, float** dev_ptr, int* n_floats)
     HIP_TRY(hipMemsetAsync(c->tile.p1, 0, std::max<size_t>(n1, 1) * sizeof(float), c->stream));
     // bf16 operands: the lean data flow here too -- an fp32 blob / diff is written only where something reads fp32 (the weighted
     // blobs: the region-of-interest loss kernels are fp32), pools ride on their producing conv, the backward masks from the bf16 copies
-    ST_TRY(forward_range(c, a, c->x[c->cur], last, c->bf16 && c->lean));
+    // fp32, inside the fused iteration (st_tile_step): the full-resolution blobs of pooled, un-weighted layers are not written either
+    bool lean32 = false;
+    if (!c->bf16 && c->tile.fused) { const char* e = getenv("ST2_LEAN32"); lean32 = !(e && *e == '0'); }
+    ST_TRY(forward_range(c, a, c->x[c->cur], last, (c->bf16 && c->lean) || lean32));
     size_t pos = 0;
     for (const ActiveLayer& al : c->active) {
         const int b = al.blob, C = a.C[b];

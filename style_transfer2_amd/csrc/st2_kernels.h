@@ -59,6 +59,7 @@ bool conv_wino_ok(int K, int M, int H, int W);
 hipError_t launch_maxpool_bwd_amap(const float* dy, const unsigned char* amap, float* dx, int C, int H, int W, hipStream_t s);
 bool conv_wino_pool_amap_ok(int K, int M, int H, int W);   // ... and such a launch fills ConvProblem::pool_amap
 bool conv_wino_can_unpool(int K, int M, int H, int W);   // a data-gradient launch of this shape may take ConvProblem::unpool_amap
+bool conv_wino_can_skip_out(int K, int M, int H, int W);   // a forward launch with pool_out + pool_amap may pass out == nullptr
 bool conv_wino_can_pool(int K, int M, int H, int W);   // launch_conv3x3_wino may fuse the following max-pool (ConvProblem::pool_out)
 int conv_wino_splits(int K, int M, int H, int W);   // split-K factor the automatic path would use (1 = none); needs splits*M*H*W floats of scratch
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);

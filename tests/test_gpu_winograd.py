@@ -145,3 +145,51 @@ def test_big_tensor_builds_equal_the_plain_builds_bit_for_bit(h, w, monkeypatch)
         assert np.array_equal(out['0'][0][n], out['1'][0][n]), n
     assert np.array_equal(out['0'][1], out['1'][1])
     assert float(np.abs(out['0'][1]).max()) > 0
+
+
+@pytest.mark.parametrize('optimizer,weighted_pooled', [('adam', False), ('lbfgs', False), ('adam', True)])
+def test_lean_fp32_iterations_skip_dead_blobs_and_change_nothing(optimizer, weighted_pooled, monkeypatch):
+    """Inside an iteration (st_step) the full-resolution blob of a pooled layer that carries no weight is dead: the next conv reads the
+    pooled blob, the pool's backward the arg-max map (ReLU sign included).  The NOOUT builds of the half-tile (conv1_2) and the
+    128-channel kernel (conv2_2) do not write it (conv1_2 at 1024^2: 268 MB per step and the row exchange / bias / ReLU / store of
+    every accumulator row).  ST2_LEAN32=0 writes everything: the iterates and traces must be equal bit for bit; st_opfunc (the test
+    hook) always writes every blob; a weighted pooled layer keeps its blob.  256 x 512: large enough that neither launch splits K
+    (a split-K launch has no fused pool)."""
+    topo = oracle.VGG19_TOPOLOGY[:10]                   # ... conv3_1 .. conv3_4
+    params = oracle.he_init_weights(topo, seed=3, bias_std=0.2)
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (256, 512, 3)).astype(np.uint8), rs(2).randint(0, 256, (40, 36, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (256, 512, 3)).astype(np.uint8))
+    weights = {'content': {'conv3_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1}, 'deepdream': {}}
+    if weighted_pooled:
+        weights['style']['conv2_2'] = 0.5
+    tv = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
+    runs = {}
+    for lean in ('1', '0'):
+        monkeypatch.setenv('ST2_LEAN32', lean)
+        dev = st2.StyleTransfer(st2.HipModel(params, topology=topo))
+        dev.set_input(init); dev.set_content(content); dev.set_style(style); dev.reset()
+        dev.set_weights(weights, tv)
+        dev.optimizer_cls = st2.AdamOptimizer if optimizer == 'adam' else st2.LBFGSOptimizer
+        dev.set_step_size(10 if optimizer == 'adam' else 1)
+        dev.reset()
+        assert dev.start()
+        out = [dev.step() for _ in range(4)]
+        runs[lean] = [(np.asarray(i).copy(), dict(t)) for i, t in out]
+        if lean == '1':
+            with pytest.raises(st2.StError):
+                dev.engine.get_blob('conv1_2')                                  # pooled, un-weighted: not written inside the step
+            if weighted_pooled:
+                assert dev.engine.get_blob('conv2_2') is not None               # pooled but weighted: kept
+            else:
+                with pytest.raises(st2.StError):
+                    dev.engine.get_blob('conv2_2')
+        else:
+            assert dev.engine.get_blob('conv1_2') is not None
+        dev.opfunc()
+        assert dev.engine.get_blob('conv1_2') is not None                       # the test hook writes every blob
+    for (ia, ta), (ib, tb) in zip(runs['1'], runs['0']):
+        assert np.array_equal(ia, ib)
+        for k in ta:
+            if k != 'time':
+                assert ta[k] == tb[k] or (np.isnan(ta[k]) and np.isnan(tb[k])), k
