@@ -200,6 +200,9 @@ def cpu_baseline_and_parity(inputs, optimizer, precision, dev_eval, iterations=1
     net = oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False,
                            operands='bf16' if precision == 'bf16' else 'fp32')
     job = oracle.TransferOracle(net)
+    # (content features / style Grams of the weighted blobs only -- the reference keeps all 22 because the weights may change later;
+    #  here they are fixed: same values, two whole-net forwards less of untimed set-up)
+    job.feature_layers = [n for n in net.layers() if any(abs(weights[k].get(n, 0)) > 1e-15 for k in weights)]
     job.set_input(init)
     job.set_content(content)
     job.set_style(style)

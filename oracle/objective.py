@@ -85,6 +85,10 @@ class TransferOracle:
         self.step_size = self.default_steps['lbfgs']
         self.norms = {k: {} for k in 'cds'}
         self.traces = []
+        # The reference keeps the content features and style Grams of EVERY blob (worker.py:204-216: the weights may change later),
+        # which at full size is a whole-net forward and 22 blob copies per image.  A test that fixes its weights beforehand may name
+        # the blobs it will weight: only those are then computed and kept -- the values are the same, the others are never read.
+        self.feature_layers = None
 
     # --- state (worker.py:140-229) -----------------------------------------------------------
     def check_consistency(self):
@@ -129,12 +133,12 @@ class TransferOracle:
 
     def set_content(self, image):
         self.content = self.model.preprocess(image)
-        self.features = {k: v.copy() for k, v in self.model.forward(self.content).items()}
+        self.features = {k: v.copy() for k, v in self.model.forward(self.content, self.feature_layers).items()}
         self._maybe_start()
         self.objective_changed()
 
     def set_style(self, image):
-        feats = self.model.forward(self.model.preprocess(image))
+        feats = self.model.forward(self.model.preprocess(image), self.feature_layers)
         self.grams = {k: gram(v) for k, v in feats.items()}
         self._maybe_start()
         self.objective_changed()
