@@ -865,6 +865,29 @@ def test_fused_tile_lbfgs_on_a_1x1_grid_follows_the_engine_lbfgs(h, w, monkeypat
         assert np.mean((ft.tile_image() - img) ** 2) <= (1e-4 if i < 3 else 0.1), i
 
 
+@pytest.mark.parametrize('optimizer', ['adam', 'lbfgs'])
+def test_fused_tile_step_without_a_trace_reads_nothing_back_and_changes_nothing(optimizer):
+    """st_tile_step(ctx, NULL): the device loop of a headless sharded job -- no trace, no host synchronisation.  Three iterations of
+    which the first two are trace-less must leave the same tile, bit for bit, as three iterations with their traces."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    h, w = 64, 96
+    content, style, init = _tiled_images(h, w)
+    params = oracle.he_init_weights(TILED_TOPO, 0, 0.1)
+    grid = tiling.TileGrid(h, w, 1, 1, TILED_TOPO, 5)
+    tiles = []
+    for quiet in (True, False):
+        backend = HipTileBackend(params, grid, 0, content, style, init, TILED_WEIGHTS, TILED_PARAMS, step_size=10 if optimizer == 'adam' else 1,
+                                 topology=TILED_TOPO, optimizer=optimizer)
+        backend.comm_init_solo(0, 1)
+        ft = tiled.FusedTiledTransfer(grid, 0, backend)
+        for _ in range(2):
+            ft.step_async() if quiet else ft.step()
+        vals = ft.step()
+        tiles.append((ft.tile_image(), np.asarray(vals)))
+    assert np.array_equal(tiles[0][0], tiles[1][0]) and np.array_equal(tiles[0][1], tiles[1][1])
+
+
 @pytest.mark.parametrize('rows,cols', [(1, 2), (2, 4)])
 def test_fused_tile_lbfgs_on_in_process_grids_follows_the_oracle(rows, cols):
     """The reference's default optimizer (worker.py:135-136) over the sharded image, fused: every rank one st_tile_step per iteration,
