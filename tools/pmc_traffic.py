@@ -21,10 +21,10 @@ LOAD_WIDTH = (
     ('conv3x3_first_split_k', 4),                 # the fp32 image, dword loads into the halo tile
     ('conv3x3_mfma', 16),                         # LDS-DMA dwordx4 for weights and activation tiles (fp32 and bf16 kernels)
     ('conv3x3_dgrad_first_f32q', 16), ('conv3x3_dgrad_first_bf16', 16), ('conv3x3_dgrad_first_f32', 4),
-    ('conv3x3_dgrad_smallM16', 16), ('conv3x3_dgrad_smallM', 4),
+    ('conv3x3_dgrad_smallM16', 16), ('conv3x3_dgrad_smallM_dma', 16), ('conv3x3_dgrad_smallM', 4),
     ('wino_combine_k', 16),
     ('gram_partial_dma', 16), ('gram16_partial', 16), ('gram_partial_k', 4), ('gram_fold_k', 4), ('gram_reduce', 4),
-    ('style_grad_mfma', 16), ('style_grad16', 16), ('style16_pack', 4), ('style_s2_trace_k', 16),
+    ('style_grad_mfma', 16), ('style_grad_big_k', 16), ('style_grad16', 16), ('style16_pack', 4), ('style_s2_trace_k', 16),
     ('layer_elem_k', 16),
     ('image_pass_k', 16), ('image_pass_tile_k', 4),
     ('maxpool_fwd_v4_k', 16), ('maxpool_bwd_v4_k', 16), ('maxpool_bwd_amap_k', 8), ('maxpool_bwd_idx16_k', 16),

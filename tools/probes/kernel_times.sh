@@ -7,7 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/kernel_times
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt -- python3 $REPO/bench.py --no-cpu-baseline --no-worker-level --steps 10 --repeats 1 "$@" > $OUT/bench.json 2> $OUT/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o kt -- python3 $REPO/bench.py --no-cpu-baseline --no-worker-level --no-extra-configs --steps 10 --repeats 1 "$@" > $OUT/bench.json 2> $OUT/err.log
 python3 - <<PY
 import csv, glob, re
 f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)

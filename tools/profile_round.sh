@@ -10,10 +10,10 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- python3 $ROOT/bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-worker-level "$@" > $OUT/bench_stats.json 2> $OUT/stats.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-worker-level "$@" > $OUT/bench_fetch.json 2> $OUT/fetch.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python3 $ROOT/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-worker-level "$@" > $OUT/bench_write.json 2> $OUT/write.log
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- python3 $ROOT/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-worker-level "$@" > $OUT/bench_mfma.json 2> $OUT/mfma.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- python3 $ROOT/bench.py --steps 20 --warmup 3 --repeats 1 --no-cpu-baseline --no-worker-level --no-extra-configs "$@" > $OUT/bench_stats.json 2> $OUT/stats.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o f -- python3 $ROOT/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-worker-level --no-extra-configs "$@" > $OUT/bench_fetch.json 2> $OUT/fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o w -- python3 $ROOT/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-worker-level --no-extra-configs "$@" > $OUT/bench_write.json 2> $OUT/write.log
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/mfma -o m -- python3 $ROOT/bench.py --steps 4 --warmup 1 --repeats 1 --no-cpu-baseline --no-worker-level --no-extra-configs "$@" > $OUT/bench_mfma.json 2> $OUT/mfma.log
 cd $ROOT
 M=$(find $OUT/mfma -name '*counter_collection.csv' | head -1)
 python3 tools/pmc_mfma.py $M $OUT/pmc_mfma.json > $OUT/pmc_mfma.txt
