@@ -327,7 +327,7 @@ int st_tile_plan(st_ctx* c, int phase, int n_peers, const st_tile_peer* peers)
 // torus ring of the TV stencil -> image-space pass.  adam: that pass is the fused TV / p-norm / Adam update into x[cur ^ 1]; else it
 // leaves the combined gradient of the tile's pixels in c->grad (window layout).  The phase-3 sums are all-reduced either way.
 struct TileEval { float *p1 = nullptr, *p2 = nullptr, *p3 = nullptr; int n1 = 0, n2 = 0, n3 = 0; };
-static int tile_evaluate(st_ctx* c, bool adam, TileEval& e)
+static int tile_evaluate(st_ctx* c, bool adam, TileEval& e, bool want_trace)
 {
     st_ctx::Tile& t = c->tile;
     const int wh = c->H, ww = c->W, th = t.ty1 - t.ty0, tw = t.tx1 - t.tx0;
@@ -348,7 +348,9 @@ static int tile_evaluate(st_ctx* c, bool adam, TileEval& e)
     ST_TRY(comm_exchange(c, ST_TILE_PLAN_RING, c->x[c->cur], wh, ww, c->comm.ring, th + 2, tw + 2, false));
     if (adam) ST_TRY(st_tile_update(c, c->comm.ring, &e.p3, &e.n3));            // phase 4: TV / p-norm / Adam on the tile
     else ST_TRY(st_tile_gradient(c, c->comm.ring, &e.p3, &e.n3));               //          or the combined gradient only
-    ST_TRY(comm_allreduce(c, e.p3, e.n3));
+    // the image-space sums (and, in steady state, the style-gradient sums) feed the TRACE only: a caller that reads nothing back
+    // (st_tile_step(ctx, NULL), the device loop of a headless job) saves this collective -- one all-reduce per Adam iteration remains
+    if (want_trace) ST_TRY(comm_allreduce(c, e.p3, e.n3));
     return ST_OK;
 }
 
@@ -375,7 +377,7 @@ static int tile_read_trace(st_ctx* c, const TileEval& e, double* trace)
 // 2 kLbNB-vector replaces the <= 2k + 3 scalar all-reduces of the chain form (tiled.TiledTransfer), after which every rank runs the same
 // bookkeeping (the s.y > 1e-10 gate, eviction) and coefficient recursion on the same numbers.  Per step: 2 all-reduces + 3 exchanges
 // for the evaluation, 1 all-reduce for the pair, 1 apron refresh.
-static int tile_lbfgs_step(st_ctx* c, TileEval& e)
+static int tile_lbfgs_step(st_ctx* c, TileEval& e, bool want_trace)
 {
     st_ctx::Tile& t = c->tile;
     const int wh = c->H, ww = c->W, th = t.ty1 - t.ty0, tw = t.tx1 - t.tx0;
@@ -404,7 +406,7 @@ static int tile_lbfgs_step(st_ctx* c, TileEval& e)
     }
     if (!c->lb_gram_form) return fail(ST_ERR_STATE, "the history was built by the chain form: reset the optimizer before the fused tile-sharded L-BFGS");
     if (!c->have_cur) {             // optimizers.py:64-65: loss, grad at the starting point
-        ST_TRY(tile_evaluate(c, false, e));
+        ST_TRY(tile_evaluate(c, false, e, false));
         ST_TRY(strips(c, c->grad, 3, wh, ww, tile_rect, c->g_cur, 0));
         { ProfScope ps(c, P_VECTOR, 0, 4.0 * n_t);
           HIP_TRY(launch_lbfgs_gram_pass_local(args(1), nullptr, 0, s)); }
@@ -419,7 +421,7 @@ static int tile_lbfgs_step(st_ctx* c, TileEval& e)
         ST_TRY(strips(c, c->x[c->cur], 3, wh, ww, tile_rect, t.lb_x, 1));
         ST_TRY(comm_exchange(c, ST_TILE_PLAN_REFRESH, c->x[c->cur], wh, ww, c->x[c->cur], wh, ww, false));
     }
-    ST_TRY(tile_evaluate(c, false, e));                                         // loss, grad = opfunc(x)           (optimizers.py:72)
+    ST_TRY(tile_evaluate(c, false, e, want_trace));                             // loss, grad = opfunc(x)           (optimizers.py:72)
     ST_TRY(strips(c, c->grad, 3, wh, ww, tile_rect, c->pvec, 0));               // this rank's tile of the new gradient
     {   // y = grad - self.grad; store_curvature_pair(s, y)                                                         (optimizers.py:73-87)
         { ProfScope ps(c, P_VECTOR, 0, 4.0 * n_t * (2.0 * kLbfgsCorr + 4.0));
@@ -443,10 +445,10 @@ int st_tile_step(st_ctx* c, double* trace)
     c->tile.fused = true;
     TileEval e;
     if (c->opt_kind == ST_OPT_LBFGS) {
-        ST_TRY(tile_lbfgs_step(c, e));
+        ST_TRY(tile_lbfgs_step(c, e, trace != nullptr));
         if (trace) ST_TRY(tile_read_trace(c, e, trace));                        // (x was updated in place: no swap)
     } else {
-        ST_TRY(tile_evaluate(c, true, e));
+        ST_TRY(tile_evaluate(c, true, e, trace != nullptr));
         ST_TRY(comm_exchange(c, ST_TILE_PLAN_REFRESH, c->x[c->cur ^ 1], wh, ww, c->x[c->cur ^ 1], wh, ww, false));
         if (trace) ST_TRY(tile_read_trace(c, e, trace));
         c->cur ^= 1;                                                            // st_tile_swap

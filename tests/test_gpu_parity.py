@@ -865,27 +865,53 @@ def test_fused_tile_lbfgs_on_a_1x1_grid_follows_the_engine_lbfgs(h, w, monkeypat
         assert np.mean((ft.tile_image() - img) ** 2) <= (1e-4 if i < 3 else 0.1), i
 
 
+class _QuietFirst:
+    """A FusedTiledTransfer whose first `n` iterations read nothing back (st_tile_step(ctx, NULL))."""
+    def __init__(self, ft, n):
+        self.ft, self.n, self.k = ft, n, 0
+
+    def step(self):
+        self.k += 1
+        if self.k <= self.n:
+            self.ft.step_async()
+            return np.zeros(1)
+        return self.ft.step()
+
+    def tile_image(self):
+        return self.ft.tile_image()
+
+
 @pytest.mark.parametrize('optimizer', ['adam', 'lbfgs'])
-def test_fused_tile_step_without_a_trace_reads_nothing_back_and_changes_nothing(optimizer):
-    """st_tile_step(ctx, NULL): the device loop of a headless sharded job -- no trace, no host synchronisation.  Three iterations of
-    which the first two are trace-less must leave the same tile, bit for bit, as three iterations with their traces."""
+@pytest.mark.parametrize('cols', [1, 2])
+def test_fused_tile_step_without_a_trace_reads_nothing_back_and_changes_nothing(optimizer, cols):
+    """st_tile_step(ctx, NULL): the device loop of a headless sharded job -- no trace, no host synchronisation, and the all-reduce that
+    only the trace needs is not issued (every rank skips it together).  Three iterations of which the first two are trace-less must
+    leave the same tiles and the same third trace, bit for bit, as three iterations with their traces -- one rank and two."""
     from style_transfer2_amd import tiled, tiling
     from style_transfer2_amd.tile_backend import HipTileBackend
     h, w = 64, 96
     content, style, init = _tiled_images(h, w)
     params = oracle.he_init_weights(TILED_TOPO, 0, 0.1)
-    grid = tiling.TileGrid(h, w, 1, 1, TILED_TOPO, 5)
-    tiles = []
-    for quiet in (True, False):
-        backend = HipTileBackend(params, grid, 0, content, style, init, TILED_WEIGHTS, TILED_PARAMS, step_size=10 if optimizer == 'adam' else 1,
-                                 topology=TILED_TOPO, optimizer=optimizer)
-        backend.comm_init_solo(0, 1)
-        ft = tiled.FusedTiledTransfer(grid, 0, backend)
-        for _ in range(2):
-            ft.step_async() if quiet else ft.step()
-        vals = ft.step()
-        tiles.append((ft.tile_image(), np.asarray(vals)))
-    assert np.array_equal(tiles[0][0], tiles[1][0]) and np.array_equal(tiles[0][1], tiles[1][1])
+    grid = tiling.TileGrid(h, w, 1, cols, TILED_TOPO, 5)
+    results, reduces = [], []
+    for quiet in (2, 0):
+        fabric = ThreadFabric(cols)
+        ranks = []
+        for r in range(cols):
+            backend = HipTileBackend(params, grid, r, content, style, init, TILED_WEIGHTS, TILED_PARAMS, step_size=10 if optimizer == 'adam' else 1,
+                                     topology=TILED_TOPO, optimizer=optimizer)
+            if cols == 1:
+                backend.comm_init_solo(0, 1)
+            else:
+                backend.comm_init_local(r, cols, fabric)
+            ranks.append(_QuietFirst(tiled.FusedTiledTransfer(grid, r, backend), quiet))
+        out = _run_ranks_as_threads(ranks, 3, fabric)
+        results.append([(out[r][-1][0], np.asarray(out[r][-1][1])) for r in range(cols)])
+        reduces.append(fabric.reduces)
+    for r in range(cols):
+        assert np.array_equal(results[0][r][0], results[1][r][0]) and np.array_equal(results[0][r][1], results[1][r][1]), r
+    if cols > 1:
+        assert reduces[0] == reduces[1] - 2, reduces          # the two trace-less iterations saved one all-reduce each
 
 
 @pytest.mark.parametrize('rows,cols', [(1, 2), (2, 4)])
