@@ -386,7 +386,7 @@ def test_vgg19_ranged_backward_fp32_at_1024_on_shared_forward_state():
 
 
 # ------------------------------------------------------------------------------ configs[2]: 2048^2, bf16, L-BFGS
-def test_vgg19_objective_bf16_at_2048_and_one_lbfgs_step():
+def test_vgg19_objective_bf16_at_2048():
     """Whole objective against the rounded-operand oracle.  Two correct bf16 implementations decorrelate to the bf16
     noise floor within a few layers (a 1e-6 fp32 difference moves ~2.5e-4 of a blob's elements across a bf16 rounding
     boundary, tests/test_gpu_bf16.py), hence the loss / cosine bars; the per-layer arithmetic is pinned tightly by
@@ -410,20 +410,10 @@ def test_vgg19_objective_bf16_at_2048_and_one_lbfgs_step():
     assert ferr['conv1_1'] <= 1e-6 and max(ferr.values()) <= 2e-2, ferr
     assert np.isclose(ld, lo, rtol=3e-3)
     assert cos >= 0.998 and vals['grad_rel_l2'] <= 8e-2
-    # one L-BFGS step from the same state (optimizers.py:62-77: first step = unit-RMS direction, two evaluations).  The oracle's
-    # first evaluation would repeat the one above at the same image with the same freshly captured norms (a minute of CPU time at
-    # this size): its optimizer is handed that result instead; the engine runs the whole step from a reset.
-    dev.reset()
-    assert cpu.optimizer.loss is None and not cpu.optimizer.pairs
-    cpu.optimizer.loss, cpu.optimizer.grad = lo, go.copy()
-    ic, tc = cpu.step()
-    idv, td = dev.step()
-    assert list(td) == list(tc)
-    mse = float(np.mean((idv - ic) ** 2))
-    report('bf16 vgg19 2048 one L-BFGS step', {'loss_rel': float(abs(td['loss'] - tc['loss']) / abs(tc['loss'])), 'image_mse': mse,
-                                               'moved_mse': float(np.mean((ic - images(2048)[2]) ** 2))})
-    assert np.isclose(td['loss'], tc['loss'], rtol=1e-2)
-    assert mse <= 0.02                      # the step moves every pixel by ~1 level (unit-RMS direction): MSE of the move ~1
+    # (Round 3 also took ONE L-BFGS step here against the oracle -- a second 30 s oracle evaluation at this size for a step whose
+    #  direction is the gradient just compared, normalised to unit RMS (optimizers.py:97-99).  The optimizer at this size is now checked
+    #  where it says more: bf16 against the fp32 engine over five L-BFGS steps at 1536 x 2048 and twenty at 768 x 1024 on a contracting
+    #  workload, and the engine's bf16 drift against the rounded-operand oracle's own over eleven steps, below.)
 
 
 # ------------------------------------------------------------------------------ bf16 feature path against the fp32 engine, over many steps

@@ -15,6 +15,17 @@ fw = [('conv1_1', 3, 64, 1), ('conv1_2', 64, 64, 1), ('conv2_1', 64, 128, 2), ('
       ('conv4_1', 256, 512, 8), ('conv4_2', 512, 512, 8), ('conv4_3', 512, 512, 8), ('conv4_4', 512, 512, 8),
       ('conv5_1', 512, 512, 16)]
 convs = [r for r in it if 'conv3x3' in r['Kernel_Name']]
+
+
+def wgs(r):
+    """workgroups of a launch: the grid may be two- or three-dimensional (rocprofv3 reports work-items per dimension)"""
+    n = 1
+    for ax in 'XYZ':
+        g, w = int(r.get('Grid_Size_' + ax, 1) or 1), int(r.get('Workgroup_Size_' + ax, 1) or 1)
+        n *= max(1, g // max(1, w))
+    return n
+
+
 names = [f[0] + ' fwd' for f in fw] + [f[0] + ' bwd' for f in reversed(fw)]
 specs = fw + list(reversed(fw))
 tot = totf = 0
@@ -26,7 +37,7 @@ for r, n, s in zip(convs, names, specs):
     totf += fl
     kn = r['Kernel_Name'].split('(')[0].replace('void st2::', '')[:34]
     print('%-12s %-34s wgs=%-6d %8.1f us %6.1f TF/s  vgpr=%s+%s lds=%s' % (
-        n, kn, int(r['Grid_Size_X']) // int(r['Workgroup_Size_X']), d, fl / d / 1e6, r['VGPR_Count'],
+        n, kn, wgs(r), d, fl / d / 1e6, r['VGPR_Count'],
         r['Accum_VGPR_Count'], r['LDS_Block_Size']))
 print('conv total %.1f us, %.1f TF/s' % (tot, totf / tot / 1e6))
 print('--- every kernel of the iteration (duration, gap to previous)')
