@@ -72,15 +72,25 @@ struct Conv16KArgs {
     unsigned in_bytes, w_bytes;
     // fused style term (data-gradient launches): out = mask(conv) + D' @ F, F = the bf16 copy of the blob this launch differentiates
     const unsigned short* s_in16; const unsigned short* s_wpack; int s_nch; unsigned s_in_bytes, s_w_bytes;
+    // UNPOOL builds (data-gradient launches directly below a max-pool): in16 is the POOLED diff [K/8][up_h][up_w][8] and up_amap the
+    // pool's arg-max map ([K/8][up_h][up_w][8] bytes: slot | positive << 2); the staged activation tile is expanded in LDS
+    const unsigned char* up_amap; int up_h, up_w;
 };
 
 // SB = true: ONE staging buffer instead of two.  A short reduction (K <= 128: two to eight chunks) never reaches the steady state
 // the double buffer is built for -- the workgroup waits for its first chunks at HBM latency with nothing to overlap -- so the
 // short-K launches trade the second buffer for occupancy: 39 KiB of LDS per workgroup, FOUR workgroups per CU, and one
 // workgroup's DMA wait runs under the other three's MFMAs.
-template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false>
+// UNPOOL = true (round 4; the double-buffered pipeline only): the launch differentiates the conv directly below a max-pool and reads
+// the POOLED diff instead of the full-resolution one maxpool_bwd_idx16_k would have written.  Every staged quad (8 channels of one
+// full-resolution pixel) is fetched from its pooling window's quad of the pooled diff -- the four pixels of a window fetch the same
+// 16 bytes, served by the caches -- and, once a chunk has landed, each lane passes the quads it fetched through the window's eight
+// arg-max bytes: a channel keeps its value iff its byte says "this position, maximum positive" (exactly maxpool_bwd_idx16_k's rule),
+// in LDS, before any wave reads operands.  Gone: that kernel, its full-resolution output and this launch's read of it.
+template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false, bool UNPOOL = false>
 __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 {
+    static_assert(!(SB && UNPOOL), "the unpooling build uses the double-buffered pipeline");
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = ROWS / WAVES_N;
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
@@ -117,17 +127,32 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, a.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in16, 0, a.in_bytes, 0x00020000);
 
-    unsigned ioff[I_PER_WAVE];
-#pragma unroll
-    for (int t = 0; t < I_PER_WAVE; ++t) {
-        const int f = (wave + 4 * t) * 64 + lane;                // quad index in the activation image
+    const unsigned pplane = UNPOOL ? (unsigned)a.up_h * a.up_w : 0u;      // quads per channel block of the pooled diff
+    auto full_res_offset = [&](int t, int ln) -> unsigned {      // byte offset of staged quad (wave + 4 t) * 64 + ln in a [blocks][H][W] quad tensor
+        const int f = (wave + 4 * t) * 64 + ln;                  // quad index in the activation image
         const int h = f / (IN_ROWS * PXW);
         const int rem = f - h * (IN_ROWS * PXW);
         const int rr = rem / PXW, col = rem - rr * PXW;
         const int gy = y0 - 1 + rr, gx = x0 - 1 + col;
         const bool ok = f < I_QUADS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        ioff[t] = ok ? ((unsigned)h * plane + (unsigned)gy * a.W + gx) * 16u : kOOB16;
+        return ok ? ((unsigned)h * plane + (unsigned)gy * a.W + gx) * 16u : kOOB16;
+    };
+    unsigned ioff[I_PER_WAVE];
+    unsigned up_here = 0;                                        // UNPOOL: 3 bits per staged quad: 4 | 2 (y & 1) | (x & 1) -- what the arg-max byte must say
+#pragma unroll
+    for (int t = 0; t < I_PER_WAVE; ++t) {
+        if constexpr (UNPOOL) {
+            const int f = (wave + 4 * t) * 64 + lane;
+            const int h = f / (IN_ROWS * PXW);
+            const int rem = f - h * (IN_ROWS * PXW);
+            const int rr = rem / PXW, col = rem - rr * PXW;
+            const int gy = y0 - 1 + rr, gx = x0 - 1 + col;
+            const bool ok = f < I_QUADS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            ioff[t] = ok ? ((unsigned)h * pplane + (unsigned)(gy >> 1) * a.up_w + (gx >> 1)) * 16u : kOOB16;
+            up_here |= (4u | (2u * (gy & 1)) | (gx & 1)) << (3 * t);
+        } else ioff[t] = full_res_offset(t, lane);
     }
+    static_assert(!UNPOOL || 3 * I_PER_WAVE <= 32, "the window positions of a lane's quads fit one register");
     unsigned woff[W_PER_WAVE];
 #pragma unroll
     for (int t = 0; t < W_PER_WAVE; ++t) {
@@ -148,13 +173,52 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             const int u = t - W_PER_WAVE;
             const int j = wave + 4 * u;
             if (I_INSTR % 4 == 0 || j < I_INSTR) {
-                const unsigned coff = (unsigned)ch * 2u * plane * 16u;
+                const unsigned coff = (unsigned)ch * 2u * (UNPOOL ? pplane : plane) * 16u;
                 const unsigned vo = ioff[u] == kOOB16 ? kOOB16 : ioff[u] + coff;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lptr_t)(dst + W_QUADS + j * 64), 16, vo, 0, 0, 0);
             }
         }
     };
-
+    // UNPOOL: the expansion of a staged chunk, by the lane that fetched each quad -- so it needs that lane's own loads back, not a
+    // barrier.  The arg-max bytes (8 per quad, from the caches: the four pixels of a window share them) are requested two MFMA steps
+    // ahead (unpool_prefetch); at the last step, the wave's pieces having landed (unpool_landed), each lane reads its quads back from
+    // LDS, keeps the channels whose byte says "this position, maximum positive" and writes them in place (unpool_quad); the chunk's
+    // barrier follows as in the plain build.  (Measured, 2048^2 bf16: the four launches cost 0.16 ms more and maxpool_bwd_idx16_k's
+    // 0.28 ms are gone; spreading the quads over the MFMAs of steps 6 and 7 instead was slower, +0.22 .. 0.33 ms.)
+    // Per 4 channels: t = (bytes ^ here) & 7 per byte is 0 iff kept; (t + 7) bit 3 = "not kept"; bytes 0/1 -> halves of two words.
+    uint2 mm[UNPOOL ? I_PER_WAVE : 1];
+    auto unpool_prefetch = [&](int ch) {
+        if constexpr (UNPOOL) {
+            const unsigned coff = (unsigned)ch * 2u * pplane * 8u;
+#pragma unroll
+            for (int u = 0; u < I_PER_WAVE; ++u) {
+                const bool live = (I_INSTR % 4 == 0 || wave + 4 * u < I_INSTR) && ioff[u] != kOOB16;
+                mm[u] = live ? *reinterpret_cast<const uint2*>(a.up_amap + (size_t)(ioff[u] >> 1) + coff) : make_uint2(0u, 0u);
+            }
+        }
+    };
+    auto unpool_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };      // this lane's DMA pieces of the chunk and its arg-max bytes
+    auto unpool_quad = [&](int u, int buf) {
+        if constexpr (UNPOOL) {
+            uint4* img = smem + buf * BUF_Q + W_QUADS;
+            const int j = wave + 4 * u;
+            if ((I_INSTR % 4 == 0 || j < I_INSTR) && ioff[u] != kOOB16) {          // (quads outside the image are zero already)
+                const unsigned here = ((up_here >> (3 * u)) & 7u) * 0x01010101u;
+                const uint4 d = img[j * 64 + lane];
+                auto keep = [&](unsigned bytes) {                // 0xff per byte whose low three bits equal `here`
+                    const unsigned t = (bytes ^ here) & 0x07070707u;
+                    return ((((t + 0x07070707u) >> 3) & 0x01010101u) ^ 0x01010101u) * 0xffu;
+                };
+                const unsigned k0 = keep(mm[u].x), k1 = keep(mm[u].y);
+                uint4 o;
+                o.x = d.x & __builtin_amdgcn_perm(0u, k0, 0x01010000u);
+                o.y = d.y & __builtin_amdgcn_perm(0u, k0, 0x03030202u);
+                o.z = d.z & __builtin_amdgcn_perm(0u, k1, 0x01010000u);
+                o.w = d.w & __builtin_amdgcn_perm(0u, k1, 0x03030202u);
+                img[j * 64 + lane] = o;
+            }
+        }
+    };
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -204,6 +268,11 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         }
     }
   } else {
+    if constexpr (UNPOOL) {
+        unpool_prefetch(0); unpool_landed();
+#pragma unroll
+        for (int u = 0; u < I_PER_WAVE; ++u) unpool_quad(u, 0);
+    }
     __syncthreads();
     fetch(smem, 0, av[0], bv[0]);
     for (int ch = 0; ch < a.nch; ++ch) {
@@ -225,8 +294,14 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 #pragma unroll
                             for (int pp = 0; pp < PPS; ++pp)
                                 if (s2 * PPS + pp < NPIECE) dma_piece(s2 * PPS + pp, ch + 1, cur ^ 1);
+                            if (UNPOOL && s2 == NSTEP - 3) unpool_prefetch(ch + 1);
                         }
                     } else if (more) {
+                        if constexpr (UNPOOL) {
+                            unpool_landed();
+#pragma unroll
+                            for (int u = 0; u < I_PER_WAVE; ++u) unpool_quad(u, cur ^ 1);
+                        }
                         __syncthreads();
                         fetch(next, 0, av[0], bv[0]);            // 9 % 3 == 0: the next chunk starts on set 0 again
                     }
@@ -303,13 +378,18 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         static_assert(SW_QUADS <= W_QUADS, "the style slab fits the weight region");
         const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.s_wpack, 0, a.s_w_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)a.s_in16, 0, a.s_in_bytes, 0x00020000);
+        unsigned soff[I_PER_WAVE];                               // the blob's own bf16 copy is full resolution (UNPOOL: ioff addresses the pooled diff)
+        int ln = lane;
+        if constexpr (UNPOOL) asm volatile("" : "+v"(ln));      // computed HERE: hoisted above the main loop they would live through it in scratch
+#pragma unroll
+        for (int u = 0; u < I_PER_WAVE; ++u) soff[u] = UNPOOL ? full_res_offset(u, ln) : ioff[u];
         auto s_dma = [&](int ch, int buf) {
             uint4* dst = smem + buf * BUF_Q;
 #pragma unroll
             for (int t = 0; t < (SW_INSTR + 3) / 4; ++t) {
                 const int i = wave + 4 * t;
                 if (SW_INSTR % 4 == 0 || i < SW_INSTR) {
-                    const int q = i * 64 + lane, r = q / BM, m = q - r * BM;
+                    const int q = i * 64 + ln, r = q / BM, m = q - r * BM;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)(dst + i * 64), 16, ((unsigned)(ch * 4 + r) * a.MPad + m0 + m) * 16u, 0, 0, 0);
                 }
             }
@@ -318,7 +398,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                 const int j = wave + 4 * u;
                 if (I_INSTR % 4 == 0 || j < I_INSTR) {
                     const unsigned coff = (unsigned)ch * 2u * plane * 16u;
-                    const unsigned vo = ioff[u] == kOOB16 ? kOOB16 : ioff[u] + coff;
+                    const unsigned vo = soff[u] == kOOB16 ? kOOB16 : soff[u] + coff;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)(dst + W_QUADS + j * 64), 16, vo, 0, 0, 0);
                 }
             }
@@ -492,6 +572,9 @@ ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x256, 64, 8, 1, 4, 2)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_128x128, 128, 4, 2, 2, 1)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x128, 64, 4, 1, 4, 3)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x512, 64, 16, 1, 4, 2)     // 4 rows per wave: twice the MFMA work per staged weight slab
+// data-gradient launches directly below a max-pool: the pooled diff + the arg-max map, expanded in the staged tile (conv16_body, UNPOOL)
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_unpool(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, true>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_unpool(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, true>(a); }
 // single staging buffer, three workgroups per CU (162 registers, 30 KiB of LDS each): the short-K launches (conv16_body, SB)
 __global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true>(a); }
 
@@ -514,6 +597,18 @@ static int conv16_pick_cfg(const Conv16Problem& p)
 // may this launch pool its own output (Conv16Problem::pool16 / pool32 / amap)?  Needs a tile configuration whose waves
 // hold two rows (0 and 1) and M % 8 == 0 (channel-blocked outputs).
 bool conv16_can_pool(const Conv16Problem& p) { return conv16_pick_cfg(p) != 2 && p.M % 8 == 0; }
+
+// may a data-gradient launch of this shape take the pooled diff + the pool's arg-max map (Conv16Problem::unpool_amap)?  The 64 x 512
+// and 64 x 256 pixel tiles have the build; even H and W (every window whole).  ST2_CONV16_UNPOOL=0: keep maxpool_bwd_idx16_k (read per call).
+bool conv16_can_unpool(const Conv16Problem& p)
+{
+    const char* e = getenv("ST2_CONV16_UNPOOL");
+    if (e && *e == '0') return false;
+    const char* sbe = getenv("ST2_CONV16_SB_MAXK");
+    if (sbe && *sbe && p.K <= atoi(sbe)) return false;
+    const int cfg = conv16_pick_cfg(p);
+    return (cfg == 3 || cfg == 0) && p.H % 2 == 0 && p.W % 2 == 0 && p.K % 16 == 0;      // whole windows, whole 16-channel chunks
+}
 
 hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
 {
@@ -538,7 +633,11 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     k.K = p.K; k.M = p.M; k.MPad = p.MPad; k.H = p.H; k.W = p.W;
     k.nch = (p.K + 15) / 16;
     k.tiles_x = (int)tx; k.tiles_y = (p.H + ROWS - 1) / ROWS; k.n_mtiles = p.MPad / BM; k.relu = p.relu;
-    const unsigned long long in_bytes = 16ull * ((p.K + 7) / 8) * p.H * p.W, w_bytes = 2ull * conv16_pack_elems(p.K, p.M);
+    const bool unpool = p.unpool_amap != nullptr;
+    if (unpool && (!conv16_can_unpool(p) || sb || pools)) return hipErrorInvalidValue;
+    k.up_amap = p.unpool_amap; k.up_h = p.H / 2; k.up_w = p.W / 2;
+    const unsigned long long in_bytes = 16ull * ((p.K + 7) / 8) * (unpool ? (unsigned long long)k.up_h * k.up_w : (unsigned long long)p.H * p.W),
+                             w_bytes = 2ull * conv16_pack_elems(p.K, p.M);
     const unsigned long long out_bytes = 4ull * p.M * p.H * p.W;
     if (in_bytes >= 0xfffffff0ull || w_bytes >= 0xfffffff0ull || out_bytes >= 0xfffffff0ull) return hipErrorInvalidValue;
     if (p.s_in16 || p.s_wpack16) {          // fused style term: a data-gradient launch whose output blob has M % 16 == 0 channels
@@ -551,6 +650,8 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     if (cfg == 0 && sb) conv3x3_mfma_bf16_64x256_sb<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    else if (cfg == 3 && unpool) conv3x3_mfma_bf16_64x512_unpool<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    else if (cfg == 0 && unpool) conv3x3_mfma_bf16_64x256_unpool<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else if (cfg == 3) conv3x3_mfma_bf16_64x512<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else if (cfg == 0) conv3x3_mfma_bf16_64x256<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
     else if (cfg == 1) conv3x3_mfma_bf16_128x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);

@@ -325,6 +325,7 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
         if (L.is_conv) {
             const double px = (double)a.h[i] * a.w[i];
             const bool small_m = !mask_src && conv_dgrad_smallM_ok(L.cout, L.cin);
+            if (small_m && pending_unpool) return fail(ST_ERR_STATE, "internal: an unpooling data gradient was planned for %s but the small-M kernel runs", L.name.c_str());
             const bool wino_bwd = !small_m && !(c->bf16 && conv16_ok(c, L.cout)) && c->wino && L.u_bwd && conv_wino_ok(L.cout, L.cin, a.h[i], a.w[i]);
             if (small_m && c->bf16 && L.w_raw_r) {
                 // bf16 feature path: this conv's operands are bf16 too -- the diff arrives as (or is packed into) a bf16 copy
@@ -368,8 +369,9 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
                 if (p.mask_src && !a.has32[below]) return fail(ST_ERR_STATE, "internal: mask blob %d missing", below);
                 if (lean && below16) p.out = nullptr;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
+                p.unpool_amap = pending_unpool; pending_unpool = nullptr;      // cur16 is the POOLED diff then (3/4 byte per pooled channel value more, 1.5 less per full one)
                 ProfScope ps(c, P_CONV_DGRAD_BF16, 2.0 * 9 * L.cin * L.cout * px + (fused ? 2.0 * L.cin * L.cin * px : 0.0),
-                             px * (2.0 * L.cout + (fused ? 2.0 : 0.0) * L.cin + (p.out ? 4.0 : 0.0) * L.cin + (p.out16 ? 2.0 : 0.0) * L.cin + (mask_src ? (p.mask16 ? 2.0 : 4.0) : 0.0) * L.cin));
+                             px * ((p.unpool_amap ? 0.75 : 2.0) * L.cout + (fused ? 2.0 : 0.0) * L.cin + (p.out ? 4.0 : 0.0) * L.cin + (p.out16 ? 2.0 : 0.0) * L.cin + (mask_src ? (p.mask16 ? 2.0 : 4.0) : 0.0) * L.cin));
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
                 cur16 = below16 ? dst16 : nullptr;
                 cur = p.out ? dst : nullptr;
@@ -399,6 +401,13 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
                 HIP_TRY(launch_pack_act16(cur, tmp16, C, hw_top, c->stream));
                 cur16 = tmp16;
                 dst16 = (cur16 == c->diff16A) ? c->diff16B : c->diff16A;
+            }
+            {   // ... inside the data gradient of the conv below when it has the build (conv16_body, UNPOOL): it stages the pooled diff and
+                // expands it in LDS through the map (maxpool_bwd_idx16_k, its full-resolution output and the conv's read of it are gone)
+                const Layer& P = c->topo[below - 1];
+                Conv16Problem q{};
+                q.K = P.cout; q.M = P.cin; q.MPad = conv_mpad(P.cin); q.H = a.h[below]; q.W = a.w[below];
+                if (conv16_ok(c, P.cout) && !conv_dgrad_smallM_ok(P.cout, P.cin) && conv16_can_unpool(q)) { pending_unpool = a.amap[i]; continue; }
             }
             ProfScope ps(c, P_POOL_BWD, 0, (double)C * (hw_top * 3.0 + hw * 2.0));
             HIP_TRY(launch_maxpool_bwd_idx16(cur16, a.amap[i], dst16, C, a.h[below], a.w[below], c->stream));

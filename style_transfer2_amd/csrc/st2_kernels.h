@@ -105,6 +105,9 @@ struct Conv16Problem {
     // data-gradient, optional: the style gradient of the blob this launch differentiates rides on the launch,
     //     out = mask(conv) + D' @ F        (D' = sw / norm * c2 * D as hi + lo bf16 terms: launch_style_fuse_pack; F = s_in16, M channels)
     const unsigned short* s_in16 = nullptr; const unsigned short* s_wpack16 = nullptr;
+    // data-gradient directly below a max-pool, optional (conv16_can_unpool): in16 is the POOLED diff [K/8][H/2][W/2][8] and unpool_amap
+    // the pool's arg-max map; the launch expands them in its staged tile (maxpool_bwd_idx16_k and its output are not needed)
+    const unsigned char* unpool_amap = nullptr;
 };
 // A-operand image of the scaled D for the fused style term: [M / 16][hl][k half][MPad] quads
 size_t style_fuse_pack_elems(int C, int MPad);
@@ -114,6 +117,7 @@ hipError_t launch_style_fuse_pack(const float* D, int ld, int C, int MPad, float
 int style_s2_trace_blocks(int C);
 hipError_t launch_style_s2_trace(const float* D, int ld, const float* A, int C, double n, float c2, float* partial, int* n_partial, hipStream_t s);
 bool conv16_can_pool(const Conv16Problem& p);
+bool conv16_can_unpool(const Conv16Problem& p);
 // dx16 = pool backward of dy16 through the arg-max map (all channel-blocked, C % 8 == 0), ReLU mask of the pooled-from blob included
 hipError_t launch_maxpool_bwd_idx16(const unsigned short* dy16, const unsigned char* amap, unsigned short* dx16, int C, int H, int W, hipStream_t s);
 size_t conv16_pack_elems(int K, int M);

@@ -312,3 +312,36 @@ def test_style_gradient_on_the_bf16_matrix_cores_matches_rounded_operand_oracle(
         ref32.set_weights(weights, p4)
         _, g32 = ref32.opfunc(ref32.input)
         assert 1e-5 < rel_l2(g_first, g32) < 5e-2
+
+
+@pytest.mark.parametrize('size', [(512, 512), (160, 224), (96, 132)])
+def test_unpooling_bf16_data_gradient_equals_the_separate_pool_backward_bit_for_bit(size, conv16_cfg, monkeypatch):
+    """The data gradient of the conv directly below a fused max-pool stages the POOLED bf16 diff and expands it in LDS through the
+    pool's arg-max map (conv16_body, UNPOOL; the 64x512 and 64x256 pixel tiles, whole windows); ST2_CONV16_UNPOOL=0 keeps
+    maxpool_bwd_idx16_k and its full-resolution output.  Routing only places values: objective, gradient and trajectories are the
+    same bits -- first evaluation (separate style kernels) and from the second on (style term fused into the very launches that
+    unpool: its operand is addressed at full resolution there).  Sizes: the auto-selected big tiles, forced tiles with clipped edges,
+    and one whose deeper levels are odd (no unpooling there)."""
+    if size == (512, 512) and conv16_cfg in ('1', '2'):
+        pytest.skip('one forced configuration is enough at the large size')
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('ST2_CONV16_UNPOOL', flag)
+        job = _bf16_job('bf16', size, LEAN_WEIGHTS, 'adam')
+        first = job.opfunc()
+        second = job.opfunc()
+        steps = [job.step() for _ in range(2)]
+        job.engine.profile_enable(True)
+        job.opfunc()
+        prof = job.engine.profile_read().get('maxpool_bwd', {}).get('launches', 0)
+        job.engine.profile_enable(False)
+        out[flag] = (first[0], first[1].copy(), second[0], second[1].copy(), [(t['loss'], i.copy()) for i, t in steps], prof)
+    a, b = out['1'], out['0']
+    assert a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and np.array_equal(a[3], b[3])
+    for (la, ia), (lb, ib) in zip(a[4], b[4]):
+        assert la == lb and np.array_equal(ia, ib)
+    if conv16_cfg in ('0', '3') and size != (96, 132):
+        assert a[5] == 0 and b[5] == 4, (a[5], b[5])          # every pool of the 16-layer chain is expanded inside the conv below it
+    elif conv16_cfg == 'auto' and size == (512, 512):
+        assert a[5] < b[5], (a[5], b[5])
