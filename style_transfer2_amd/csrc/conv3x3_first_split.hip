@@ -63,11 +63,19 @@ void pack_conv_first_split(const float* w /*Cout, Cin, 3, 3*/, const float* bias
 struct FirstSplitArgs {
     const float* x; const uint4* wpk; float* out; unsigned short* out16;
     int M, H, W, relu;
+    unsigned short* bits;                          // optional: one bit per output element, "the bf16 copy is non-zero" (Conv16Problem::bits_out's layout)
 };
 
 // two consecutive taps' 16-bit fields -> one dword of a B fragment
 __device__ __forceinline__ unsigned lo16_pair(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }   // {b.lo : a.lo}
 __device__ __forceinline__ unsigned hi16_pair(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // {b.hi : a.hi}
+
+// bit e of the result: 16-bit field e of (u0.x, u0.y, u1.x, u1.y) is non-zero (eight bf16 values -> one byte of a sign map)
+__device__ __forceinline__ unsigned nonzero_halves(uint2 u0, uint2 u1)
+{
+    auto two = [](unsigned w) { return ((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u); };
+    return two(u0.x) | (two(u0.y) << 2) | (two(u1.x) << 4) | (two(u1.y) << 6);
+}
 
 template <int FS_TH>
 __global__ __launch_bounds__(256) void conv3x3_first_split_k(const FirstSplitArgs a)
@@ -166,6 +174,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_split_k(const FirstSplitArg
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[ks], b1[ks], acc, 0, 0, 0);
             // C/D map: column = lane & 31 (the pixel), row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5) (the channel within the tile)
+            unsigned bits = 0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int mbase = mt * 32 + 4 * khalf + 16 * h;
@@ -187,6 +196,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_split_k(const FirstSplitArg
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { pk0[e] = (__bf16)v[e]; pk1[e] = (__bf16)v[4 + e]; }
                     const uint2 u0 = __builtin_bit_cast(uint2, pk0), u1 = __builtin_bit_cast(uint2, pk1);
+                    bits |= nonzero_halves(u0, u1) << (8 * h);
                     const auto sx = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
                     const auto sy = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
                     const int mq = mt * 32 + 16 * h + 8 * khalf;                       // first channel of this lane's quad
@@ -194,6 +204,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_split_k(const FirstSplitArg
                         *reinterpret_cast<uint4*>(a.out16 + ((size_t)(mq >> 3) * plane + pix) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
                 }
             }
+            if (a.bits && inside) a.bits[((size_t)mt * plane + pix) * 2 + khalf] = (unsigned short)bits;
         }
     }
 }
@@ -207,12 +218,12 @@ bool conv_first_split_ok(int Cin, int Cout, int H, int W)
 }
 
 hipError_t launch_conv3x3_first_split(const float* x, const unsigned short* wpk, float* out, unsigned short* out16,
-                                      int Cin, int Cout, int H, int W, int relu, hipStream_t s)
+                                      int Cin, int Cout, int H, int W, int relu, hipStream_t s, unsigned short* bits_out)
 {
-    if (!conv_first_split_ok(Cin, Cout, H, W) || (!out && !out16) || (reinterpret_cast<uintptr_t>(wpk) & 15) != 0 ||
+    if (!conv_first_split_ok(Cin, Cout, H, W) || (!out && !out16) || (bits_out && !out16) || (reinterpret_cast<uintptr_t>(wpk) & 15) != 0 ||
         (out16 && (reinterpret_cast<uintptr_t>(out16) & 15) != 0))
         return hipErrorInvalidValue;
-    FirstSplitArgs a{x, reinterpret_cast<const uint4*>(wpk), out, out16, Cout, H, W, relu};
+    FirstSplitArgs a{x, reinterpret_cast<const uint4*>(wpk), out, out16, Cout, H, W, relu, bits_out};
     // four rows per workgroup: measured at 2048^2 against 1 / 2 / 8 (0.267 / 0.217 / 0.233 ms against 0.211)
     const dim3 grid((W + FS_TW - 1) / FS_TW, (H + 3) / 4);
     conv3x3_first_split_k<4><<<grid, 256, 0, s>>>(a);

@@ -75,7 +75,24 @@ struct Conv16KArgs {
     // UNPOOL builds (data-gradient launches directly below a max-pool): in16 is the POOLED diff [K/8][up_h][up_w][8] and up_amap the
     // pool's arg-max map ([K/8][up_h][up_w][8] bytes: slot | positive << 2); the staged activation tile is expanded in LDS
     const unsigned char* up_amap; int up_h, up_w;
+    // sign maps (Conv16Problem::bits_out / mask_bits): [M / 32][H * W][2] 16-bit words in the accumulator layout
+    unsigned short* bits_out; const unsigned short* mask_bits;
 };
+
+// v if bit `bit` of `word` is set, else +0: the one-bit field sign-extended (v_bfe_i32: 0 or ~0) and-ed onto the value -- two VALU
+// operations and no condition register (128 selects in a row otherwise queue up on SGPR pairs and spill)
+__device__ __forceinline__ float keep_if_bit(float v, unsigned word, int bit)
+{
+    const int m = __builtin_amdgcn_sbfe((int)word, bit, 1);
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
+}
+
+// bit e of the result: 16-bit field e of (u0.x, u0.y, u1.x, u1.y) is non-zero (eight bf16 values -> one byte of a sign map)
+__device__ __forceinline__ unsigned nonzero_halves16(uint2 u0, uint2 u1)
+{
+    auto two = [](unsigned w) { return ((w & 0xffffu) ? 1u : 0u) | ((w >> 16) ? 2u : 0u); };
+    return two(u0.x) | (two(u0.y) << 2) | (two(u1.x) << 4) | (two(u1.y) << 6);
+}
 
 // SB = true: ONE staging buffer instead of two.  A short reduction (K <= 128: two to eight chunks) never reaches the steady state
 // the double buffer is built for -- the workgroup waits for its first chunks at HBM latency with nothing to overlap -- so the
@@ -87,10 +104,17 @@ struct Conv16KArgs {
 // 16 bytes, served by the caches -- and, once a chunk has landed, each lane passes the quads it fetched through the window's eight
 // arg-max bytes: a channel keeps its value iff its byte says "this position, maximum positive" (exactly maxpool_bwd_idx16_k's rule),
 // in LDS, before any wave reads operands.  Gone: that kernel, its full-resolution output and this launch's read of it.
-template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false, bool UNPOOL = false>
+// DG: which epilogue the build carries (round 4: one epilogue with every option of both directions ran out of registers).
+//   DG = false, "forward":        bias, ReLU, fp32 / bf16 outputs, the fused max-pool (pool16 / pool32 / amap), the sign map (bits_out)
+//   DG = true,  "data gradient":  ReLU mask of the blob below (mask_src / mask16 / mask_bits), inject, fp32 / bf16 outputs, the fused style term
+// (a launch with none of these options runs on the forward build)
+// MB (data-gradient builds): the ReLU mask comes as a sign map (mask_bits) -- the other two forms have their own build, for the same reason
+template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false, bool UNPOOL = false, bool DG = UNPOOL, bool MB = false>
 __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 {
+    static_assert(DG || !MB, "sign-map masks are a data-gradient option");
     static_assert(!(SB && UNPOOL), "the unpooling build uses the double-buffered pipeline");
+    static_assert(DG || !UNPOOL, "unpooling is a data-gradient option");
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = ROWS / WAVES_N;
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
@@ -320,9 +344,12 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     // the (wave-uniform) fast path of a tile that lies inside M.
     const int gx = x0 + l31;
     const bool colv = gx < a.W;
-    const bool fuse_style = a.s_nch > 0;                         // the ReLU mask is then applied in registers, before the style chunks
-    const bool has_bias = a.bias != nullptr, has_mask = a.mask_src != nullptr, has_inj = a.inject != nullptr, has_mask16 = a.mask16 != nullptr && !fuse_style;
-    const bool pooling = TN % 2 == 0 && (a.pool16 || a.pool32 || a.amap);
+    const bool fuse_style = DG && a.s_nch > 0;                   // the ReLU mask is then applied in registers, before the style chunks
+    constexpr bool has_bits = MB;                                // the ReLU mask as a sign map: 16 elements per 2-byte load (instead of mask16)
+    const bool has_bias = !DG && a.bias != nullptr, relu = !DG && a.relu, has_mask = DG && !MB && a.mask_src != nullptr, has_inj = DG && a.inject != nullptr,
+               has_mask16 = DG && !MB && a.mask16 != nullptr && !fuse_style;
+    const bool pooling = !DG && TN % 2 == 0 && (a.pool16 || a.pool32 || a.amap);
+    const bool bits_out = !DG && a.bits_out != nullptr;
     const bool full_m = m0 + BM <= a.M;                          // uniform: no channel of this tile is padding
     unsigned pixj[TN];
     bool livej[TN];
@@ -348,30 +375,57 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                     mk[h][j][g] = *reinterpret_cast<const uint2*>(a.mask16 + ((size_t)(mg >> 3) * plane + pixj[j]) * 8 + (mg & 7));
                 }
     };
+    // sign maps go through buffer resources: one offset register per access instead of a 64-bit address (this epilogue has none to spare);
+    // 4 bytes per (32-channel group, pixel) -- below 2^32 with the output's own byte count
+    const unsigned bits_bytes = (unsigned)(a.M >> 5) * plane * 4u;
+    const __amdgpu_buffer_rsrc_t rs_mb = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask_bits, 0, has_bits ? bits_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bits_out, 0, bits_out ? bits_bytes : 0u, 0x00020000);
+    auto load_bits = [&](int i, unsigned (&mb)[TN]) {            // word j: bit 8 h + e keeps acc[i][j][8 h + e]  (a padding group reads out of range: 0)
+        const unsigned blk = (unsigned)(m0 + wave_m * (TM * 32) + i * 32) >> 5;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mb[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_mb, pixj[j] * 4u + 2u * khalf, blk * plane * 4u, 0);
+    };
     if (fuse_style) {
         // ---- fused style gradient (worker.py:262-269 behind the ranged backward of :100-106): this launch's output is the diff of a
         // style layer's blob, diff = mask(dgrad) + sw / norm * c2 * (D @ F).  The conv sum is masked in registers, then C / 16 more
         // chunks accumulate D' @ F on top: A = D' = D scaled, as hi + lo bf16 terms (slab [hl][k half][BM] per 16 channels, packed by
         // style16_pack_d_scaled_k), B = the blob's own bf16 copy, staged as the conv's activation tile (its centre tap is the pixel).
         // Saves the separate style-gradient kernel, its fp32 output and this epilogue's read of it.
-        if (a.mask16) {
+        if (has_bits) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                uint2 mk[2][TN][2];
-                load_masks(i, mk);
+                unsigned mb[TN];
+                load_bits(i, mb);
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = keep_if_bit(acc[i][j][e], mb[j], e);
+            }
+        } else if (!MB && a.mask16) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                    // (one half of the 32-channel group at a time: 16 registers of masks, not 32)
+                    uint2 mk[TN][2];
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
-                            const uint2 m2 = mk[h][j][g];
+                            const int mg0 = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h + 8 * g;
+                            const int mg = mg0 < a.M ? mg0 : 0;
+                            mk[j][g] = *reinterpret_cast<const uint2*>(a.mask16 + ((size_t)(mg >> 3) * plane + pixj[j]) * 8 + (mg & 7));
+                        }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const uint2 m2 = mk[j][g];
                             acc[i][j][8 * h + 4 * g + 0] = (m2.x & 0xffffu) ? acc[i][j][8 * h + 4 * g + 0] : 0.0f;
                             acc[i][j][8 * h + 4 * g + 1] = (m2.x >> 16) ? acc[i][j][8 * h + 4 * g + 1] : 0.0f;
                             acc[i][j][8 * h + 4 * g + 2] = (m2.y & 0xffffu) ? acc[i][j][8 * h + 4 * g + 2] : 0.0f;
                             acc[i][j][8 * h + 4 * g + 3] = (m2.y >> 16) ? acc[i][j][8 * h + 4 * g + 3] : 0.0f;
                         }
-            }
+                }
         }
         constexpr int SW_QUADS = 4 * BM;                         // [hl][k half][BM]
         constexpr int SW_INSTR = SW_QUADS / 64;
@@ -440,6 +494,11 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             if (!MK_ALL && has_mask16) load_masks(i, mk16[0]);
+            unsigned mbits[TN];
+            if (has_bits && !fuse_style) load_bits(i, mbits);
+            unsigned obits[TN];                                  // bits_out: word (i, j) of this lane, filled by both h
+#pragma unroll
+            for (int j = 0; j < TN; ++j) obits[j] = 0u;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int mbase = m0 + wave_m * (TM * 32) + i * 32 + 4 * khalf + 16 * h;
@@ -462,11 +521,14 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                         off[e] = (unsigned)((FULL || m < a.M) ? m : a.M - 1) * plane + pix;
                         v[j][e] = acc[i][j][8 * h + e] + bs[e];
                     }
-                    if (a.relu) {
+                    if (relu) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[j][e] = v[j][e] > 0.0f ? v[j][e] : 0.0f;
                     }
-                    if (has_mask16) {
+                    if (has_bits && !fuse_style) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[j][e] = keep_if_bit(v[j][e], mbits[j], 8 * h + e);
+                    } else if (has_mask16) {
                         // the blob below is post-ReLU (>= 0): its bf16 copy is non-zero exactly where it is positive
 #pragma unroll
                         for (int g = 0; g < 2; ++g) {
@@ -503,6 +565,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { pk0[e] = (__bf16)v[j][e]; pk1[e] = (__bf16)v[j][4 + e]; }
                         const uint2 u0 = __builtin_bit_cast(uint2, pk0), u1 = __builtin_bit_cast(uint2, pk1);
+                        if (bits_out) obits[j] |= nonzero_halves16(u0, u1) << (8 * h);
                         const auto sx = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
                         const auto sy = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
                         const int mq = mbase - 4 * khalf + 8 * khalf;                  // first channel of this lane's quad
@@ -561,22 +624,34 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                     }
                 }
             }
+            if (bits_out) {                                      // (M % 32 == 0 on this path: the 32-channel group is whole or padding -- out of range, dropped)
+                const unsigned blk = (unsigned)(m0 + wave_m * (TM * 32) + i * 32) >> 5;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    if (livej[j]) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)obits[j], rs_ob, pixj[j] * 4u + 2u * khalf, blk * plane * 4u, 0);
+            }
         }
     };
     if (full_m) tile_out(std::true_type{}); else tile_out(std::false_type{});
 }
 
 #define ST2_CONV16_KERNEL(NAME, BM, ROWS, WM, WN, WPE) \
-    __global__ __launch_bounds__(NT, WPE) void NAME(const Conv16KArgs a) { conv16_body<BM, ROWS, WM, WN>(a); }
+    __global__ __launch_bounds__(NT, WPE) void NAME(const Conv16KArgs a) { conv16_body<BM, ROWS, WM, WN, false, false, false>(a); } \
+    __global__ __launch_bounds__(NT, WPE) void NAME##_dg(const Conv16KArgs a) { conv16_body<BM, ROWS, WM, WN, false, false, true>(a); } \
+    __global__ __launch_bounds__(NT, WPE) void NAME##_dgb(const Conv16KArgs a) { conv16_body<BM, ROWS, WM, WN, false, false, true, true>(a); }
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x256, 64, 8, 1, 4, 2)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_128x128, 128, 4, 2, 2, 1)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x128, 64, 4, 1, 4, 3)
 ST2_CONV16_KERNEL(conv3x3_mfma_bf16_64x512, 64, 16, 1, 4, 2)     // 4 rows per wave: twice the MFMA work per staged weight slab
 // data-gradient launches directly below a max-pool: the pooled diff + the arg-max map, expanded in the staged tile (conv16_body, UNPOOL)
-__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_unpool(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, true>(a); }
-__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_unpool(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, true>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_unpool(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, true, true>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_unpool(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, true, true>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_unpool_b(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, true, true, true>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_unpool_b(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, true, true, true>(a); }
 // single staging buffer, three workgroups per CU (162 registers, 30 KiB of LDS each): the short-K launches (conv16_body, SB)
-__global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true>(a); }
+__global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, false>(a); }
+__global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb_dg(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, true>(a); }
+__global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb_dgb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, true, true>(a); }
 
 static int conv16_pick_cfg(const Conv16Problem& p)
 {
@@ -633,6 +708,9 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     k.K = p.K; k.M = p.M; k.MPad = p.MPad; k.H = p.H; k.W = p.W;
     k.nch = (p.K + 15) / 16;
     k.tiles_x = (int)tx; k.tiles_y = (p.H + ROWS - 1) / ROWS; k.n_mtiles = p.MPad / BM; k.relu = p.relu;
+    if ((p.bits_out || p.mask_bits) && p.M % 32 != 0) return hipErrorInvalidValue;
+    if (p.bits_out && (!p.out16 || (reinterpret_cast<uintptr_t>(p.bits_out) & 1) != 0)) return hipErrorInvalidValue;
+    k.bits_out = p.bits_out; k.mask_bits = p.mask_bits;
     const bool unpool = p.unpool_amap != nullptr;
     if (unpool && (!conv16_can_unpool(p) || sb || pools)) return hipErrorInvalidValue;
     k.up_amap = p.unpool_amap; k.up_h = p.H / 2; k.up_w = p.W / 2;
@@ -649,13 +727,21 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     k.in_bytes = (unsigned)in_bytes; k.w_bytes = (unsigned)w_bytes;
     const long long nblk = (long long)k.tiles_x * k.tiles_y * k.n_mtiles;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (cfg == 0 && sb) conv3x3_mfma_bf16_64x256_sb<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
-    else if (cfg == 3 && unpool) conv3x3_mfma_bf16_64x512_unpool<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
-    else if (cfg == 0 && unpool) conv3x3_mfma_bf16_64x256_unpool<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
-    else if (cfg == 3) conv3x3_mfma_bf16_64x512<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
-    else if (cfg == 0) conv3x3_mfma_bf16_64x256<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
-    else if (cfg == 1) conv3x3_mfma_bf16_128x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
-    else conv3x3_mfma_bf16_64x128<<<dim3((unsigned)nblk), dim3(NT), 0, s>>>(k);
+    // which epilogue: the data-gradient build iff the launch uses one of its options; both directions' options together have no build
+    const bool dg = p.mask_src || p.mask16 || p.mask_bits || p.inject || p.s_in16 || unpool;
+    if (dg && (p.bias || p.relu || pools || p.bits_out)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)nblk), block(NT);
+    const bool mb = p.mask_bits != nullptr;
+    if (mb && (p.mask_src || p.mask16)) return hipErrorInvalidValue;            // one form of the mask per launch
+#define ST2_CONV16_LAUNCH3(NAME) do { if (mb) NAME##_dgb<<<grid, block, 0, s>>>(k); else if (dg) NAME##_dg<<<grid, block, 0, s>>>(k); else NAME<<<grid, block, 0, s>>>(k); } while (0)
+    if (cfg == 0 && sb) ST2_CONV16_LAUNCH3(conv3x3_mfma_bf16_64x256_sb);
+    else if (cfg == 3 && unpool) { if (mb) conv3x3_mfma_bf16_64x512_unpool_b<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x512_unpool<<<grid, block, 0, s>>>(k); }
+    else if (cfg == 0 && unpool) { if (mb) conv3x3_mfma_bf16_64x256_unpool_b<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x256_unpool<<<grid, block, 0, s>>>(k); }
+    else if (cfg == 3) ST2_CONV16_LAUNCH3(conv3x3_mfma_bf16_64x512);
+    else if (cfg == 0) ST2_CONV16_LAUNCH3(conv3x3_mfma_bf16_64x256);
+    else if (cfg == 1) ST2_CONV16_LAUNCH3(conv3x3_mfma_bf16_128x128);
+    else ST2_CONV16_LAUNCH3(conv3x3_mfma_bf16_64x128);
+#undef ST2_CONV16_LAUNCH3
     return hipGetLastError();
 }
 

@@ -91,6 +91,8 @@ void act_free(ActSet& a)
     for (size_t i = 1; i < a.data.size(); ++i) dfree(a.data[i]);
     for (size_t i = 0; i < a.data16.size(); ++i) dfree16(a.data16[i]);
     for (size_t i = 0; i < a.amap.size(); ++i) if (a.amap[i]) { (void)hipFree(a.amap[i]); a.amap[i] = nullptr; }
+    for (size_t i = 0; i < a.bits.size(); ++i) dfree16(a.bits[i]);
+    a.bits.clear();
     a.data.clear();
     a.data16.clear();
     a.amap.clear();
@@ -108,6 +110,8 @@ int act_ensure(st_ctx* c, ActSet& a, int H, int W)
     a.amap.assign(c->nb, nullptr);
     a.has32.assign(c->nb, 0);
     a.amap_ok.assign(c->nb, 0);
+    a.bits.assign(c->nb, nullptr);
+    a.bits_ok.assign(c->nb, 0);
     for (int i = 1; i < c->nb; ++i) ST_TRY(dmalloc(&a.data[i], (size_t)a.C[i] * a.h[i] * a.w[i]));
     a.H = H; a.W = W;
     return ST_OK;
@@ -155,8 +159,10 @@ bool style_fuse_ok(const st_ctx* c, const ActSet& a, int b, int last)
 int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
 {
     a.data[0] = const_cast<float*>(x);
-    a.has32.assign(c->nb, 0); a.amap_ok.assign(c->nb, 0);
+    a.has32.assign(c->nb, 0); a.amap_ok.assign(c->nb, 0); a.bits_ok.assign(c->nb, 0);
     a.has32[0] = 1;
+    const char* be = getenv("ST2_MASK_BITS");          // =0: the data gradients mask with the bf16 copies (read per forward: the tests compare both)
+    const bool want_bits = lean && c->bf16 && !(be && *be == '0');
     int pooled_by_conv = -1;
     for (int i = 1; i <= last; ++i) {
         const Layer& L = c->topo[i - 1];
@@ -171,6 +177,10 @@ int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
                 for (const ActiveLayer& al : c->active) if (al.blob == i && al.s) next16 = true;
             if (next16 && !a.data16[i]) ST_TRY(dmalloc16(&a.data16[i], act16_elems(a.C[i], (size_t)a.h[i] * a.w[i])));
             a.has32[i] = 1;
+            // lean: the data gradient of the bf16 conv above masks with blob i -- through a sign map (1 bit per element, written by
+            // this launch's epilogue) instead of the bf16 copy (16 bits)
+            const bool bits_i = want_bits && conv_next16 && L.cout % 32 == 0;
+            if (bits_i && !a.bits[i]) ST_TRY(dmalloc16(&a.bits[i], conv16_bits_elems(a.C[i], (size_t)a.h[i] * a.w[i])));
             if (c->bf16 && conv16_ok(c, L.cin) && a.data16[i - 1]) {
                 Conv16Problem p{};
                 p.in16 = a.data16[i - 1]; p.wpack16 = L.w16_fwd; p.bias = L.bias; p.out = a.data[i];
@@ -199,6 +209,7 @@ int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
                         bytes = px * (2.0 * L.cin + 2.0 * L.cout);
                     }
                 }
+                if (bits_i && p.out16) { p.bits_out = a.bits[i]; a.bits_ok[i] = 1; bytes += px * L.cout / 8.0; }
                 ProfScope ps(c, P_CONV_FWD_BF16, 2.0 * 9 * L.cin * L.cout * px, bytes);
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
             } else {
@@ -233,8 +244,11 @@ int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
                          // lean: conv1_1's fp32 blob is written only if something reads it (conv1_2, the ReLU mask and a style term take the copy)
                          if (lean && packed && conv_next16 && i < last && !blob_needs32(c, a, i)) { p.out = nullptr; a.has32[i] = 0; }
                          // bf16 path: the image keeps its fp32 precision (three-way bf16 split, six partial products on the bf16 matrix cores)
-                         if (c->bf16 && L.w_split && conv_first_split_ok(p.K, p.M, p.H, p.W))
-                             HIP_TRY(launch_conv3x3_first_split(p.in, L.w_split, p.out, p.out16, p.K, p.M, p.H, p.W, p.relu, c->stream));
+                         if (c->bf16 && L.w_split && conv_first_split_ok(p.K, p.M, p.H, p.W)) {
+                             unsigned short* bits = (bits_i && p.out16) ? a.bits[i] : nullptr;
+                             HIP_TRY(launch_conv3x3_first_split(p.in, L.w_split, p.out, p.out16, p.K, p.M, p.H, p.W, p.relu, c->stream, bits));
+                             if (bits) a.bits_ok[i] = 1;
+                         }
                          else HIP_TRY(launch_conv3x3(p, c->stream)); } }
                 if (next16 && !packed) { ProfScope ps(c, P_MISC, 0, px * 6.0 * L.cout); HIP_TRY(launch_pack_act16(a.data[i], a.data16[i], a.C[i], (size_t)a.h[i] * a.w[i], c->stream)); }
             }
@@ -361,17 +375,19 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
                 p.in16 = cur16; p.wpack16 = L.w16_bwd; p.bias = nullptr; p.out = dst; p.out16 = below16 ? dst16 : nullptr;
                 p.mask_src = mask_src; p.inject = inject;
                 if (lean && mask_src && a.data16[below]) { p.mask16 = a.data16[below]; p.mask_src = nullptr; }
+                const bool bits_below = lean && mask_src && a.bits_ok[below];
                 const bool fused = below >= 1 && (size_t)below < c->sf_w.size() && c->sf_w[below] != nullptr;
                 if (fused) {                // the style gradient of blob `below` rides on this launch: out = mask(conv) + D' @ F (+ inject)
                     p.s_in16 = c->sf_in[below]; p.s_wpack16 = c->sf_w[below];
                     if (mask_src) { p.mask16 = a.data16[below]; p.mask_src = nullptr; }      // the mask is applied in registers, from the bf16 copy
                 }
+                if (bits_below) { p.mask_bits = a.bits[below]; p.mask16 = nullptr; p.mask_src = nullptr; }      // ... or from the blob's sign map
                 if (p.mask_src && !a.has32[below]) return fail(ST_ERR_STATE, "internal: mask blob %d missing", below);
                 if (lean && below16) p.out = nullptr;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
                 p.unpool_amap = pending_unpool; pending_unpool = nullptr;      // cur16 is the POOLED diff then (3/4 byte per pooled channel value more, 1.5 less per full one)
                 ProfScope ps(c, P_CONV_DGRAD_BF16, 2.0 * 9 * L.cin * L.cout * px + (fused ? 2.0 * L.cin * L.cin * px : 0.0),
-                             px * ((p.unpool_amap ? 0.75 : 2.0) * L.cout + (fused ? 2.0 : 0.0) * L.cin + (p.out ? 4.0 : 0.0) * L.cin + (p.out16 ? 2.0 : 0.0) * L.cin + (mask_src ? (p.mask16 ? 2.0 : 4.0) : 0.0) * L.cin));
+                             px * ((p.unpool_amap ? 0.75 : 2.0) * L.cout + (fused ? 2.0 : 0.0) * L.cin + (p.out ? 4.0 : 0.0) * L.cin + (p.out16 ? 2.0 : 0.0) * L.cin + (mask_src ? (p.mask_bits ? 0.125 : p.mask16 ? 2.0 : 4.0) : 0.0) * L.cin));
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
                 cur16 = below16 ? dst16 : nullptr;
                 cur = p.out ? dst : nullptr;

@@ -58,6 +58,8 @@ struct ActSet {                    // activations of one forward geometry
     std::vector<unsigned short*> data16;   // bf16 channel-blocked copies of the blobs that feed a bf16 conv
     std::vector<unsigned char*> amap;      // lean bf16 path: arg-max maps of the pools fused into the producing conv
     std::vector<char> has32, amap_ok;      // per blob: fp32 copy / arg-max map written by the last forward
+    std::vector<unsigned short*> bits;     // bf16 lean flow: sign map of a conv blob that feeds a bf16 conv (Conv16Problem::bits_out) ...
+    std::vector<char> bits_ok;             // ... written by the last forward: the data gradient above masks with it instead of the bf16 copy
     int valid_to = -1;
 };
 

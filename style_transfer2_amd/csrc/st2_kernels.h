@@ -79,7 +79,7 @@ size_t conv_first_split_pack_elems(int Cout);
 void pack_conv_first_split(const float* w /*Cout, Cin, 3, 3*/, const float* bias /*Cout or nullptr*/, int Cout, int Cin, unsigned short* dst);
 bool conv_first_split_ok(int Cin, int Cout, int H, int W);
 hipError_t launch_conv3x3_first_split(const float* x, const unsigned short* wpk, float* out, unsigned short* out16,
-                                      int Cin, int Cout, int H, int W, int relu, hipStream_t s);
+                                      int Cin, int Cout, int H, int W, int relu, hipStream_t s, unsigned short* bits_out = nullptr);
 bool conv_dgrad_smallM_ok(int Cout, int Cin);
 hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* dx, const float* inject,
                                        int Cout, int Cin, int H, int W, hipStream_t s);
@@ -108,7 +108,13 @@ struct Conv16Problem {
     // data-gradient directly below a max-pool, optional (conv16_can_unpool): in16 is the POOLED diff [K/8][H/2][W/2][8] and unpool_amap
     // the pool's arg-max map; the launch expands them in its staged tile (maxpool_bwd_idx16_k and its output are not needed)
     const unsigned char* unpool_amap = nullptr;
+    // one bit per element of a post-ReLU blob, "its bf16 copy is non-zero", in the accumulator layout of the 32 x 32 MFMA tile:
+    //     [M / 32][H * W][2] 16-bit words; word (blk, pixel, half), bit 8 h + e  <->  channel 32 blk + 4 half + 16 h + (e & 3) + 8 (e >> 2)
+    // (conv16_bits_elems words, M % 32 == 0).  bits_out: written by a forward launch next to out16; mask_bits: read by the data
+    // gradient instead of mask16 -- 1/16 of its bytes, one 2-byte load per 16 elements instead of two 8-byte ones
+    unsigned short* bits_out = nullptr; const unsigned short* mask_bits = nullptr;
 };
+inline size_t conv16_bits_elems(int M, size_t hw) { return (size_t)(M / 32) * hw * 2; }
 // A-operand image of the scaled D for the fused style term: [M / 16][hl][k half][MPad] quads
 size_t style_fuse_pack_elems(int C, int MPad);
 hipError_t launch_style_fuse_pack(const float* D, int ld, int C, int MPad, float c2, float sw, const float* norm, unsigned short* A16, hipStream_t s);
