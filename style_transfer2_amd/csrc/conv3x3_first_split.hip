@@ -204,7 +204,10 @@ __global__ __launch_bounds__(256) void conv3x3_first_split_k(const FirstSplitArg
                         *reinterpret_cast<uint4*>(a.out16 + ((size_t)(mq >> 3) * plane + pix) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
                 }
             }
-            if (a.bits && inside) a.bits[((size_t)mt * plane + pix) * 2 + khalf] = (unsigned short)bits;
+            if (a.bits) {                                            // lane ^ 32 holds the other 16-bit word of the same pixel: one dword store per pixel
+                const auto sw = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+                if (inside && !khalf) reinterpret_cast<unsigned*>(a.bits)[(size_t)mt * plane + pix] = bits | (sw[1] << 16);
+            }
         }
     }
 }
@@ -220,7 +223,7 @@ bool conv_first_split_ok(int Cin, int Cout, int H, int W)
 hipError_t launch_conv3x3_first_split(const float* x, const unsigned short* wpk, float* out, unsigned short* out16,
                                       int Cin, int Cout, int H, int W, int relu, hipStream_t s, unsigned short* bits_out)
 {
-    if (!conv_first_split_ok(Cin, Cout, H, W) || (!out && !out16) || (bits_out && !out16) || (reinterpret_cast<uintptr_t>(wpk) & 15) != 0 ||
+    if (!conv_first_split_ok(Cin, Cout, H, W) || (!out && !out16) || (bits_out && (!out16 || (reinterpret_cast<uintptr_t>(bits_out) & 3) != 0)) || (reinterpret_cast<uintptr_t>(wpk) & 15) != 0 ||
         (out16 && (reinterpret_cast<uintptr_t>(out16) & 15) != 0))
         return hipErrorInvalidValue;
     FirstSplitArgs a{x, reinterpret_cast<const uint4*>(wpk), out, out16, Cout, H, W, relu, bits_out};

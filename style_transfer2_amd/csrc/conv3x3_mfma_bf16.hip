@@ -627,8 +627,10 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             if (bits_out) {                                      // (M % 32 == 0 on this path: the 32-channel group is whole or padding -- out of range, dropped)
                 const unsigned blk = (unsigned)(m0 + wave_m * (TM * 32) + i * 32) >> 5;
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    if (livej[j]) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)obits[j], rs_ob, pixj[j] * 4u + 2u * khalf, blk * plane * 4u, 0);
+                for (int j = 0; j < TN; ++j) {                   // lane ^ 32 holds the other 16-bit word of the same pixel: one dword store per pixel
+                    const auto sw = __builtin_amdgcn_permlane32_swap(obits[j], obits[j], false, false);
+                    if (livej[j] && !khalf) __builtin_amdgcn_raw_buffer_store_b32(obits[j] | (sw[1] << 16), rs_ob, pixj[j] * 4u, blk * plane * 4u, 0);
+                }
             }
         }
     };
@@ -681,6 +683,11 @@ bool conv16_can_unpool(const Conv16Problem& p)
     if (e && *e == '0') return false;
     const char* sbe = getenv("ST2_CONV16_SB_MAXK");
     if (sbe && *sbe && p.K <= atoi(sbe)) return false;
+    // ... and K <= 128 (ST2_CONV16_UNPOOL_MAXK): the expansion costs the launch about as much per pooled element as the separate kernel
+    // did, which pays where that kernel's full-resolution output was the expense -- measured at 2048^2: conv1_2 -145 + 0 us,
+    // conv2_2 -73 + 12, conv3_4 -39 + 32, conv4_4 -24 + 33
+    const char* mk = getenv("ST2_CONV16_UNPOOL_MAXK");
+    if (p.K > (mk && *mk ? atoi(mk) : 128)) return false;
     const int cfg = conv16_pick_cfg(p);
     return (cfg == 3 || cfg == 0) && p.H % 2 == 0 && p.W % 2 == 0 && p.K % 16 == 0;      // whole windows, whole 16-channel chunks
 }
@@ -709,7 +716,7 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     k.nch = (p.K + 15) / 16;
     k.tiles_x = (int)tx; k.tiles_y = (p.H + ROWS - 1) / ROWS; k.n_mtiles = p.MPad / BM; k.relu = p.relu;
     if ((p.bits_out || p.mask_bits) && p.M % 32 != 0) return hipErrorInvalidValue;
-    if (p.bits_out && (!p.out16 || (reinterpret_cast<uintptr_t>(p.bits_out) & 1) != 0)) return hipErrorInvalidValue;
+    if (p.bits_out && (!p.out16 || (reinterpret_cast<uintptr_t>(p.bits_out) & 3) != 0)) return hipErrorInvalidValue;
     k.bits_out = p.bits_out; k.mask_bits = p.mask_bits;
     const bool unpool = p.unpool_amap != nullptr;
     if (unpool && (!conv16_can_unpool(p) || sb || pools)) return hipErrorInvalidValue;

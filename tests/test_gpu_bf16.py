@@ -325,6 +325,7 @@ def test_unpooling_bf16_data_gradient_equals_the_separate_pool_backward_bit_for_
     if size == (512, 512) and conv16_cfg in ('1', '2'):
         pytest.skip('one forced configuration is enough at the large size')
     out = {}
+    monkeypatch.setenv('ST2_CONV16_UNPOOL_MAXK', '512')        # (default 128: deeper, the separate kernel is as cheap; here every pool is expanded)
     for flag in ('1', '0'):
         monkeypatch.setenv('ST2_CONV16_UNPOOL', flag)
         job = _bf16_job('bf16', size, LEAN_WEIGHTS, 'adam')
