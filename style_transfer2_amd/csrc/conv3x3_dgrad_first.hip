@@ -180,6 +180,94 @@ __global__ __launch_bounds__(256) void conv3x3_dgrad_first_bf16(const uint4* __r
     dgrad_first_gather<M>(z_s, dx, inject, x0, y0, H, W);
 }
 
+// bf16, Cout = 64 (round 4): the same sums in the same order (bit-identical to conv3x3_dgrad_first_bf16), laid out for the memory
+// system.  The tile kernel above reads its halo tile (1.33x the diff), computes, stores and exits -- 16384 short-lived workgroups
+// at 2048^2, 2.5 TB/s.  Here a workgroup owns a COLUMN STRIP, 126 output pixels wide (128 with the halo: one 32-pixel MFMA column
+// group per wave), and walks down it row by row: a row of the diff is read once (no vertical halo: Z rows stay in a four-slot LDS
+// ring until the three output rows that need them are done), its 16-byte quads ARE the B fragments (4 per lane and row, the rows
+// r + 1 .. r + 4 under way while row r is multiplied), four MFMAs make the row's Z[27][128], one barrier, and 252 threads add the
+// 27 shifted terms of output row r - 1.  Per row and workgroup: 16 KB of diff in, 1.5 KB out; the strips x segments grid is sized
+// to be resident at once (two workgroups per CU, 128 KB of loads in flight per CU).
+constexpr int DS_OW = 126, DS_HW = 128, DS_ZS = DS_HW + 1, DS_SLOTS = 4, DS_DEPTH = 4;
+
+template <int M>
+__global__ __launch_bounds__(256, 2) void conv3x3_dgrad_first_bf16_strip(const uint4* __restrict__ dy16, const float* __restrict__ w,
+                                                                         float* __restrict__ dx, const float* __restrict__ inject,
+                                                                         int H, int W, int seg, unsigned dy_bytes)
+{
+    __shared__ float z_s[DS_SLOTS][DF_ROWS][DS_ZS];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * DS_OW, y0 = blockIdx.y * seg;
+    const int nq = min(seg, H - y0) + 2;                     // halo rows of this segment: gy = y0 - 1 + q
+    const unsigned plane = (unsigned)H * W;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dy16, 0, dy_bytes, 0x00020000);
+    const int gx = x0 - 1 + 32 * wave + l31;
+    const bool colok = gx >= 0 && gx < W;
+    // A fragments (rows = the 9 M (m, tap) pairs, K = 16 channels per step): registers for the life of the workgroup
+    const int r = l31, m_r = r / 9, tap_r = r - 9 * m_r;
+    df_bf16x8 a[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cl = 16 * ks + 8 * khalf + j;
+            a[ks][j] = (__bf16)(r < 9 * M ? w[(cl * M + m_r) * 9 + tap_r] : 0.f);          // exact: w is bf16-representable
+        }
+    auto load_row = [&](int q, uint4 (&b)[4]) {              // (an offset beyond the tensor reads zeros: rows / columns outside the image)
+        const int gy = y0 - 1 + q;
+        const bool ok = colok && gy >= 0 && gy < H && q < nq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const unsigned off = ok ? ((unsigned)(2 * ks + khalf) * plane + (unsigned)gy * W + gx) * 16u : 0xfffffff0u;
+            b[ks] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+        }
+    };
+    uint4 b[DS_DEPTH][4];
+#pragma unroll
+    for (int u = 0; u < DS_DEPTH; ++u) load_row(u, b[u]);
+    const int col = tid & 127, half = tid >> 7;              // the adds: thread = one output column; half 0 takes m = 0 (and 1 of 3), half 1 the last m
+    const int ox = x0 + col;
+    const bool out_ok = col < DS_OW && ox < W;
+    for (int q0 = 0; q0 < nq; q0 += DS_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DS_DEPTH; ++u) {
+            const int q = q0 + u;
+            if (q >= nq) break;                              // uniform
+            df_f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], __builtin_bit_cast(df_bf16x8, b[u][ks]), acc, 0, 0, 0);
+            load_row(q + DS_DEPTH, b[u]);
+            float* zq = &z_s[q & (DS_SLOTS - 1)][0][0];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (row < DF_ROWS) zq[row * DS_ZS + 32 * wave + l31] = acc[e];
+            }
+            // one barrier per row: the slot written next (q + 1) was last read for output row q - 3 + 1, two barriers ago
+            __syncthreads();
+            if (q >= 2 && out_ok) {
+                const int oy = y0 + q - 2;
+                auto out_m = [&](int m) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)      // source pixel (y - ky + 1, x - kx + 1) = halo row q - ky, halo column col + 2 - kx
+                            v += z_s[(q - ky) & (DS_SLOTS - 1)][m * 9 + ky * 3 + kx][col + 2 - kx];
+                    const size_t idx = (size_t)m * plane + (size_t)oy * W + ox;
+                    dx[idx] = v + (inject ? inject[idx] : 0.f);
+                };
+                if (half == 0) { out_m(0); if (M == 3) out_m(1); }
+                else if (M >= 2) out_m(M - 1);
+            }
+        }
+    }
+}
+
 // fp32, aligned widths (W % 4 == 0): every lane fetches 16-byte QUADS of the diff (four pixels of one channel) and feeds them to
 // FOUR accumulator tiles, one per pixel of the quad -- 32 loads in flight per lane instead of 96 four-byte ones.  One workgroup =
 // 5 x 64 output pixels; its halo tile is 7 rows x 72 columns (x0 - 4 .. x0 + 67) = 126 quads = one 32-lane group per wave.
@@ -312,8 +400,32 @@ hipError_t launch_conv3x3_dgrad_first16(const unsigned short* dy16, const float*
                                         int H, int W, hipStream_t s)
 {
     if (!conv_dgrad_first_ok(Cout, Cin, H, W, true) || (reinterpret_cast<uintptr_t>(dy16) & 15) != 0) return hipErrorInvalidValue;
-    const dim3 grid((W + DF_TW - 1) / DF_TW, (H + DF_TH - 1) / DF_TH);
     const uint4* q16 = reinterpret_cast<const uint4*>(dy16);
+    {   // Cout = 64: the strip walker (ST2_DGRAD_FIRST_STRIP=0: the tile kernel; read per launch, the tests compare both)
+        const char* e = getenv("ST2_DGRAD_FIRST_STRIP");
+        const unsigned long long bytes = 16ull * (Cout / 8) * H * W;
+        if (!(e && *e == '0') && Cout == 64 && bytes < 0xfffffff0ull) {
+            // segments: as many as keep strips x segments within the resident capacity (2 workgroups per CU), at least 8 rows each
+            static int capacity = 0;
+            if (!capacity) {
+                int dev = 0, cus = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+                capacity = 2 * cus;
+            }
+            const int strips = (W + DS_OW - 1) / DS_OW;
+            const int max_segs = capacity / strips > 0 ? capacity / strips : 1;
+            int seg = (H + max_segs - 1) / max_segs;
+            if (seg < 8) seg = 8;
+            const dim3 grid(strips, (H + seg - 1) / seg);
+            switch (Cin) {
+            case 1: conv3x3_dgrad_first_bf16_strip<1><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, H, W, seg, (unsigned)bytes); break;
+            case 2: conv3x3_dgrad_first_bf16_strip<2><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, H, W, seg, (unsigned)bytes); break;
+            default: conv3x3_dgrad_first_bf16_strip<3><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, H, W, seg, (unsigned)bytes); break;
+            }
+            return hipGetLastError();
+        }
+    }
+    const dim3 grid((W + DF_TW - 1) / DF_TW, (H + DF_TH - 1) / DF_TH);
     switch (Cin) {
     case 1: conv3x3_dgrad_first_bf16<1><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, Cout, H, W); break;
     case 2: conv3x3_dgrad_first_bf16<2><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, Cout, H, W); break;

@@ -371,3 +371,20 @@ def test_sign_map_relu_masks_equal_the_bf16_copy_masks_bit_for_bit(size, conv16_
     assert a[2] == b[2] and np.array_equal(a[3], b[3])
     for (la, ia), (lb, ib) in zip(a[4], b[4]):
         assert la == lb and np.array_equal(ia, ib)
+
+
+@pytest.mark.parametrize('size', [(512, 512), (75, 100), (131, 380), (40, 127)])
+def test_strip_walking_first_layer_data_gradient_equals_the_tile_kernel_bit_for_bit(size, monkeypatch):
+    """conv1_1's data gradient on the bf16 path (64 -> 3 channels: Z = A @ dy on the matrix cores, then 27 shifted adds): the strip
+    kernel (conv3x3_dgrad_first_bf16_strip: a workgroup walks down a 126-pixel column strip, each row of the diff read once, Z rows in
+    an LDS ring) takes the same sums in the same order as the tile kernel (ST2_DGRAD_FIRST_STRIP=0).  Sizes: whole strips, one
+    partial strip, several strips with a ragged last one and a ragged last segment, a strip of exactly 127 columns (two strips, the
+    second one pixel wide)."""
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('ST2_DGRAD_FIRST_STRIP', flag)
+        job = _bf16_job('bf16', size, LEAN_WEIGHTS, 'adam')
+        loss, grad = job.opfunc()
+        out[flag] = (loss, grad.copy())
+    assert out['1'][0] == out['0'][0]
+    assert np.array_equal(out['1'][1], out['0'][1])
