@@ -77,6 +77,9 @@ struct Conv16KArgs {
     const unsigned char* up_amap; int up_h, up_w;
     // sign maps (Conv16Problem::bits_out / mask_bits): [M / 32][H * W][2] 16-bit words in the accumulator layout
     unsigned short* bits_out; const unsigned short* mask_bits;
+    int diag_stagger;                    // DIAG builds only: n > 0 = the first-generation workgroups in odd wave slots sleep n x 3.4 us before starting
+    int diag_nodma;                      // DIAG builds only: 1 = the main loop issues no staging loads (multiplies stale LDS: the loop's own pace)
+    unsigned long long* stamps;          // DIAG builds only (tools/probes): per workgroup {start, first chunk landed, main loop done, end} in 100 MHz ticks
 };
 
 // v if bit `bit` of `word` is set, else +0: the one-bit field sign-extended (v_bfe_i32: 0 or ~0) and-ed onto the value -- two VALU
@@ -109,9 +112,17 @@ __device__ __forceinline__ unsigned nonzero_halves16(uint2 u0, uint2 u1)
 //   DG = true,  "data gradient":  ReLU mask of the blob below (mask_src / mask16 / mask_bits), inject, fp32 / bf16 outputs, the fused style term
 // (a launch with none of these options runs on the forward build)
 // MB (data-gradient builds): the ReLU mask comes as a sign map (mask_bits) -- the other two forms have their own build, for the same reason
-template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false, bool UNPOOL = false, bool DG = UNPOOL, bool MB = false>
+template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false, bool UNPOOL = false, bool DG = UNPOOL, bool MB = false, bool DIAG = false>
 __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 {
+    unsigned long long t_start = 0, t_first = 0, t_loop = 0;
+    if constexpr (DIAG) {
+        if (a.diag_stagger > 0 && blockIdx.x < 2 * 256) {       // does a convoy of co-resident workgroups cost anything?  offset their phases once
+            const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.wave_id
+            if (slot & 1) for (int i = 0; i < a.diag_stagger; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+        t_start = __builtin_amdgcn_s_memrealtime();
+    }
     static_assert(DG || !MB, "sign-map masks are a data-gradient option");
     static_assert(!(SB && UNPOOL), "the unpooling build uses the double-buffered pipeline");
     static_assert(DG || !UNPOOL, "unpooling is a data-gradient option");
@@ -270,6 +281,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     for (int ch = 0; ch < a.nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                         // chunk ch has landed
+        if constexpr (DIAG) { if (ch == 0) t_first = __builtin_amdgcn_s_memrealtime(); }
         fetch(smem, 0, av[0], bv[0]);
 #pragma unroll
         for (int s2 = 0; s2 < NSTEP; ++s2) {
@@ -288,7 +300,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         if (ch + 1 < a.nch) {
             __syncthreads();                                     // every wave has read its last operands of chunk ch
 #pragma unroll
-            for (int t = 0; t < NPIECE; ++t) dma_piece(t, ch + 1, 0);
+            for (int t = 0; t < NPIECE; ++t) if (!(DIAG && a.diag_nodma)) dma_piece(t, ch + 1, 0);
         }
     }
   } else {
@@ -298,6 +310,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         for (int u = 0; u < I_PER_WAVE; ++u) unpool_quad(u, 0);
     }
     __syncthreads();
+    if constexpr (DIAG) t_first = __builtin_amdgcn_s_memrealtime();
     fetch(smem, 0, av[0], bv[0]);
     for (int ch = 0; ch < a.nch; ++ch) {
         const int cur = ch & 1;
@@ -314,7 +327,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                     __builtin_amdgcn_sched_barrier(0);
                     if (s2 + 1 < NSTEP) {
                         fetch(base, s2 + 1, av[(s2 + 1) % 3], bv[(s2 + 1) % 3]);
-                        if (more) {
+                        if (more && !(DIAG && a.diag_nodma)) {
 #pragma unroll
                             for (int pp = 0; pp < PPS; ++pp)
                                 if (s2 * PPS + pp < NPIECE) dma_piece(s2 * PPS + pp, ch + 1, cur ^ 1);
@@ -337,6 +350,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     }
   }
 
+    if constexpr (DIAG) t_loop = __builtin_amdgcn_s_memrealtime();
     // ---- epilogue: fp32 blob (same as the fp32 kernel, optional) + bf16 channel-blocked copy (optional) + fused pool (optional)
     // Written for the memory system, not for brevity: every load the epilogue needs (the bf16 ReLU masks of the whole tile,
     // the bias) is issued up front and unconditionally (clamped addresses instead of branches: a per-element "load or zero"
@@ -635,6 +649,13 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         }
     };
     if (full_m) tile_out(std::true_type{}); else tile_out(std::false_type{});
+    if constexpr (DIAG) {
+        if (a.stamps && threadIdx.x == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores are out of the wave's queue
+            unsigned long long* st = a.stamps + 4 * (size_t)blockIdx.x;
+            st[0] = t_start; st[1] = t_first; st[2] = t_loop; st[3] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
 }
 
 #define ST2_CONV16_KERNEL(NAME, BM, ROWS, WM, WN, WPE) \
@@ -650,10 +671,16 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_unpool(const C
 __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_unpool(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, true, true>(a); }
 __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_unpool_b(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, true, true, true>(a); }
 __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_unpool_b(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, true, true, true>(a); }
+#ifndef SB_WPE
+#define SB_WPE 4
+#endif
 // single staging buffer, three workgroups per CU (162 registers, 30 KiB of LDS each): the short-K launches (conv16_body, SB)
-__global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, false>(a); }
+__global__ __launch_bounds__(NT, SB_WPE) void conv3x3_mfma_bf16_64x256_sb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, false>(a); }
 __global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb_dg(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, true>(a); }
-__global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb_dgb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, true, true>(a); }
+// DIAG builds (tools/probes only: Conv16Problem::stamps)
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_diag(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, false, false, false, true>(a); }
+__global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb_diag(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, false, false, true>(a); }
+__global__ __launch_bounds__(NT, SB_WPE) void conv3x3_mfma_bf16_64x256_sb_dgb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, true, true>(a); }
 
 static int conv16_pick_cfg(const Conv16Problem& p)
 {
@@ -681,8 +708,6 @@ bool conv16_can_unpool(const Conv16Problem& p)
 {
     const char* e = getenv("ST2_CONV16_UNPOOL");
     if (e && *e == '0') return false;
-    const char* sbe = getenv("ST2_CONV16_SB_MAXK");
-    if (sbe && *sbe && p.K <= atoi(sbe)) return false;
     // ... and K <= 128 (ST2_CONV16_UNPOOL_MAXK): the expansion costs the launch about as much per pooled element as the separate kernel
     // did, which pays where that kernel's full-resolution output was the expense -- measured at 2048^2: conv1_2 -145 + 0 us,
     // conv2_2 -73 + 12, conv3_4 -39 + 32, conv4_4 -24 + 33
@@ -701,11 +726,13 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     if (!p.out && !p.out16 && !pools) return hipErrorInvalidValue;          // nothing to write
     const long long tx = (p.W + 31) / 32;
     int cfg = conv16_pick_cfg(p);
-    // short reductions (K <= ST2_CONV16_SB_MAXK; default 0 = off until measured faster): the 64x256 tile with ONE staging buffer,
-    // three workgroups per CU
+    // short reductions (K <= ST2_CONV16_SB_MAXK, default 64): the 64x256 tile with ONE staging buffer, four workgroups per CU (120
+    // registers, 29 KiB of LDS each since the forward / data-gradient epilogues became builds of their own).  Measured in isolation
+    // (tools/probes/conv16_shallow.sh, 2048^2 job): conv1_2 forward with its pool 386 -> 344 us, conv2_1 forward 186 -> 175, K = 128: 279 -> 268;
+    // in the 2048^2 bf16 job: forward class 2.507 -> 2.466 ms with 64, the same with 128 but the data gradients +0.01 (profiles/r04_k_bf16_sb_ab.txt)
     const char* sbe = getenv("ST2_CONV16_SB_MAXK");          // read per launch: the tests compare both pipelines
-    const int sb_maxk = sbe && *sbe ? atoi(sbe) : 0;
-    const bool sb = p.K <= sb_maxk && (cfg == 3 || cfg == 0);
+    const int sb_maxk = sbe && *sbe ? atoi(sbe) : 64;
+    const bool sb = p.K <= sb_maxk && (cfg == 3 || cfg == 0) && !p.unpool_amap;       // (the unpooling builds are double-buffered)
     if (sb) cfg = 0;
     const int BM = cfg == 1 ? 128 : 64, ROWS = cfg == 0 ? 8 : cfg == 3 ? 16 : 4;
     Conv16KArgs k{};
@@ -719,7 +746,7 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     if (p.bits_out && (!p.out16 || (reinterpret_cast<uintptr_t>(p.bits_out) & 3) != 0)) return hipErrorInvalidValue;
     k.bits_out = p.bits_out; k.mask_bits = p.mask_bits;
     const bool unpool = p.unpool_amap != nullptr;
-    if (unpool && (!conv16_can_unpool(p) || sb || pools)) return hipErrorInvalidValue;
+    if (unpool && (!conv16_can_unpool(p) || pools)) return hipErrorInvalidValue;
     k.up_amap = p.unpool_amap; k.up_h = p.H / 2; k.up_w = p.W / 2;
     const unsigned long long in_bytes = 16ull * ((p.K + 7) / 8) * (unpool ? (unsigned long long)k.up_h * k.up_w : (unsigned long long)p.H * p.W),
                              w_bytes = 2ull * conv16_pack_elems(p.K, p.M);
@@ -738,6 +765,14 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     const bool dg = p.mask_src || p.mask16 || p.mask_bits || p.inject || p.s_in16 || unpool;
     if (dg && (p.bias || p.relu || pools || p.bits_out)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)nblk), block(NT);
+    if (p.stamps) {                                                              // measurement builds: forward launches of two tiles
+        if (dg || !(cfg == 3 || (cfg == 0 && sb))) return hipErrorInvalidValue;
+        k.stamps = p.stamps;
+        { const char* nd = getenv("ST2_BENCH_NODMA"); k.diag_nodma = nd && *nd == '1'; }
+        { const char* sg = getenv("ST2_BENCH_STAGGER"); k.diag_stagger = sg && *sg ? atoi(sg) : 0; }
+        if (sb) conv3x3_mfma_bf16_64x256_sb_diag<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x512_diag<<<grid, block, 0, s>>>(k);
+        return hipGetLastError();
+    }
     const bool mb = p.mask_bits != nullptr;
     if (mb && (p.mask_src || p.mask16)) return hipErrorInvalidValue;            // one form of the mask per launch
 #define ST2_CONV16_LAUNCH3(NAME) do { if (mb) NAME##_dgb<<<grid, block, 0, s>>>(k); else if (dg) NAME##_dg<<<grid, block, 0, s>>>(k); else NAME<<<grid, block, 0, s>>>(k); } while (0)

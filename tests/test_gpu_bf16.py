@@ -388,3 +388,24 @@ def test_strip_walking_first_layer_data_gradient_equals_the_tile_kernel_bit_for_
         out[flag] = (loss, grad.copy())
     assert out['1'][0] == out['0'][0]
     assert np.array_equal(out['1'][1], out['0'][1])
+
+
+@pytest.mark.parametrize('size', [(512, 512), (160, 224)])
+def test_single_buffer_pipeline_of_the_short_reductions_changes_no_bit(size, monkeypatch):
+    """K <= 64 launches stage one chunk at a time (conv16_body, SB: one LDS buffer, four workgroups per CU) instead of double
+    buffering; ST2_CONV16_SB_MAXK=0 keeps the double-buffered tiles, =512 sends every launch through the single buffer.  Staging
+    does not touch the order of any sum."""
+    out = {}
+    for flag in ('0', '128', '512'):
+        monkeypatch.setenv('ST2_CONV16_SB_MAXK', flag)
+        job = _bf16_job('bf16', size, LEAN_WEIGHTS, 'adam')
+        first = job.opfunc()
+        second = job.opfunc()
+        steps = [job.step() for _ in range(2)]
+        out[flag] = (first[0], first[1].copy(), second[0], second[1].copy(), [(t['loss'], i.copy()) for i, t in steps])
+    for flag in ('128', '512'):
+        a, b = out[flag], out['0']
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]), flag
+        assert a[2] == b[2] and np.array_equal(a[3], b[3]), flag
+        for (la, ia), (lb, ib) in zip(a[4], b[4]):
+            assert la == lb and np.array_equal(ia, ib), flag

@@ -15,6 +15,7 @@ PROTOTYPES = {
     'st_bench_mfma': (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
     'st_bench_issue_probe': (c_int, [c_int, c_int, c_int, POINTER(c_double)]),
     'st_bench_lds_feed_probe': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_double)]),
+    'st_bench_conv16': (c_int, [c_int] * 7 + [POINTER(c_double)]),
     'st_bench_wino_probe': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_double)]),
 }
 

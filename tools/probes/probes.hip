@@ -555,5 +555,95 @@ int st_bench_conv(int device_id, int K, int M, int H, int W, int cfg, int dgrad_
     return rc;
 }
 
+// Isolated timing of the bf16 conv launcher (conv3x3_mfma_bf16.hip) on one layer shape with the options one launch of the lean
+// flow carries.  mode: sum of  1 out16, 2 fp32 out, 4 fused pool (pool16 + amap), 8 bits_out   (forward: bias + ReLU)
+//                               16 data gradient: mask_bits, 32 mask16, 64 unpool (pooled diff + arg-max map), 128 fused style term
+// The tile configuration is the launcher's own (ST2_CONV16_CFG / ST2_CONV16_SB_MAXK / ST2_CONV16_BIG_MIN apply).  Random data.
+int st_bench_conv16(int device_id, int K, int M, int H, int W, int mode, int iters, double* avg_ms)
+{
+    if (K <= 0 || M <= 0 || H <= 0 || W <= 0 || iters <= 0 || !avg_ms || K % 8 || M % 8) return fail(ST_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(device_id));
+    const size_t hw = (size_t)H * W, phw = (size_t)((H + 1) / 2) * ((W + 1) / 2);
+    const bool dg = (mode & (16 | 32 | 64 | 128)) != 0;
+    std::vector<float> w((size_t)M * K * 9);
+    uint32_t st = 777u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& x : w) x = rnd() * 0.05f;
+    std::vector<unsigned short> pk(conv16_pack_elems(K, M));
+    if (dg) pack_conv_weights16_dgrad(w.data(), K, M, pk.data()); else pack_conv_weights16_fwd(w.data(), M, K, pk.data());
+    auto dalloc = [&](void** p, size_t bytes, int fill) -> int {
+        if (hipMalloc(p, std::max<size_t>(bytes, 16)) != hipSuccess) return fail(ST_ERR_HIP, "hipMalloc(%zu)", bytes);
+        // bf16 pattern 0x3c00.. (small positive numbers) / arg-max bytes 4..7 / all-ones bits
+        return hipMemset(*p, fill, std::max<size_t>(bytes, 16)) == hipSuccess ? ST_OK : fail(ST_ERR_HIP, "hipMemset");
+    };
+    void *din = nullptr, *dw = nullptr, *dbias = nullptr, *dout16 = nullptr, *dout = nullptr, *dpool = nullptr, *damap = nullptr, *dbits = nullptr,
+         *dmask16 = nullptr, *dF = nullptr, *dD = nullptr, *dA = nullptr, *dnorm = nullptr;
+    const size_t in_elems = (size_t)(K / 8) * ((mode & 64) ? phw : hw) * 8;
+    ST_TRY(dalloc(&din, in_elems * 2, 0x3c)); ST_TRY(dalloc(&dw, pk.size() * 2, 0)); ST_TRY(dalloc(&dbias, (size_t)conv_mpad(M) * 4, 0));
+    HIP_TRY(hipMemcpy(dw, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    ST_TRY(dalloc(&dout16, (size_t)(M / 8) * hw * 16, 0));
+    Conv16Problem p{};
+    p.in16 = (const unsigned short*)din; p.wpack16 = (const unsigned short*)dw; p.K = K; p.M = M; p.MPad = conv_mpad(M); p.H = H; p.W = W;
+    if (mode & 1) p.out16 = (unsigned short*)dout16;
+    if (mode & 2) { ST_TRY(dalloc(&dout, (size_t)M * hw * 4, 0)); p.out = (float*)dout; }
+    if (!dg) {
+        p.bias = (const float*)dbias; p.relu = 1;
+        if (mode & 4) { ST_TRY(dalloc(&dpool, (size_t)(M / 8) * phw * 16, 0)); ST_TRY(dalloc(&damap, (size_t)(M / 8) * phw * 8, 0)); p.pool16 = (unsigned short*)dpool; p.amap = (unsigned char*)damap; }
+        if (mode & 8) { ST_TRY(dalloc(&dbits, conv16_bits_elems(M, hw) * 2, 0)); p.bits_out = (unsigned short*)dbits; }
+    } else {
+        if (mode & 16) { ST_TRY(dalloc(&dbits, conv16_bits_elems(M, hw) * 2, 0xff)); p.mask_bits = (const unsigned short*)dbits; }
+        if (mode & 32) { ST_TRY(dalloc(&dmask16, (size_t)(M / 8) * hw * 16, 0x3c)); p.mask16 = (const unsigned short*)dmask16; }
+        if (mode & 64) { ST_TRY(dalloc(&damap, (size_t)(K / 8) * phw * 8, 0x05)); p.unpool_amap = (const unsigned char*)damap; }
+        if (mode & 128) {
+            ST_TRY(dalloc(&dF, (size_t)(M / 8) * hw * 16, 0x3c)); ST_TRY(dalloc(&dD, (size_t)M * M * 4, 0)); ST_TRY(dalloc(&dnorm, 16, 0));
+            ST_TRY(dalloc(&dA, style_fuse_pack_elems(M, p.MPad) * 2, 0));
+            const float one = 1.0f;
+            HIP_TRY(hipMemcpy(dnorm, &one, 4, hipMemcpyHostToDevice));
+            HIP_TRY(launch_style_fuse_pack((const float*)dD, M, M, p.MPad, 1.0f, 1.0f, (const float*)dnorm, (unsigned short*)dA, 0));
+            p.s_in16 = (const unsigned short*)dF; p.s_wpack16 = (const unsigned short*)dA;
+        }
+    }
+    // ST2_BENCH_STAMPS=1 (forward modes, 64x512 / SB tiles): in-kernel phase times of every workgroup
+    void* dst = nullptr;
+    const size_t max_wg = (size_t)((W + 31) / 32) * ((H + 3) / 4) * (p.MPad / 64);
+    const bool stamps = !dg && getenv("ST2_BENCH_STAMPS") && *getenv("ST2_BENCH_STAMPS") == '1';
+    if (stamps) { ST_TRY(dalloc(&dst, max_wg * 32, 0)); p.stamps = (unsigned long long*)dst; }
+    hipStream_t s;
+    HIP_TRY(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    int rc = ST_OK;
+    HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < 2 && rc == ST_OK; ++i) { hipError_t e = launch_conv3x3_bf16(p, s); if (e != hipSuccess) rc = fail(ST_ERR_HIP, "bf16 conv launch failed: %s", hipGetErrorString(e)); }
+    if (rc == ST_OK) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) (void)launch_conv3x3_bf16(p, s);
+        (void)hipEventRecord(e1, s);
+        if (hipStreamSynchronize(s) != hipSuccess) rc = fail(ST_ERR_HIP, "conv16 bench sync failed");
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        *avg_ms = ms / iters;
+        if (stamps) {          // the last launch's stamps: medians of the three phases and of the whole lifetime, and the launch's span
+            std::vector<unsigned long long> h(max_wg * 4);
+            (void)hipMemcpy(h.data(), dst, max_wg * 32, hipMemcpyDeviceToHost);
+            std::vector<double> pro, loop, epi, life;
+            unsigned long long tmin = ~0ull, tmax = 0;
+            for (size_t b = 0; b < max_wg; ++b) {
+                const unsigned long long* t = &h[4 * b];
+                if (!t[3]) continue;
+                pro.push_back((t[1] - t[0]) * 0.01); loop.push_back((t[2] - t[1]) * 0.01); epi.push_back((t[3] - t[2]) * 0.01); life.push_back((t[3] - t[0]) * 0.01);
+                tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[3]);
+            }
+            auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+            auto p90 = [](std::vector<double>& v) { return v.empty() ? 0.0 : v[v.size() * 9 / 10]; };
+            const double m0 = med(pro), m1 = med(loop), m2 = med(epi), m3 = med(life);
+            fprintf(stderr, "[stamps] workgroups=%zu  first chunk %.2f us (p90 %.2f)  main loop %.2f us (p90 %.2f)  epilogue %.2f us (p90 %.2f)  lifetime %.2f us; launch span %.1f us\n",
+                    life.size(), m0, p90(pro), m1, p90(loop), m2, p90(epi), m3, (tmax - tmin) * 0.01);
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    for (void* q : {din, dw, dbias, dout16, dout, dpool, damap, dbits, dmask16, dF, dD, dA, dnorm, dst}) if (q) (void)hipFree(q);
+    return rc;
+}
 
 }  // extern "C"

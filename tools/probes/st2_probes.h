@@ -29,6 +29,10 @@ int st_bench_lds_feed_probe(int device_id, int extra_dma, int K, int blocks, dou
 /* Winograd operand-feed probe: executed MFMA TFLOP/s with the A operands streamed L2 -> VGPR; depth = k-pairs in
  * flight: 1, 2, or 12 (= 2 with a staggered k walk).  Depth 4 is rejected: see probes.hip. */
 int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int depth, double* tflops);
+/* isolated timing of the bf16 conv launcher with the options of one lean-flow launch.  mode = sum of: 1 out16, 2 fp32 out,
+ * 4 fused pool (pool16 + amap), 8 bits_out (forward: bias + ReLU); 16 mask_bits, 32 mask16, 64 unpool, 128 fused style term
+ * (any of these: a data-gradient launch) */
+int st_bench_conv16(int device_id, int K, int M, int H, int W, int mode, int iters, double* avg_ms);
 #ifdef __cplusplus
 }
 #endif
