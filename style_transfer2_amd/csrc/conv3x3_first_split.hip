@@ -77,13 +77,15 @@ __device__ __forceinline__ unsigned nonzero_halves(uint2 u0, uint2 u1)
     return two(u0.x) | (two(u0.y) << 2) | (two(u1.x) << 4) | (two(u1.y) << 6);
 }
 
-template <int FS_TH>
-__global__ __launch_bounds__(256) void conv3x3_first_split_k(const FirstSplitArgs a)
+// MT = the most 32-channel groups a launch may have (sizes the weight image in LDS: 6 KB each; 64 channels -> 31 KB with the
+// halo tile, four workgroups per CU instead of three)
+template <int FS_TH, int MT>
+__global__ __launch_bounds__(256, MT <= 2 ? 4 : 3) void conv3x3_first_split_k(const FirstSplitArgs a)
 {
     constexpr int FS_HH = FS_TH + 2;
     // the halo tile, every value already split: .x = x1 | x2 << 16, .y = x3 (bf16 bit patterns) -- a pixel is split once, not once per tap
     __shared__ uint2 x_s[FS_MAXC * FS_HH * FS_HW];
-    __shared__ uint4 w_s[(FS_MAXM / 32) * 6 * 64];                  // A fragments: [mt][split][k-step][lane]
+    __shared__ uint4 w_s[MT * 6 * 64];                              // A fragments: [mt][split][k-step][lane]
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * FS_TW, y0 = blockIdx.y * FS_TH;
@@ -229,7 +231,8 @@ hipError_t launch_conv3x3_first_split(const float* x, const unsigned short* wpk,
     FirstSplitArgs a{x, reinterpret_cast<const uint4*>(wpk), out, out16, Cout, H, W, relu, bits_out};
     // four rows per workgroup: measured at 2048^2 against 1 / 2 / 8 (0.267 / 0.217 / 0.233 ms against 0.211)
     const dim3 grid((W + FS_TW - 1) / FS_TW, (H + 3) / 4);
-    conv3x3_first_split_k<4><<<grid, 256, 0, s>>>(a);
+    if (Cout <= 64) conv3x3_first_split_k<4, 2><<<grid, 256, 0, s>>>(a);
+    else conv3x3_first_split_k<4, FS_MAXM / 32><<<grid, 256, 0, s>>>(a);
     return hipGetLastError();
 }
 
