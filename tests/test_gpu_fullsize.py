@@ -547,26 +547,15 @@ BF16_LOSS_RTOL, BF16_MSE_OF_MOVE = 5e-2, 0.15
 
 def test_bf16_engine_drifts_from_fp32_no_more_than_the_rounded_operand_oracle_does():
     """192 x 256 (the pair fitted to 256 px), 11 L-BFGS steps (through the roll-over at ten pairs), four runs: oracle fp32 / oracle
-    with bf16 conv operands / engine fp32 / engine bf16.  The engine's bf16-vs-fp32 drift (per-step loss, final iterate) must not
+    with bf16 conv operands (both stored: tests/golden/oracle_trajectories.npz) / engine fp32 / engine bf16.  The engine's bf16-vs-fp32 drift (per-step loss, final iterate) must not
     exceed twice the oracle's own bf16-vs-fp32 drift."""
     inputs = _image_like(256)
     content, style, init = inputs
-    topo = oracle.VGG19_TOPOLOGY
-
-    def cpu_run(operands):
-        job = oracle.TransferOracle(oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False, operands=operands))
-        job.feature_layers = WEIGHTED
-        job.set_input(init); job.set_content(content); job.set_style(style); job.reset()
-        job.set_weights(WEIGHTS, PARAMS)
-        job.set_optimizer('lbfgs', 1)
-        assert job.start()
-        losses = []
-        for _ in range(11):
-            img, tr = job.step()
-            losses.append(tr['loss'])
-        return losses, img
-    lo32, io32 = cpu_run('fp32')
-    lo16, io16 = cpu_run('bf16')
+    # the two oracle trajectories are stored (tests/golden/make_trajectories.py made them with oracle.TransferOracle, 53 s of numpy;
+    # tests/test_oracle_golden.py re-runs their first steps on the CPU): the box's time goes to the engine
+    from helpers import load
+    g = load('oracle_trajectories.npz')
+    lo32, io32, lo16, io16 = list(g['drift_losses_fp32']), g['drift_final_fp32'], list(g['drift_losses_bf16']), g['drift_final_bf16']
     le32, ke32 = _image_like_engine_run(inputs, 'fp32', 11, (11,))
     le16, ke16 = _image_like_engine_run(inputs, 'bf16', 11, (11,))
     rel_o, mse_o, moved_o = _trajectory_report('image-like 192x256, 11 L-BFGS steps: ORACLE bf16 operands vs oracle fp32', lo32, lo16, io32, io16, init)

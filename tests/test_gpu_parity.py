@@ -453,22 +453,23 @@ def test_config1_golden_gate_starry_night_256px_adam_iters():
     weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1},
                'deepdream': {}}
     params4 = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
-    cpu = oracle.TransferOracle(oracle.NetOracle(topo, params, full_forward=False))
+    # the oracle's 30 iterations are stored (tests/golden/make_trajectories.py: oracle.TransferOracle on these very inputs;
+    # tests/test_oracle_golden.py re-runs the first ones on the CPU)
+    traj = __import__('helpers').load('oracle_trajectories.npz')
+    lc, ic = list(traj['config1_losses']), traj['config1_final']
+    first = dict(zip([str(k) for k in traj['config1_first_keys']], traj['config1_first_values']))
     dev = st2.StyleTransfer(st2.HipModel(params))
-    for st in (cpu, dev):
-        st.set_input(init); st.set_content(content); st.set_style(style); st.reset()
-        st.set_weights(weights, params4)
-    cpu.set_optimizer('adam', 10)
+    dev.set_input(init); dev.set_content(content); dev.set_style(style); dev.reset()
+    dev.set_weights(weights, params4)
     dev.optimizer_cls = st2.AdamOptimizer; dev.set_step_size(10); dev.reset()
-    assert cpu.start() and dev.start()
-    lc, ld = [], []
+    assert dev.start()
+    ld = []
     for i in range(30):
-        ic, tc = cpu.step()
         idv, td = dev.step()
-        lc.append(tc['loss']); ld.append(td['loss'])
+        ld.append(td['loss'])
         if i == 0:
-            assert list(td) == list(tc)
-            assert np.isclose(td['loss'], tc['loss'], rtol=1e-4) and np.isclose(td['grad'], tc['grad'], rtol=1e-3)
+            assert [str(k) for k in td] == list(first)
+            assert np.isclose(td['loss'], first['loss'], rtol=1e-4) and np.isclose(td['grad'], first['grad'], rtol=1e-3)
     assert np.allclose(ld[:10], lc[:10], rtol=2e-3)
     assert np.allclose(ld, lc, rtol=2e-2)
     assert idv.shape == (192, 256, 3) and idv.dtype == F32

@@ -134,3 +134,28 @@ def test_trajectories_match_reference(name, kind, step, n):
     assert np.array_equal(np.stack(images), g[name + '_images'])
     check_trace(g[name + '_last_trace_keys'], g[name + '_last_trace_vals'], trace, rtol=0)
     assert rel_l2(images[-1], g[name + '_images'][-1]) == 0.0
+
+
+def test_stored_oracle_trajectories_are_what_the_oracle_computes():
+    """tests/golden/oracle_trajectories.npz holds whole CPU-oracle trajectories that the GPU tests compare the engine with
+    (made by tests/golden/make_trajectories.py).  Their first steps, re-run here with the same functions: a change of the oracle
+    that moved them would leave the GPU tests comparing against a stale answer."""
+    import importlib.util
+    import os
+    from helpers import GOLDEN
+    spec = importlib.util.spec_from_file_location('make_trajectories', os.path.join(GOLDEN, 'make_trajectories.py'))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    g = load('oracle_trajectories.npz')
+    l32, _ = mk.drift_run('fp32', 2)
+    l16, _ = mk.drift_run('bf16', 1)
+    lc, _, keys, vals = mk.config1_run(3)
+    assert np.allclose(l32, g['drift_losses_fp32'][:2], rtol=1e-6, atol=0), (l32, g['drift_losses_fp32'][:2])
+    assert np.allclose(l16, g['drift_losses_bf16'][:1], rtol=1e-6, atol=0), (l16, g['drift_losses_bf16'][:1])
+    assert np.allclose(lc, g['config1_losses'][:3], rtol=1e-6, atol=0), (lc, g['config1_losses'][:3])
+    assert keys == [str(k) for k in g['config1_first_keys']]
+    stored = dict(zip(keys, g['config1_first_values']))
+    for k, v in zip(keys, vals):
+        if k != 'time':
+            assert np.isclose(v, stored[k], rtol=1e-6), (k, v, stored[k])
+    assert len(g['drift_losses_fp32']) == 11 and len(g['config1_losses']) == 30 and g['drift_final_bf16'].shape == (192, 256, 3)
