@@ -268,6 +268,82 @@ __global__ __launch_bounds__(256, 2) void conv3x3_dgrad_first_bf16_strip(const u
     }
 }
 
+// fp32, Cout = 64: the strip walker on v_mfma_f32_32x32x2_f32 (the sums of conv3x3_dgrad_first_f32 in the same order, bit-identical).
+// A row of the strip = 32 k-pairs = 32 four-byte loads per lane (a wave's instruction reads 128 contiguous bytes of two channel
+// planes), rows r + 1 .. r + DSF_DEPTH in flight; everything else as in the bf16 walker.
+constexpr int DSF_DEPTH = 3;
+
+template <int M>
+__global__ __launch_bounds__(256, 2) void conv3x3_dgrad_first_f32_strip(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                        float* __restrict__ dx, const float* __restrict__ inject,
+                                                                        int H, int W, int seg, unsigned dy_bytes)
+{
+    __shared__ float z_s[DS_SLOTS][DF_ROWS][DS_ZS];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, khalf = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = blockIdx.x * DS_OW, y0 = blockIdx.y * seg;
+    const int nq = min(seg, H - y0) + 2;                     // halo rows of this segment: gy = y0 - 1 + q
+    const unsigned plane = (unsigned)H * W;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)dy, 0, dy_bytes, 0x00020000);
+    const int gx = x0 - 1 + 32 * wave + l31;
+    const bool colok = gx >= 0 && gx < W;
+    const int r = l31, m_r = r / 9, tap_r = r - 9 * m_r;
+    float a[32];                                             // A: row r = (m, tap), k-pair kp = channels 2 kp + khalf
+#pragma unroll
+    for (int kp = 0; kp < 32; ++kp) a[kp] = r < 9 * M ? w[((2 * kp + khalf) * M + m_r) * 9 + tap_r] : 0.f;
+    auto load_row = [&](int q, float (&b)[32]) {             // (an offset beyond the tensor reads zeros: rows / columns outside the image)
+        const int gy = y0 - 1 + q;
+        const bool ok = colok && gy >= 0 && gy < H && q < nq;
+        // the k-pair's planes ride in the SCALAR offset, which the hardware's range check leaves out (raw buffers check the vector
+        // offset + the immediate): a lane outside the image stays out of range whatever is added, and one register addresses the row
+        const unsigned base = ok ? ((unsigned)khalf * plane + (unsigned)gy * W + gx) * 4u : 0xfffffff0u;
+#pragma unroll
+        for (int kp = 0; kp < 32; ++kp)
+            b[kp] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, base, (unsigned)(2 * kp) * plane * 4u, 0));
+    };
+    float b[DSF_DEPTH][32];
+#pragma unroll
+    for (int u = 0; u < DSF_DEPTH; ++u) load_row(u, b[u]);
+    const int col = tid & 127, half = tid >> 7;
+    const int ox = x0 + col;
+    const bool out_ok = col < DS_OW && ox < W;
+    for (int q0 = 0; q0 < nq; q0 += DSF_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DSF_DEPTH; ++u) {
+            const int q = q0 + u;
+            if (q >= nq) break;                              // uniform
+            df_f32x16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int kp = 0; kp < 32; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kp], b[u][kp], acc, 0, 0, 0);
+            load_row(q + DSF_DEPTH, b[u]);
+            float* zq = &z_s[q & (DS_SLOTS - 1)][0][0];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * khalf;
+                if (row < DF_ROWS) zq[row * DS_ZS + 32 * wave + l31] = acc[e];
+            }
+            __syncthreads();                                 // (one per row: see the bf16 walker)
+            if (q >= 2 && out_ok) {
+                const int oy = y0 + q - 2;
+                auto out_m = [&](int m) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            v += z_s[(q - ky) & (DS_SLOTS - 1)][m * 9 + ky * 3 + kx][col + 2 - kx];
+                    const size_t idx = (size_t)m * plane + (size_t)oy * W + ox;
+                    dx[idx] = v + (inject ? inject[idx] : 0.f);
+                };
+                if (half == 0) { out_m(0); if (M == 3) out_m(1); }
+                else if (M >= 2) out_m(M - 1);
+            }
+        }
+    }
+}
+
 // fp32, aligned widths (W % 4 == 0): every lane fetches 16-byte QUADS of the diff (four pixels of one channel) and feeds them to
 // FOUR accumulator tiles, one per pixel of the quad -- 32 loads in flight per lane instead of 96 four-byte ones.  One workgroup =
 // 5 x 64 output pixels; its halo tile is 7 rows x 72 columns (x0 - 4 .. x0 + 67) = 126 quads = one 32-lane group per wave.
@@ -384,6 +460,44 @@ hipError_t launch_conv3x3_dgrad_first_quad(const float* dy, const float* w, floa
     return hipGetLastError();
 }
 
+// strips x segments of the walkers: as many segments as keep the grid within the resident capacity (2 workgroups per CU), at least 8 rows each
+static dim3 dgrad_strip_grid(int H, int W, int* seg_out)
+{
+    static int capacity = 0;
+    if (!capacity) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        capacity = 2 * cus;
+    }
+    const int strips = (W + DS_OW - 1) / DS_OW;
+    const int max_segs = capacity / strips > 0 ? capacity / strips : 1;
+    int seg = (H + max_segs - 1) / max_segs;
+    if (seg < 8) seg = 8;
+    *seg_out = seg;
+    return dim3(strips, (H + seg - 1) / seg);
+}
+
+// fp32 strip walker: Cout = 64, tensor below 4 GiB (32-bit buffer offsets); ST2_DGRAD_FIRST_STRIP=0 switches it off (read per launch)
+bool conv_dgrad_first_strip_ok(int Cout, int Cin, int H, int W)
+{
+    const char* e = getenv("ST2_DGRAD_FIRST_STRIP");
+    return !(e && *e == '0') && Cout == 64 && Cin >= 1 && Cin <= 3 && H >= 1 && W >= 1 && 4ull * Cout * H * W < 0xfffffff0ull;
+}
+
+hipError_t launch_conv3x3_dgrad_first_strip(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s)
+{
+    if (!conv_dgrad_first_strip_ok(Cout, Cin, H, W)) return hipErrorInvalidValue;
+    int seg = 0;
+    const dim3 grid = dgrad_strip_grid(H, W, &seg);
+    const unsigned bytes = (unsigned)(4ull * Cout * H * W);
+    switch (Cin) {
+    case 1: conv3x3_dgrad_first_f32_strip<1><<<grid, 256, 0, s>>>(dy, w, dx, inject, H, W, seg, bytes); break;
+    case 2: conv3x3_dgrad_first_f32_strip<2><<<grid, 256, 0, s>>>(dy, w, dx, inject, H, W, seg, bytes); break;
+    default: conv3x3_dgrad_first_f32_strip<3><<<grid, 256, 0, s>>>(dy, w, dx, inject, H, W, seg, bytes); break;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_conv3x3_dgrad_first(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s)
 {
     if (!conv_dgrad_first_ok(Cout, Cin, H, W, false)) return hipErrorInvalidValue;
@@ -405,18 +519,8 @@ hipError_t launch_conv3x3_dgrad_first16(const unsigned short* dy16, const float*
         const char* e = getenv("ST2_DGRAD_FIRST_STRIP");
         const unsigned long long bytes = 16ull * (Cout / 8) * H * W;
         if (!(e && *e == '0') && Cout == 64 && bytes < 0xfffffff0ull) {
-            // segments: as many as keep strips x segments within the resident capacity (2 workgroups per CU), at least 8 rows each
-            static int capacity = 0;
-            if (!capacity) {
-                int dev = 0, cus = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-                capacity = 2 * cus;
-            }
-            const int strips = (W + DS_OW - 1) / DS_OW;
-            const int max_segs = capacity / strips > 0 ? capacity / strips : 1;
-            int seg = (H + max_segs - 1) / max_segs;
-            if (seg < 8) seg = 8;
-            const dim3 grid(strips, (H + seg - 1) / seg);
+            int seg = 0;
+            const dim3 grid = dgrad_strip_grid(H, W, &seg);
             switch (Cin) {
             case 1: conv3x3_dgrad_first_bf16_strip<1><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, H, W, seg, (unsigned)bytes); break;
             case 2: conv3x3_dgrad_first_bf16_strip<2><<<grid, 256, 0, s>>>(q16, w_rounded, dx, inject, H, W, seg, (unsigned)bytes); break;

@@ -941,6 +941,10 @@ hipError_t launch_conv3x3_dgrad_smallM(const float* dy, const float* w, float* d
                                        int Cout, int Cin, int H, int W, hipStream_t s)
 {
     if (!conv_dgrad_smallM_ok(Cout, Cin)) return hipErrorInvalidValue;
+    {   // ST2_DGRAD_FIRST selects among the older kernels when it is set; unset, the strip walker takes the layer it is built for
+        const char* e = getenv("ST2_DGRAD_FIRST");
+        if (!(e && *e) && conv_dgrad_first_strip_ok(Cout, Cin, H, W)) return launch_conv3x3_dgrad_first_strip(dy, w, dx, inject, Cout, Cin, H, W, s);
+    }
     if (conv_dgrad_first_quad_ok(Cout, Cin, H, W, dy)) return launch_conv3x3_dgrad_first_quad(dy, w, dx, inject, Cout, Cin, H, W, s);        // matrix cores, quads
     if (conv_dgrad_first_ok(Cout, Cin, H, W, false)) return launch_conv3x3_dgrad_first(dy, w, dx, inject, Cout, Cin, H, W, s);              // matrix cores
     dim3 grid((W + SM_TX - 1) / SM_TX, (H + SM_TY - 1) / SM_TY);

@@ -68,6 +68,8 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
 // conv1_1's data gradient on the matrix cores (conv3x3_dgrad_first.hip): Z = A @ dy (1x1, 9 M rows) + 9 M shifted adds; Cin <= 3
 bool conv_dgrad_first_ok(int Cout, int Cin, int H, int W, bool bf16);
 hipError_t launch_conv3x3_dgrad_first(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s);
+bool conv_dgrad_first_strip_ok(int Cout, int Cin, int H, int W);                      // fp32, Cout = 64: the strip walker (each row of the diff read once)
+hipError_t launch_conv3x3_dgrad_first_strip(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s);
 bool conv_dgrad_first_quad_ok(int Cout, int Cin, int H, int W, const float* dy);      // fp32, W % 4 == 0: 16-byte operand loads
 hipError_t launch_conv3x3_dgrad_first_quad(const float* dy, const float* w, float* dx, const float* inject, int Cout, int Cin, int H, int W, hipStream_t s);
 hipError_t launch_conv3x3_dgrad_first16(const unsigned short* dy16, const float* w_rounded, float* dx, const float* inject, int Cout, int Cin,

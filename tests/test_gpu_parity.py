@@ -90,6 +90,36 @@ def test_first_conv_data_gradient_on_the_matrix_cores(precision, kernel, cout, h
         assert err <= (5e-5 if precision == 'bf16' else 2e-6), (names, err)
 
 
+@pytest.mark.parametrize('h,w', [(64, 96), (75, 100), (8, 32), (23, 132), (40, 127), (131, 380), (256, 512)])
+def test_first_conv_data_gradient_strip_walker_fp32(h, w, monkeypatch):
+    """conv1_1's fp32 data gradient at 64 channels, the default since round 4: conv3x3_dgrad_first_f32_strip (a workgroup walks down a
+    126-pixel column strip: every row of the diff is read once, three rows in flight, Z = A @ dy on v_mfma_f32_32x32x2_f32, Z rows in
+    an LDS ring, 27 shifted adds per pixel) -- the sums of the tile kernel (ST2_DGRAD_FIRST=1) in the same order, bit for bit, and the
+    oracle's to 2e-6; with and without a diff injected at the data blob; one partial strip, a second strip one pixel wide (127),
+    several strips with ragged last strip / segment."""
+    topo = (('conv', 'conv1_1', 3, 64),)
+    params = oracle.he_init_weights(topo, seed=64 + h, bias_std=0.2)
+    cpu = oracle.NetOracle(topo, params)
+    rng = np.random.RandomState(h * w + 64)
+    x = (rng.randn(1, 3, h, w) * 40).astype(F32)
+    cases = [{n: rng.randn(*((1, 64, h, w) if n != 'data' else x.shape)).astype(F32) for n in names} for names in (['conv1_1'], ['conv1_1', 'data'])]
+    got = {}
+    for kernel in ('strip', 'tile'):
+        if kernel == 'tile':
+            monkeypatch.setenv('ST2_DGRAD_FIRST', '1')
+        else:
+            monkeypatch.delenv('ST2_DGRAD_FIRST', raising=False)
+        monkeypatch.setenv('ST2_DGRAD_FIRST_Q', '0')
+        gpu = st2.HipModel(params, topology=topo)
+        f = gpu.forward(x, ['conv1_1'])
+        got[kernel] = [gpu.backward(d) for d in cases]
+    cpu.forward(x)
+    cpu.adopt_forward_state(f)
+    for d, a, b in zip(cases, got['strip'], got['tile']):
+        assert np.array_equal(a, b)
+        assert rel_l2(a, cpu.backward(d)) <= 2e-6
+
+
 @pytest.mark.parametrize('cout,h,w', [(64, 64, 96), (64, 75, 100), (64, 8, 32), (24, 12, 20), (64, 23, 132), (62, 40, 260), (64, 256, 512)])
 def test_first_conv_data_gradient_lds_dma_staging_equals_the_register_staged_kernel(cout, h, w, monkeypatch):
     """conv3x3_dgrad_smallM_dma (round 4: the 4-channel tile staged as aligned quads by LDS-DMA, one barrier per chunk) against the
