@@ -79,7 +79,7 @@ struct Conv16KArgs {
     unsigned short* bits_out; const unsigned short* mask_bits;
     int diag_stagger;                    // DIAG builds only: n > 0 = the first-generation workgroups in odd wave slots sleep n x 3.4 us before starting
     int diag_nodma;                      // DIAG builds only: 1 = the main loop issues no staging loads (multiplies stale LDS: the loop's own pace)
-    unsigned long long* stamps;          // DIAG builds only (tools/probes): per workgroup {start, first chunk landed, main loop done, end} in 100 MHz ticks
+    unsigned long long* stamps;          // DIAG builds only (tools/probes): per workgroup {start, first chunk landed, main loop done, end} in 100 MHz ticks + the shader-clock counter at the two middle points
 };
 
 // v if bit `bit` of `word` is set, else +0: the one-bit field sign-extended (v_bfe_i32: 0 or ~0) and-ed onto the value -- two VALU
@@ -115,7 +115,7 @@ __device__ __forceinline__ unsigned nonzero_halves16(uint2 u0, uint2 u1)
 template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false, bool UNPOOL = false, bool DG = UNPOOL, bool MB = false, bool DIAG = false>
 __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 {
-    unsigned long long t_start = 0, t_first = 0, t_loop = 0;
+    unsigned long long t_start = 0, t_first = 0, t_loop = 0, c_first = 0, c_loop = 0;      // 100 MHz ticks / shader cycles
     if constexpr (DIAG) {
         if (a.diag_stagger > 0 && blockIdx.x < 2 * 256) {       // does a convoy of co-resident workgroups cost anything?  offset their phases once
             const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);      // HW_ID.wave_id
@@ -281,7 +281,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     for (int ch = 0; ch < a.nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                         // chunk ch has landed
-        if constexpr (DIAG) { if (ch == 0) t_first = __builtin_amdgcn_s_memrealtime(); }
+        if constexpr (DIAG) { if (ch == 0) { t_first = __builtin_amdgcn_s_memrealtime(); c_first = __builtin_amdgcn_s_memtime(); } }
         fetch(smem, 0, av[0], bv[0]);
 #pragma unroll
         for (int s2 = 0; s2 < NSTEP; ++s2) {
@@ -310,7 +310,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         for (int u = 0; u < I_PER_WAVE; ++u) unpool_quad(u, 0);
     }
     __syncthreads();
-    if constexpr (DIAG) t_first = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DIAG) { t_first = __builtin_amdgcn_s_memrealtime(); c_first = __builtin_amdgcn_s_memtime(); }
     fetch(smem, 0, av[0], bv[0]);
     for (int ch = 0; ch < a.nch; ++ch) {
         const int cur = ch & 1;
@@ -350,7 +350,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     }
   }
 
-    if constexpr (DIAG) t_loop = __builtin_amdgcn_s_memrealtime();
+    if constexpr (DIAG) { t_loop = __builtin_amdgcn_s_memrealtime(); c_loop = __builtin_amdgcn_s_memtime(); }
     // ---- epilogue: fp32 blob (same as the fp32 kernel, optional) + bf16 channel-blocked copy (optional) + fused pool (optional)
     // Written for the memory system, not for brevity: every load the epilogue needs (the bf16 ReLU masks of the whole tile,
     // the bias) is issued up front and unconditionally (clamped addresses instead of branches: a per-element "load or zero"
@@ -652,8 +652,8 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     if constexpr (DIAG) {
         if (a.stamps && threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores are out of the wave's queue
-            unsigned long long* st = a.stamps + 4 * (size_t)blockIdx.x;
-            st[0] = t_start; st[1] = t_first; st[2] = t_loop; st[3] = __builtin_amdgcn_s_memrealtime();
+            unsigned long long* st = a.stamps + 6 * (size_t)blockIdx.x;
+            st[0] = t_start; st[1] = t_first; st[2] = t_loop; st[3] = __builtin_amdgcn_s_memrealtime(); st[4] = c_first; st[5] = c_loop;
         }
     }
 }

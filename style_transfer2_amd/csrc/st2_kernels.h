@@ -115,7 +115,7 @@ struct Conv16Problem {
     // (conv16_bits_elems words, M % 32 == 0).  bits_out: written by a forward launch next to out16; mask_bits: read by the data
     // gradient instead of mask16 -- 1/16 of its bytes, one 2-byte load per 16 elements instead of two 8-byte ones
     unsigned short* bits_out = nullptr; const unsigned short* mask_bits = nullptr;
-    unsigned long long* stamps = nullptr;   // tools/probes only: 4 x 100 MHz ticks per workgroup (start, first chunk landed, main loop done, end)
+    unsigned long long* stamps = nullptr;   // tools/probes only: 6 words per workgroup: 100 MHz ticks at start / first chunk landed / main loop done / end, shader cycles at the two middle points
 };
 inline size_t conv16_bits_elems(int M, size_t hw) { return (size_t)(M / 32) * hw * 2; }
 // A-operand image of the scaled D for the fused style term: [M / 16][hl][k half][MPad] quads

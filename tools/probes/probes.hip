@@ -607,7 +607,7 @@ int st_bench_conv16(int device_id, int K, int M, int H, int W, int mode, int ite
     void* dst = nullptr;
     const size_t max_wg = (size_t)((W + 31) / 32) * ((H + 3) / 4) * (p.MPad / 64);
     const bool stamps = !dg && getenv("ST2_BENCH_STAMPS") && *getenv("ST2_BENCH_STAMPS") == '1';
-    if (stamps) { ST_TRY(dalloc(&dst, max_wg * 32, 0)); p.stamps = (unsigned long long*)dst; }
+    if (stamps) { ST_TRY(dalloc(&dst, max_wg * 48, 0)); p.stamps = (unsigned long long*)dst; }
     hipStream_t s;
     HIP_TRY(hipStreamCreate(&s));
     hipEvent_t e0, e1;
@@ -624,21 +624,22 @@ int st_bench_conv16(int device_id, int K, int M, int H, int W, int mode, int ite
         (void)hipEventElapsedTime(&ms, e0, e1);
         *avg_ms = ms / iters;
         if (stamps) {          // the last launch's stamps: medians of the three phases and of the whole lifetime, and the launch's span
-            std::vector<unsigned long long> h(max_wg * 4);
-            (void)hipMemcpy(h.data(), dst, max_wg * 32, hipMemcpyDeviceToHost);
-            std::vector<double> pro, loop, epi, life;
+            std::vector<unsigned long long> h(max_wg * 6);
+            (void)hipMemcpy(h.data(), dst, max_wg * 48, hipMemcpyDeviceToHost);
+            std::vector<double> pro, loop, epi, life, clk;
             unsigned long long tmin = ~0ull, tmax = 0;
             for (size_t b = 0; b < max_wg; ++b) {
-                const unsigned long long* t = &h[4 * b];
+                const unsigned long long* t = &h[6 * b];
                 if (!t[3]) continue;
                 pro.push_back((t[1] - t[0]) * 0.01); loop.push_back((t[2] - t[1]) * 0.01); epi.push_back((t[3] - t[2]) * 0.01); life.push_back((t[3] - t[0]) * 0.01);
                 tmin = std::min(tmin, t[0]); tmax = std::max(tmax, t[3]);
+                if (t[2] > t[1]) clk.push_back((double)(t[5] - t[4]) / (double)(t[2] - t[1]) * 0.1);      // shader cycles per 10 ns -> GHz
             }
             auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
             auto p90 = [](std::vector<double>& v) { return v.empty() ? 0.0 : v[v.size() * 9 / 10]; };
             const double m0 = med(pro), m1 = med(loop), m2 = med(epi), m3 = med(life);
-            fprintf(stderr, "[stamps] workgroups=%zu  first chunk %.2f us (p90 %.2f)  main loop %.2f us (p90 %.2f)  epilogue %.2f us (p90 %.2f)  lifetime %.2f us; launch span %.1f us\n",
-                    life.size(), m0, p90(pro), m1, p90(loop), m2, p90(epi), m3, (tmax - tmin) * 0.01);
+            fprintf(stderr, "[stamps] workgroups=%zu  first chunk %.2f us (p90 %.2f)  main loop %.2f us (p90 %.2f)  epilogue %.2f us (p90 %.2f)  lifetime %.2f us; launch span %.1f us; shader clock in the main loop %.3f GHz\n",
+                    life.size(), m0, p90(pro), m1, p90(loop), m2, p90(epi), m3, (tmax - tmin) * 0.01, med(clk));
         }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
