@@ -69,7 +69,6 @@ struct Conv16KArgs {
     const float* mask_src; const float* inject; const unsigned short* mask16;
     unsigned short* pool16; float* pool32; unsigned char* amap; int pool_h, pool_w;
     int K, M, MPad, H, W, nch, tiles_x, tiles_y, n_mtiles, relu;
-    int n_tiles;                         // tiles_x * tiles_y * n_mtiles; the grid may be smaller: a workgroup then walks tiles blockIdx.x, + gridDim.x, ...
     unsigned in_bytes, w_bytes;
     // fused style term (data-gradient launches): out = mask(conv) + D' @ F, F = the bf16 copy of the blob this launch differentiates
     const unsigned short* s_in16; const unsigned short* s_wpack; int s_nch; unsigned s_in_bytes, s_w_bytes;
@@ -147,46 +146,29 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     __shared__ __attribute__((aligned(16))) uint4 smem[(SB ? 1 : 2) * BUF_Q];
 
     const int tid = threadIdx.x;
-    const int lane_of_thread = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
 
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int mt = logical % a.n_mtiles;
+    const int pt = logical / a.n_mtiles;
+    const int tx = pt % a.tiles_x, ty = pt / a.tiles_x;
+    const int m0 = mt * BM, y0 = ty * ROWS, x0 = tx * 32;
     const unsigned plane = (unsigned)a.H * a.W;
-    // tile index -> (channel tile, pixel tile); XCD-aware: tiles i, i + 8, ... (one XCD: the grid is a multiple of 8 or the whole
-    // tile count) walk neighbouring tiles of one channel slice
-    auto tile_origin = [&](int orig, int& om0, int& oy0, int& ox0) {
-        const int nwg = a.n_tiles;
-        const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-        const int mt = logical % a.n_mtiles;
-        const int pt = logical / a.n_mtiles;
-        const int tx = pt % a.tiles_x, ty = pt / a.tiles_x;
-        om0 = mt * BM; oy0 = ty * ROWS; ox0 = tx * 32;
-    };
-    // PERSISTENT launches (grid < n_tiles): before a tile's store epilogue the workgroup requests the FIRST chunk of its next tile, so
-    // that tile starts on staged data instead of a 2 - 3 us wait (measured: 3.2 of a K = 64 tile's 22 us, 2.0 of a K = 512 tile's 95)
-    // (UNPOOL and DIAG builds are launched with one workgroup per tile: their loop is compiled away)
-    constexpr bool PERSIST = !UNPOOL && !DIAG;
-    bool prefetched = false;
-    int tile = blockIdx.x;
-  do {
-    // (the lane index is made opaque per tile: everything derived from it -- staging offsets, operand offsets, the epilogue's pixel
-    //  indices -- is recomputed in a few hundred VALU operations instead of living in registers across the whole tile loop)
-    int lane = lane_of_thread;
-    asm volatile("" : "+v"(lane));
-    int m0, y0, x0;
-    tile_origin(tile, m0, y0, x0);
 
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpack, 0, a.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)a.in16, 0, a.in_bytes, 0x00020000);
 
     const unsigned pplane = UNPOOL ? (unsigned)a.up_h * a.up_w : 0u;      // quads per channel block of the pooled diff
-    auto full_res_offset = [&](int t, int ln, int ty0, int tx0) -> unsigned {      // byte offset of staged quad (wave + 4 t) * 64 + ln of the tile at (ty0, tx0) in a [blocks][H][W] quad tensor
+    auto full_res_offset = [&](int t, int ln) -> unsigned {      // byte offset of staged quad (wave + 4 t) * 64 + ln in a [blocks][H][W] quad tensor
         const int f = (wave + 4 * t) * 64 + ln;                  // quad index in the activation image
         const int h = f / (IN_ROWS * PXW);
         const int rem = f - h * (IN_ROWS * PXW);
         const int rr = rem / PXW, col = rem - rr * PXW;
-        const int gy = ty0 - 1 + rr, gx = tx0 - 1 + col;
+        const int gy = y0 - 1 + rr, gx = x0 - 1 + col;
         const bool ok = f < I_QUADS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         return ok ? ((unsigned)h * plane + (unsigned)gy * a.W + gx) * 16u : kOOB16;
     };
@@ -203,7 +185,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             const bool ok = f < I_QUADS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             ioff[t] = ok ? ((unsigned)h * pplane + (unsigned)(gy >> 1) * a.up_w + (gx >> 1)) * 16u : kOOB16;
             up_here |= (4u | (2u * (gy & 1)) | (gx & 1)) << (3 * t);
-        } else ioff[t] = full_res_offset(t, lane, y0, x0);
+        } else ioff[t] = full_res_offset(t, lane);
     }
     static_assert(!UNPOOL || 3 * I_PER_WAVE <= 32, "the window positions of a lane's quads fit one register");
     unsigned woff[W_PER_WAVE];
@@ -214,7 +196,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         woff[t] = ((unsigned)th * a.MPad + m) * 16u;
     }
 
-    auto dma_piece_of = [&](int t, int ch, int buf, const unsigned (&ioff)[I_PER_WAVE], int m0) {      // (tile given by its offsets / channel origin)
+    auto dma_piece = [&](int t, int ch, int buf) {
         uint4* dst = smem + buf * BUF_Q;
         if (t < W_PER_WAVE) {
             const int i = wave + 4 * t;
@@ -232,7 +214,6 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             }
         }
     };
-    auto dma_piece = [&](int t, int ch, int buf) { dma_piece_of(t, ch, buf, ioff, m0); };
     // UNPOOL: the expansion of a staged chunk, by the lane that fetched each quad -- so it needs that lane's own loads back, not a
     // barrier.  The arg-max bytes (8 per quad, from the caches: the four pixels of a window share them) are requested two MFMA steps
     // ahead (unpool_prefetch); at the last step, the wave's pieces having landed (unpool_landed), each lane reads its quads back from
@@ -294,10 +275,8 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         for (int j = 0; j < TN; ++j) bo[j] = __builtin_bit_cast(bf16x8, base[b_off + (j + dy) * PXW + dx]);
     };
 
-    if (!prefetched) {                                           // (the previous tile's epilogue has not already asked for this one's first chunk)
 #pragma unroll
-        for (int t = 0; t < NPIECE; ++t) dma_piece(t, 0, 0);
-    }
+    for (int t = 0; t < NPIECE; ++t) dma_piece(t, 0, 0);
   if constexpr (SB) {
     for (int ch = 0; ch < a.nch; ++ch) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -471,7 +450,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         int ln = lane;
         if constexpr (UNPOOL) asm volatile("" : "+v"(ln));      // computed HERE: hoisted above the main loop they would live through it in scratch
 #pragma unroll
-        for (int u = 0; u < I_PER_WAVE; ++u) soff[u] = UNPOOL ? full_res_offset(u, ln, y0, x0) : ioff[u];
+        for (int u = 0; u < I_PER_WAVE; ++u) soff[u] = UNPOOL ? full_res_offset(u, ln) : ioff[u];
         auto s_dma = [&](int ch, int buf) {
             uint4* dst = smem + buf * BUF_Q;
 #pragma unroll
@@ -669,21 +648,6 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             }
         }
     };
-    prefetched = false;
-    if constexpr (PERSIST) {
-        const int ntile = tile + (int)gridDim.x;
-        if (ntile < a.n_tiles) {
-            int nm0, ny0, nx0;
-            tile_origin(ntile, nm0, ny0, nx0);
-            unsigned nioff[I_PER_WAVE];
-#pragma unroll
-            for (int t = 0; t < I_PER_WAVE; ++t) nioff[t] = full_res_offset(t, lane, ny0, nx0);
-            __syncthreads();                                     // every wave has taken its last operands (main loop / style chunks) out of LDS
-#pragma unroll
-            for (int t = 0; t < NPIECE; ++t) dma_piece_of(t, 0, 0, nioff, nm0);
-            prefetched = true;
-        }
-    }
     if (full_m) tile_out(std::true_type{}); else tile_out(std::false_type{});
     if constexpr (DIAG) {
         if (a.stamps && threadIdx.x == 0) {
@@ -692,8 +656,6 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             st[0] = t_start; st[1] = t_first; st[2] = t_loop; st[3] = __builtin_amdgcn_s_memrealtime(); st[4] = c_first; st[5] = c_loop;
         }
     }
-    tile += (int)gridDim.x;
-  } while (PERSIST && tile < a.n_tiles);
 }
 
 #define ST2_CONV16_KERNEL(NAME, BM, ROWS, WM, WN, WPE) \
@@ -802,19 +764,7 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     // which epilogue: the data-gradient build iff the launch uses one of its options; both directions' options together have no build
     const bool dg = p.mask_src || p.mask16 || p.mask_bits || p.inject || p.s_in16 || unpool;
     if (dg && (p.bias || p.relu || pools || p.bits_out)) return hipErrorInvalidValue;
-    k.n_tiles = (int)nblk;
-    // persistent launches (ST2_CONV16_PERSIST=0: one workgroup per tile; read per launch): as many workgroups as are resident at once
-    // (what the build's registers / LDS allow per CU), each walking tiles blockIdx.x, + gridDim.x, ... -- see conv16_body
-    long long nwg = nblk;
-    {
-        const char* pe = getenv("ST2_CONV16_PERSIST");
-        static int cus = 0;
-        if (!cus) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256; }
-        const int per_cu = sb ? ((p.mask_src || p.mask16) ? 3 : SB_WPE) : cfg == 1 ? 1 : cfg == 2 ? 3 : 2;
-        const long long slots = (long long)per_cu * cus;
-        if (!(pe && *pe == '0') && !unpool && !p.stamps && slots % 8 == 0 && nblk > slots) nwg = slots;
-    }
-    const dim3 grid((unsigned)nwg), block(NT);
+    const dim3 grid((unsigned)nblk), block(NT);
     if (p.stamps) {                                                              // measurement builds: forward launches of two tiles
         if (dg || !(cfg == 3 || (cfg == 0 && sb))) return hipErrorInvalidValue;
         k.stamps = p.stamps;
