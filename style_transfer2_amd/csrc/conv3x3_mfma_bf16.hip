@@ -9,6 +9,9 @@
 // of the backward pass is read from the bf16 copy (mask16: 2 bytes instead of 4), and the forward epilogue can pool its
 // own output (Caffe MAX 2x2/2, ceil mode, first-max) into the bf16 copy the next conv reads plus a one-byte-per-element
 // arg-max map (bits 0-1 = window slot, bit 2 = the maximum is positive) that replaces the blob in the pool backward.
+// Round 4: forward and data-gradient epilogues are separate builds (conv16_body<..., DG, MB>); forward launches also write a 1-bit
+// sign map of their post-ReLU output (bits_out) that the data gradient above masks with (mask_bits); the data gradient below a
+// pool can take the POOLED diff and expand it in its staged tile (UNPOOL); K <= 64 launches use one staging buffer (SB).
 //
 // Same pipeline as conv3x3_mfma.hip (LDS-DMA with buffer descriptors, double-buffered LDS, one barrier per chunk,
 // pinned issue order); what changes is the operand shape: K = 16 channels per MFMA, lane (l&31, l>>5) holds 8
@@ -97,10 +100,10 @@ __device__ __forceinline__ unsigned nonzero_halves16(uint2 u0, uint2 u1)
     return two(u0.x) | (two(u0.y) << 2) | (two(u1.x) << 4) | (two(u1.y) << 6);
 }
 
-// SB = true: ONE staging buffer instead of two.  A short reduction (K <= 128: two to eight chunks) never reaches the steady state
-// the double buffer is built for -- the workgroup waits for its first chunks at HBM latency with nothing to overlap -- so the
-// short-K launches trade the second buffer for occupancy: 39 KiB of LDS per workgroup, FOUR workgroups per CU, and one
-// workgroup's DMA wait runs under the other three's MFMAs.
+// SB = true: ONE staging buffer instead of two.  A short reduction (K <= 64: two to four chunks) never reaches the steady state
+// the double buffer is built for -- the workgroup waits for its first chunk at HBM latency with nothing to overlap -- so the
+// short-K launches trade the second buffer for occupancy: 29 KiB of LDS and 120 registers per workgroup (forward and sign-map
+// data-gradient builds), FOUR workgroups per CU, and one workgroup's DMA wait runs under the other three's MFMAs.
 // UNPOOL = true (round 4; the double-buffered pipeline only): the launch differentiates the conv directly below a max-pool and reads
 // the POOLED diff instead of the full-resolution one maxpool_bwd_idx16_k would have written.  Every staged quad (8 channels of one
 // full-resolution pixel) is fetched from its pooling window's quad of the pooled diff -- the four pixels of a window fetch the same
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_unpool_b(const
 #ifndef SB_WPE
 #define SB_WPE 4
 #endif
-// single staging buffer, three workgroups per CU (162 registers, 30 KiB of LDS each): the short-K launches (conv16_body, SB)
+// single staging buffer, four workgroups per CU (three for the legacy-mask data gradient: 150 registers): the short-K launches (conv16_body, SB)
 __global__ __launch_bounds__(NT, SB_WPE) void conv3x3_mfma_bf16_64x256_sb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, false>(a); }
 __global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb_dg(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, true>(a); }
 // DIAG builds (tools/probes only: Conv16Problem::stamps)
