@@ -95,11 +95,11 @@ def build_probes(force=False):
     """Development probes + the isolated conv timing hook (tools/probes/): a library of their own, linked against
     libst2_hip.so for the product's conv launchers.  Nothing on the product path loads it."""
     lib = build_lib()
-    src = os.path.join(PROBES_DIR, 'probes.hip')
-    deps = [src, os.path.join(PROBES_DIR, 'st2_probes.h'), os.path.join(CSRC, 'st2_kernels.h'), lib]
+    srcs = [os.path.join(PROBES_DIR, 'probes.hip'), os.path.join(PROBES_DIR, 'wino_split_probe.hip')]
+    deps = srcs + [os.path.join(PROBES_DIR, 'st2_probes.h'), os.path.join(CSRC, 'st2_kernels.h'), lib]
     if force or _stale(PROBES_LIB, deps):
         r = subprocess.run([_hipcc(), '-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC', '-shared', '-Wall', '-Wno-unused-result',
-                            src, '-o', PROBES_LIB, '-L' + os.path.dirname(lib), '-lst2_hip',
+                            ] + srcs + ['-o', PROBES_LIB, '-L' + os.path.dirname(lib), '-lst2_hip',
                             '-Wl,-rpath,$ORIGIN/../../style_transfer2_amd/lib', '-Wl,-z,defs'], capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed on the probes library:\n' + r.stderr)

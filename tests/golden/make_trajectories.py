@@ -6,10 +6,15 @@ CPU by tests/test_oracle_golden.py::test_stored_oracle_trajectories_are_what_the
   drift_*    the reference's example pair fitted to 256 px (192 x 256), iterate-like initial image, initial_weights.yaml losses,
              11 L-BFGS steps with step 1: oracle in fp32 and the same oracle with every conv operand rounded to bf16
              (tests/test_gpu_fullsize.py::test_bf16_engine_drifts_from_fp32_no_more_than_the_rounded_operand_oracle_does)
-  config1_*  BASELINE configs[0]: tests/golden/config1_inputs.npz, noise initial image, Adam step 10, the first 30 iterations
+  config1_*  BASELINE configs[0]: tests/golden/config1_inputs.npz, noise initial image, Adam step 10, all 50 iterations
              (tests/test_gpu_parity.py::test_config1_golden_gate_starry_night_256px_adam_iters)
+  size_*     the same pair fitted to 1024 px (content 768 x 1024), iterate-like initial image, L-BFGS step 1 (round 5): the per-step
+             losses of the fp32 oracle over five steps and of the ROUNDED-OPERAND oracle (bf16 conv operands) over three, scalars
+             only, plus the fp32 oracle's fifth iterate rounded to uint8 (its quantisation adds 1/12 to an MSE whose bar is 45)
+             (tests/test_gpu_fullsize.py::test_image_like_job_*_follows_the_*oracle*)
 
-Run here: python tests/golden/make_trajectories.py   (about three minutes on 8 cores)
+Run here: python tests/golden/make_trajectories.py [drift] [config1] [size]   (no argument: all three; a part that is not named
+keeps its stored arrays; all of it is about ten minutes on 8 cores)
 """
 import os
 import sys
@@ -38,8 +43,8 @@ def image_like(fit):
     return content, style, init
 
 
-def drift_run(operands, steps):
-    content, style, init = image_like(256)
+def drift_run(operands, steps, fit=256):
+    content, style, init = image_like(fit)
     topo = oracle.VGG19_TOPOLOGY
     job = oracle.TransferOracle(oracle.NetOracle(topo, oracle.he_init_weights(topo, seed=0), full_forward=False, operands=operands))
     job.feature_layers = WEIGHTED
@@ -76,10 +81,22 @@ def config1_run(steps):
 
 
 if __name__ == '__main__':
-    lo32, io32 = drift_run('fp32', 11)
-    lo16, io16 = drift_run('bf16', 11)
-    lc, ic, keys, vals = config1_run(30)
-    np.savez_compressed(os.path.join(HERE, 'oracle_trajectories.npz'),
-                        drift_losses_fp32=lo32, drift_losses_bf16=lo16, drift_final_fp32=io32, drift_final_bf16=io16,
-                        config1_losses=lc, config1_final=ic, config1_first_keys=np.array(keys), config1_first_values=vals)
-    print('drift fp32', lo32, '\nbf16', lo16, '\nconfig1', lc)
+    path = os.path.join(HERE, 'oracle_trajectories.npz')
+    parts = set(sys.argv[1:]) or {'drift', 'config1', 'size'}
+    data = dict(np.load(path)) if os.path.exists(path) else {}
+    if 'drift' in parts:
+        lo32, io32 = drift_run('fp32', 11)
+        lo16, io16 = drift_run('bf16', 11)
+        data.update(drift_losses_fp32=lo32, drift_losses_bf16=lo16, drift_final_fp32=io32, drift_final_bf16=io16)
+        print('drift fp32', lo32, '\nbf16', lo16)
+    if 'config1' in parts:
+        lc, ic, keys, vals = config1_run(50)
+        data.update(config1_losses=lc, config1_final=ic, config1_first_keys=np.array(keys), config1_first_values=vals)
+        print('config1', lc)
+    if 'size' in parts:
+        ls32, is32 = drift_run('fp32', 5, fit=1024)
+        ls16, _ = drift_run('bf16', 3, fit=1024)
+        data.update(size_losses_fp32=ls32, size_losses_bf16=ls16, size_final_fp32_u8=np.clip(np.rint(is32), 0, 255).astype(np.uint8),
+                    size_final_fp32_clipped_frac=np.float64(np.mean((is32 < -0.5) | (is32 > 255.5))))
+        print('size fp32', ls32, '\nbf16', ls16)
+    np.savez_compressed(path, **data)

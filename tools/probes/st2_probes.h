@@ -33,6 +33,11 @@ int st_bench_wino_probe(int device_id, int blocks_per_cu, int K, int M, int dept
  * 4 fused pool (pool16 + amap), 8 bits_out (forward: bias + ReLU); 16 mask_bits, 32 mask16, 64 unpool, 128 fused style term
  * (any of these: a data-gradient launch) */
 int st_bench_conv16(int device_id, int K, int M, int H, int W, int mode, int iters, double* avg_ms);
+/* round 5: go / no-go probe of the split-operand Winograd (tools/probes/wino_split_probe.hip): one forward layer K -> M at H x W with the
+ * transform-domain products as six bf16 partial products of three-way split fp32 operands; check != 0 compares with a CPU loop nest */
+int st_probe_wino_split(int device_id, int K, int M, int H, int W, int iters, int check, double* avg_ms, double* rel_l2,
+                        double* loop_cycles, double* clock_mhz, double* pro_cycles, double* epi_cycles);
+const char* st_probe_wino_split_error(void);
 #ifdef __cplusplus
 }
 #endif
