@@ -24,6 +24,9 @@ K, M, H, W, iters = args
 for shape in ((16, 64, 8, 32), (32, 64, 16, 64), (64, 128, 24, 96)):
     split(*shape, 2, 1)
 t_split = split(K, M, H, W, iters, 0)
+for var in (1, 2, 3, 4, 6, 7):
+    print('loop experiment %d (1 = no U refills, 2 = no B builds, 4 = no raw reads / row transform):' % var, end=' ')
+    split(K, M, H, W, iters, 100 + var)
 ms, used = ctypes.c_double(), ctypes.c_int()
 for cfg in (101, 100):
     rc = lib.st_bench_conv(0, K, M, H, W, cfg, 0, iters, ctypes.byref(ms), ctypes.byref(used))
