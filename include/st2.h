@@ -47,7 +47,11 @@ int st_destroy(st_ctx* ctx);
 int st_load_conv_weights(st_ctx* ctx, const char* layer, const float* w, const float* bias);
 /* 1 (default; the environment variable ST2_WINO=0 also clears it): fp32 convs whose shape allows it (reduction
  * depth % 8 == 0, >= 48 output channels; any width) run as Winograd F(2x2,3x3) on the fp32 matrix cores --
- * 2.25x fewer multiplies, same IEEE fp32 products and sums in a different association.  0: direct kernel only. */
+ * 2.25x fewer multiplies, same IEEE fp32 products and sums in a different association.  0: direct kernel only.
+ * 2 (opt-in, round 5): as 1, and where the shape also allows it (reduction depth % 16 == 0, output channels % 64 == 0,
+ * width % 4 == 0, tensors below 4 GiB) the transform-domain products are taken on the bf16 matrix cores as the six
+ * exact bf16 x bf16 partial products of three-way split fp32 operands, accumulated in fp32 (conv3x3_wino_split.hip):
+ * fp32-grade results (closer to a double-precision convolution than algorithm 1's), not bit-identical to them. */
 int st_set_conv_algo(st_ctx* ctx, int winograd);
 /* 0 (default): fp32 throughout.  1: bf16 feature path (BASELINE config 3) -- conv operands (activations, weights,
  * backward diffs) in bf16 on v_mfma_f32_32x32x16_bf16, fp32 accumulate; Gram, losses, optimizer stay fp32.  Objective

@@ -21,6 +21,7 @@ SOURCES = (
     ('conv3x3_mfma.hip', ()),
     ('conv3x3_mfma_bf16.hip', ()),
     ('conv3x3_winograd.hip', ()),
+    ('conv3x3_wino_split.hip', ()),
     ('gram.hip', ()),
     ('passes.hip', ('-ffp-contract=off',)),      # NumPy-like one-rounding-per-operation arithmetic
     ('lbfgs.hip', ('-ffp-contract=off',)),

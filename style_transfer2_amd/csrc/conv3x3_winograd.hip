@@ -746,6 +746,17 @@ __global__ __launch_bounds__(256) void wino_combine_k(const float* __restrict__ 
     }
 }
 
+// the split-K combine pass, also for conv3x3_wino_split.hip (plane % 4 == 0)
+hipError_t launch_wino_combine(const float* scratch, int splits, const float* bias, int relu, const float* mask_src, const float* inject,
+                               float* out, int M, int H, int W, hipStream_t s)
+{
+    if (((size_t)H * W) % 4 != 0) return hipErrorInvalidValue;
+    const size_t n4 = (size_t)M * H * W / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    wino_combine_k<<<grid, 256, 0, s>>>(scratch, splits, bias, relu, mask_src, inject, out, M, (unsigned)(H * W));
+    return hipGetLastError();
+}
+
 static int wino_default_variant(int M, int W);
 static bool wino_variant_small(int variant);
 static bool wino_needs_big(int K, int M, int H, int W);
@@ -918,11 +929,7 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || k.splits == 1) return e;
-    if (((size_t)p.H * p.W) % 4 != 0) return hipErrorInvalidValue;      // conv_wino_splits() declines such shapes
-    const size_t n4 = (size_t)p.M * p.H * p.W / 4;
-    const unsigned grid = (unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    wino_combine_k<<<grid, 256, 0, s>>>(k.scratch, k.splits, p.bias, p.relu, p.mask_src, p.inject, p.out, p.M, (unsigned)(p.H * p.W));
-    return hipGetLastError();
+    return launch_wino_combine(k.scratch, k.splits, p.bias, p.relu, p.mask_src, p.inject, p.out, p.M, p.H, p.W, s);      // (conv_wino_splits() declines planes that are no multiple of 4)
 }
 
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s) { return launch_conv3x3_wino_cfg(p, -1, s); }

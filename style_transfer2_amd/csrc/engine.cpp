@@ -21,7 +21,7 @@ const char* const kProfNames[P_COUNT] = {"conv3x3_fwd_mfma_f32", "conv3x3_dgrad_
                                           "gram_partial_mfma_f32", "gram_reduce", "style_grad_mfma_f32", "layer_elem",
                                           "image_pass", "finalize", "vector_ops", "misc", "conv3x3_fwd_wino_f32", "conv3x3_dgrad_wino_f32",
                                           "conv3x3_fwd_mfma_bf16", "conv3x3_dgrad_mfma_bf16", "tile_comm",
-                                          "gram_partial_mfma_bf16", "style_grad_mfma_bf16"};
+                                          "gram_partial_mfma_bf16", "style_grad_mfma_bf16", "conv3x3_fwd_wino_split_bf16x6", "conv3x3_dgrad_wino_split_bf16x6"};
 
 static const struct { int kind; const char* name; int cin, cout; } kVgg19[] = {
     {0, "conv1_1", 3, 64}, {0, "conv1_2", 64, 64}, {1, "pool1", 0, 0},
@@ -60,9 +60,15 @@ void dfree16(unsigned short*& p)
     if (p && hipFree(p) != hipSuccess) (void)hipGetLastError();
     p = nullptr;
 }
-int wino_scratch(st_ctx* c, ConvProblem& p)
+// does the data gradient of conv layer L at this size run on the split-operand Winograd kernel?
+static bool dgrad_takes_split(const st_ctx* c, const Layer& L, int h, int w)
 {
-    const int sp = conv_wino_splits(p.K, p.M, p.H, p.W);
+    return c->wino && c->wino_split && !c->bf16 && L.us_bwd && conv_wino_split_ok(L.cout, L.cin, h, w);
+}
+
+int wino_scratch(st_ctx* c, ConvProblem& p, bool split_kernel)
+{
+    const int sp = split_kernel ? conv_wino_split_splits(p.K, p.M, p.H, p.W) : conv_wino_splits(p.K, p.M, p.H, p.W);
     if (sp <= 1) return ST_OK;
     const size_t need = (size_t)sp * p.M * p.H * p.W;
     if (need > c->conv_scratch_cap) {
@@ -218,16 +224,18 @@ int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
                 p.in = a.data[i - 1]; p.wpack = L.w_fwd; p.bias = L.bias; p.out = a.data[i];
                 p.K = L.cin; p.M = L.cout; p.MPad = conv_mpad(L.cout); p.H = a.h[i]; p.W = a.w[i]; p.relu = 1;
                 { const bool wino = c->wino && L.u_fwd && conv_wino_ok(p.K, p.M, p.H, p.W);
-                  // flops are the ALGORITHMIC (direct-convolution) count in both classes; Winograd executes 4/9 of them
-                  ProfScope ps(c, wino ? P_CONV_FWD_WINO : P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
+                  // st_set_conv_algo(ctx, 2): the same products as six bf16 partial products of split operands where the shape allows
+                  const bool wsplit = wino && c->wino_split && !c->bf16 && L.us_fwd && conv_wino_split_ok(p.K, p.M, p.H, p.W);
+                  // flops are the ALGORITHMIC (direct-convolution) count in every class; Winograd executes 4/9 of them (the split kernel 6 x 4/9 on the bf16 pipe)
+                  ProfScope ps(c, wsplit ? P_CONV_FWD_WSPLIT : wino ? P_CONV_FWD_WINO : P_CONV_FWD, 2.0 * 9 * L.cin * L.cout * px, 4.0 * px * (L.cin + L.cout));
                   if (wino) {
-                      p.wpack = L.u_fwd; ST_TRY(wino_scratch(c, p));
+                      p.wpack = wsplit ? reinterpret_cast<const float*>(L.us_fwd) : L.u_fwd; ST_TRY(wino_scratch(c, p, wsplit));
                       // the max-pool that follows rides on this launch's epilogue (the pooled blob is written beside the conv blob)
-                      if (i < last && !c->topo[i].is_conv && !c->bf16 && conv_wino_can_pool(p.K, p.M, p.H, p.W)) {
+                      if (i < last && !c->topo[i].is_conv && !c->bf16 && (wsplit ? conv_wino_split_can_pool(p.K, p.M, p.H, p.W) : conv_wino_can_pool(p.K, p.M, p.H, p.W))) {
                           p.pool_out = a.data[i + 1]; pooled_by_conv = i + 1; a.has32[i + 1] = 1;
                           // ... and a one-byte arg-max map for the pool's backward (maxpool_bwd_amap_k: neither blob is read again)
                           const char* ae = getenv("ST2_POOL_AMAP");          // =0: the classic pool backward (read per forward: the tests compare both)
-                          if (!(ae && *ae == '0') && conv_wino_pool_amap_ok(p.K, p.M, p.H, p.W)) {
+                          if (!(ae && *ae == '0') && (wsplit ? conv_wino_split_pool_amap_ok(p.K, p.M, p.H, p.W) : conv_wino_pool_amap_ok(p.K, p.M, p.H, p.W))) {
                               // (sized like the bf16 path's map of the same blob: the buffer is shared when the precision is switched)
                               const size_t pn = act16_elems(a.C[i + 1], (size_t)a.h[i + 1] * a.w[i + 1]);
                               if (!a.amap[i + 1]) HIP_TRY(hipMalloc((void**)&a.amap[i + 1], pn));
@@ -235,9 +243,10 @@ int forward_range(st_ctx* c, ActSet& a, const float* x, int last, bool lean)
                               // lean (inside an iteration): the full-resolution blob of a pooled, un-weighted layer is dead -- the next conv
                               // reads the pooled blob, the pool's backward the arg-max map (with the ReLU sign in it) -- so it is not
                               // written (conv1_2 at 1024^2: 268 MB and a quarter of the epilogue's instructions); same values everywhere else
-                              if (lean && !c->bf16 && !blob_active(c, i) && conv_wino_can_skip_out(p.K, p.M, p.H, p.W)) { p.out = nullptr; a.has32[i] = 0; }
+                              if (lean && !c->bf16 && !blob_active(c, i) && (wsplit ? conv_wino_split_can_skip_out(p.K, p.M, p.H, p.W) : conv_wino_can_skip_out(p.K, p.M, p.H, p.W))) { p.out = nullptr; a.has32[i] = 0; }
                           }
                       }
+                      if (wsplit) HIP_TRY(launch_conv3x3_wino_split(p, c->stream)); else
                       HIP_TRY(launch_conv3x3_wino(p, c->stream));
                   }
                   else { if (next16 && L.cout % 8 == 0) { p.out16 = a.data16[i]; packed = true; }      // the epilogue writes the bf16 copy too
@@ -400,9 +409,12 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
                 if (pending_unpool && !wino_bwd) return fail(ST_ERR_STATE, "internal: an unpooling data gradient was planned for %s but the direct kernel runs", L.name.c_str());
                 p.unpool_amap = pending_unpool; pending_unpool = nullptr;
-                ProfScope ps(c, wino_bwd ? P_CONV_DGRAD_WINO : P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px,
+                const bool wsplit = wino_bwd && dgrad_takes_split(c, L, a.h[i], a.w[i]);
+                if (wsplit && p.unpool_amap) return fail(ST_ERR_STATE, "internal: an unpooling data gradient was planned for %s but the split-operand kernel runs", L.name.c_str());
+                ProfScope ps(c, wsplit ? P_CONV_DGRAD_WSPLIT : wino_bwd ? P_CONV_DGRAD_WINO : P_CONV_DGRAD, 2.0 * 9 * L.cin * L.cout * px,
                              4.0 * px * (L.cin + (p.unpool_amap ? 0.3125 : 1.0) * L.cout));
-                if (wino_bwd) { p.wpack = L.u_bwd; ST_TRY(wino_scratch(c, p)); HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
+                if (wsplit) { p.wpack = reinterpret_cast<const float*>(L.us_bwd); ST_TRY(wino_scratch(c, p, true)); HIP_TRY(launch_conv3x3_wino_split(p, c->stream)); }
+                else if (wino_bwd) { p.wpack = L.u_bwd; ST_TRY(wino_scratch(c, p, false)); HIP_TRY(launch_conv3x3_wino(p, c->stream)); }
                 else HIP_TRY(launch_conv3x3(p, c->stream));
                 cur = dst;
             }
@@ -433,7 +445,8 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
             const Layer& P = c->topo[below - 1];             // the conv that produced the pooled-from blob: its data gradient runs next
             const bool p_wino = !c->bf16 && c->wino && P.u_bwd && !(below - 1 < 1 && conv_dgrad_smallM_ok(P.cout, P.cin)) &&
                                 conv_wino_ok(P.cout, P.cin, a.h[below], a.w[below]);
-            if (p_wino && conv_wino_can_unpool(P.cout, P.cin, a.h[below], a.w[below])) {
+            // (the split-operand kernel has no unpooling input transform: its launches keep maxpool_bwd_amap_k)
+            if (p_wino && !dgrad_takes_split(c, P, a.h[below], a.w[below]) && conv_wino_can_unpool(P.cout, P.cin, a.h[below], a.w[below])) {
                 // ... inside that data gradient: it stages the pooled diff and the map and unpools in its input transform
                 // (maxpool_bwd_amap_k, its full-resolution output and the conv's read of it are gone; same values bit for bit)
                 pending_unpool = a.amap[i];
@@ -638,7 +651,7 @@ int st_destroy(st_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 2; ++i) if (c->gexec[i]) { (void)hipGraphExecDestroy(c->gexec[i]); c->gexec[i] = nullptr; }
     dfree(c->adam_dyn);
-    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree16(L.w_split); dfree(L.u_fwd); dfree(L.u_bwd); }
+    for (Layer& L : c->topo) { dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree16(L.w_split); dfree(L.u_fwd); dfree(L.u_bwd); dfree16(L.us_fwd); dfree16(L.us_bwd); }
     dfree16(c->diff16A); dfree16(c->diff16B);
     act_free(c->act);
     for (int i = 0; i < 2; ++i) dfree(c->x[i]);
@@ -680,6 +693,21 @@ int st_destroy(st_ctx* c)
     return ST_OK;
 }
 
+// the split-operand Winograd packs of one conv layer (both directions where the kernel can take them); w = (Cout, Cin, 3, 3) on the host
+static int make_split_packs(Layer& L, const float* w)
+{
+    for (int dir = 0; dir < 2; ++dir) {
+        const int K = dir ? L.cout : L.cin, M = dir ? L.cin : L.cout;
+        unsigned short** dst = dir ? &L.us_bwd : &L.us_fwd;
+        if (*dst || !conv_wino_split_ok(K, M, 4, 4)) continue;
+        std::vector<unsigned short> hu(wino_split_pack_elems(K, M), 0);
+        if (dir) pack_wino_split_weights_dgrad(w, L.cout, L.cin, hu.data()); else pack_wino_split_weights_fwd(w, L.cout, L.cin, hu.data());
+        ST_TRY(dmalloc16(dst, hu.size()));
+        HIP_TRY(hipMemcpy(*dst, hu.data(), hu.size() * 2, hipMemcpyHostToDevice));
+    }
+    return ST_OK;
+}
+
 int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const float* bias)
 {
     if (c) c->epoch++;       // anything but st_step may change what a step launches: captured step graphs are stale
@@ -692,7 +720,7 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
         pack_conv_weights_fwd(w, L.cout, L.cin, pf.data());
         pack_conv_weights_dgrad(w, L.cout, L.cin, pb.data());
         if (bias) memcpy(bp.data(), bias, L.cout * sizeof(float));
-        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree16(L.w_split); dfree(L.u_fwd); dfree(L.u_bwd);
+        dfree(L.w_fwd); dfree(L.w_bwd); dfree(L.w_raw); dfree(L.w_raw_r); dfree(L.bias); dfree16(L.w16_fwd); dfree16(L.w16_bwd); dfree16(L.w_split); dfree(L.u_fwd); dfree(L.u_bwd); dfree16(L.us_fwd); dfree16(L.us_bwd);
         for (int dir = 0; dir < 2; ++dir) {   // Winograd packs for the directions the Winograd kernel can take (any image size)
             const int K = dir ? L.cout : L.cin, M = dir ? L.cin : L.cout;
             if (!conv_wino_ok(K, M, 4, 4)) continue;
@@ -733,6 +761,7 @@ int st_load_conv_weights(st_ctx* c, const char* layer, const float* w, const flo
             HIP_TRY(hipMemcpy(L.w_raw_r, wr.data(), wr.size() * sizeof(float), hipMemcpyHostToDevice));
         }
         HIP_TRY(hipMemcpy(L.bias, bp.data(), bp.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (c->wino_split) ST_TRY(make_split_packs(L, w));
         L.loaded = true;
         return ST_OK;
     }
@@ -743,7 +772,18 @@ int st_set_conv_algo(st_ctx* c, int winograd)
 {
     if (c) c->epoch++;       // anything but st_step may change what a step launches: captured step graphs are stale
     if (!c) return fail(ST_ERR_ARG, "ctx is NULL");
+    if (winograd < 0 || winograd > 2) return fail(ST_ERR_ARG, "conv algorithm %d: 0 direct, 1 Winograd (fp32 matrix cores), 2 split-operand Winograd (bf16 matrix cores, fp32 results)", winograd);
     c->wino = winograd != 0;
+    c->wino_split = winograd == 2;
+    if (c->wino_split) {       // the packs of the layers that are loaded already (weights come back from the device copy)
+        HIP_TRY(hipSetDevice(c->device));
+        for (Layer& L : c->topo) {
+            if (!L.is_conv || !L.loaded || !L.w_raw) continue;
+            std::vector<float> w((size_t)L.cout * L.cin * 9);
+            HIP_TRY(hipMemcpy(w.data(), L.w_raw, w.size() * sizeof(float), hipMemcpyDeviceToHost));
+            ST_TRY(make_split_packs(L, w.data()));
+        }
+    }
     return ST_OK;
 }
 

@@ -35,7 +35,7 @@ int fail(int code, const char* fmt, ...);
 // --------------------------------------------------------------------------------------- profiling
 enum ProfClass { P_CONV_FWD, P_CONV_DGRAD, P_POOL_FWD, P_POOL_BWD, P_GRAM, P_GRAM_REDUCE, P_STYLE_GRAD,
                  P_LAYER_ELEM, P_IMAGE_PASS, P_FINALIZE, P_VECTOR, P_MISC, P_CONV_FWD_WINO, P_CONV_DGRAD_WINO,
-                 P_CONV_FWD_BF16, P_CONV_DGRAD_BF16, P_COMM, P_GRAM_BF16, P_STYLE_GRAD_BF16, P_COUNT };
+                 P_CONV_FWD_BF16, P_CONV_DGRAD_BF16, P_COMM, P_GRAM_BF16, P_STYLE_GRAD_BF16, P_CONV_FWD_WSPLIT, P_CONV_DGRAD_WSPLIT, P_COUNT };
 extern const char* const kProfNames[P_COUNT];
 struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
 
@@ -48,6 +48,7 @@ struct Layer {
     unsigned short *w16_fwd = nullptr, *w16_bwd = nullptr;       // bf16 packs (bf16 feature path)
     unsigned short* w_split = nullptr;                           // first layer, bf16 path: three-way bf16 split of the weights (conv3x3_first_split.hip)
     float *u_fwd = nullptr, *u_bwd = nullptr;                    // Winograd F(2x2,3x3) packs (null: not eligible)
+    unsigned short *us_fwd = nullptr, *us_bwd = nullptr;         // split-operand Winograd packs (conv3x3_wino_split.hip; made when st_set_conv_algo(ctx, 2) asks for them)
     bool loaded = false;
 };
 
@@ -77,6 +78,7 @@ struct st_ctx {
     bool lean = false;                             // bf16 objective evaluations skip the fp32 tensors only bf16 convs would read
     bool in_step = false;                          // inside step_enqueue: objective evaluations may skip fp32 blobs nothing reads (lean fp32)
     bool wino = true;                              // Winograd F(2x2,3x3) for the eligible fp32 convs (ST2_WINO=0 disables)
+    bool wino_split = false;                       // ... on the bf16 matrix cores with three-way split operands where the shape allows (st_set_conv_algo(ctx, 2))
     unsigned short *diff16A = nullptr, *diff16B = nullptr;
     std::vector<Layer> topo;
     std::vector<std::string> blob_names;
@@ -219,7 +221,7 @@ int dmalloc16(unsigned short** p, size_t n);
 void dfree16(unsigned short*& p);
 inline size_t act16_elems(int C, size_t hw) { return (size_t)((C + 7) / 8) * hw * 8; }
 inline bool conv16_ok(const st_ctx* c, int K) { (void)c; return K >= 8 && K % 8 == 0; }
-int wino_scratch(st_ctx* c, ConvProblem& p);      // room for the split-K partial sums of a Winograd launch that would otherwise leave most CUs idle
+int wino_scratch(st_ctx* c, ConvProblem& p, bool split_kernel = false);      // room for the split-K partial sums of a Winograd launch that would otherwise leave most CUs idle
 
 struct ProfScope {
     st_ctx* c; int idx = -1;

@@ -63,7 +63,21 @@ bool conv_wino_can_skip_out(int K, int M, int H, int W);   // a forward launch w
 bool conv_wino_can_pool(int K, int M, int H, int W);   // launch_conv3x3_wino may fuse the following max-pool (ConvProblem::pool_out)
 int conv_wino_splits(int K, int M, int H, int W);   // split-K factor the automatic path would use (1 = none); needs splits*M*H*W floats of scratch
 hipError_t launch_conv3x3_wino(const ConvProblem& p, hipStream_t s);
-hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s);   // 0: 128 ch x 4x32 px, 1: 64 ch x 8x32 px
+hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_t s);
+hipError_t launch_wino_combine(const float* scratch, int splits, const float* bias, int relu, const float* mask_src, const float* inject,
+                               float* out, int M, int H, int W, hipStream_t s);
+// Split-operand Winograd (conv3x3_wino_split.hip; st_set_conv_algo(ctx, 2)): the same ConvProblem, p.wpack = the split pack (bf16 triples
+// of G g G^T in A-fragment order) passed as const float*; fp32 results from six bf16 partial products per transform-domain product.
+// K % 16 == 0, M % 64 == 0, W % 4 == 0; fused pool + arg-max map + skipped blob and split-K as launch_conv3x3_wino, no unpool_amap.
+size_t wino_split_pack_elems(int K, int M);                  // bf16 elements
+void pack_wino_split_weights_fwd(const float* w, int Cout, int Cin, unsigned short* dst);
+void pack_wino_split_weights_dgrad(const float* w, int Cout, int Cin, unsigned short* dst);
+bool conv_wino_split_ok(int K, int M, int H, int W);
+int conv_wino_split_splits(int K, int M, int H, int W);
+bool conv_wino_split_can_pool(int K, int M, int H, int W);
+bool conv_wino_split_pool_amap_ok(int K, int M, int H, int W);
+bool conv_wino_split_can_skip_out(int K, int M, int H, int W);
+hipError_t launch_conv3x3_wino_split(const ConvProblem& p, hipStream_t s);   // 0: 128 ch x 4x32 px, 1: 64 ch x 8x32 px
 // conv1_1-style dgrad (tiny M): direct VALU kernel, w is the ORIGINAL (Cout,Cin,3,3) layout
 // conv1_1's data gradient on the matrix cores (conv3x3_dgrad_first.hip): Z = A @ dy (1x1, 9 M rows) + 9 M shifted adds; Cin <= 3
 bool conv_dgrad_first_ok(int Cout, int Cin, int H, int W, bool bf16);

@@ -80,8 +80,9 @@ class Engine:
         return n.value
 
     def set_conv_algo(self, winograd):
-        """True (default): eligible fp32 convs run as Winograd F(2x2,3x3); False: direct kernel only."""
-        check(self.lib.st_set_conv_algo(self._ctx, 1 if winograd else 0))
+        """True / 1 (default): eligible fp32 convs run as Winograd F(2x2,3x3) on the fp32 matrix cores; False / 0: direct kernel only;
+        2: Winograd with the transform-domain products as six bf16 partial products of split operands (fp32 results) where the shape allows."""
+        check(self.lib.st_set_conv_algo(self._ctx, 2 if winograd == 2 else (1 if winograd else 0)))
 
     # -- lifecycle -------------------------------------------------------------------------------
     def close(self):

@@ -10,7 +10,8 @@ CPU by tests/test_oracle_golden.py::test_stored_oracle_trajectories_are_what_the
              (tests/test_gpu_parity.py::test_config1_golden_gate_starry_night_256px_adam_iters)
   size_*     the same pair fitted to 1024 px (content 768 x 1024), iterate-like initial image, L-BFGS step 1 (round 5): the per-step
              losses of the fp32 oracle over five steps and of the ROUNDED-OPERAND oracle (bf16 conv operands) over three, scalars
-             only, plus the fp32 oracle's fifth iterate rounded to uint8 (its quantisation adds 1/12 to an MSE whose bar is 45)
+             only, plus every fourth pixel (both directions) of the fp32 oracle's fifth iterate: the image MSE the test bounds (bar: 5 % of
+             a move of ~900, measured 0.13) is taken over that sample
              (tests/test_gpu_fullsize.py::test_image_like_job_*_follows_the_*oracle*)
 
 Run here: python tests/golden/make_trajectories.py [drift] [config1] [size]   (no argument: all three; a part that is not named
@@ -96,7 +97,7 @@ if __name__ == '__main__':
     if 'size' in parts:
         ls32, is32 = drift_run('fp32', 5, fit=1024)
         ls16, _ = drift_run('bf16', 3, fit=1024)
-        data.update(size_losses_fp32=ls32, size_losses_bf16=ls16, size_final_fp32_u8=np.clip(np.rint(is32), 0, 255).astype(np.uint8),
-                    size_final_fp32_clipped_frac=np.float64(np.mean((is32 < -0.5) | (is32 > 255.5))))
+        data.pop('size_final_fp32_u8', None); data.pop('size_final_fp32_clipped_frac', None)
+        data.update(size_losses_fp32=ls32, size_losses_bf16=ls16, size_final_fp32_sub4=np.ascontiguousarray(is32[::4, ::4, :]))
         print('size fp32', ls32, '\nbf16', ls16)
     np.savez_compressed(path, **data)

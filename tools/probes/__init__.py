@@ -19,6 +19,7 @@ PROTOTYPES = {
     'st_bench_wino_probe': (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_double)]),
     'st_probe_wino_split': (c_int, [c_int] * 7 + [POINTER(c_double)] * 6),
     'st_probe_wino_split_error': (c_char_p, []),
+    'st_probe_wino_split_product': (c_int, [c_int] * 8 + [POINTER(c_double)] * 6),
     'st_probe_valu_rate': (c_int, [c_int, c_int, c_int, c_int, POINTER(c_double)]),
 }
 

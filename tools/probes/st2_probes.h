@@ -38,6 +38,10 @@ int st_bench_conv16(int device_id, int K, int M, int H, int W, int mode, int ite
 int st_probe_wino_split(int device_id, int K, int M, int H, int W, int iters, int check, double* avg_ms, double* rel_l2,
                         double* loop_cycles, double* clock_mhz, double* pro_cycles, double* epi_cycles);
 const char* st_probe_wino_split_error(void);
+/* the product kernel (conv3x3_wino_split.hip) through launch_conv3x3_wino_split: mode 0 forward, 1 data gradient, 2 forward + fused pool + map,
+ * 3 = 2 without the blob; check: forward against a CPU loop nest */
+int st_probe_wino_split_product(int device_id, int K, int M, int H, int W, int iters, int mode, int check, double* avg_ms, double* rel_l2,
+                                double* loop_cycles, double* clock_mhz, double* pro_cycles, double* epi_cycles);
 /* shader cycles per group of nv VALU instructions of one kind (see wino_split_probe.hip), optionally behind a bf16 MFMA each */
 int st_probe_valu_rate(int device_id, int kind, int nv, int with_mfma, double* cycles_per_group);
 #ifdef __cplusplus

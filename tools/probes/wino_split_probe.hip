@@ -650,3 +650,138 @@ extern "C" int st_probe_valu_rate(int device_id, int kind, int nv, int with_mfma
     (void)hipFree(out); (void)hipFree(cyc);
     return 0;
 }
+
+// ---- the PRODUCT kernel (style_transfer2_amd/csrc/conv3x3_wino_split.hip) through its launcher: timing, stamps, check of the forward ----
+#include "../../style_transfer2_amd/csrc/st2_kernels.h"
+// mode: 0 forward (bias + ReLU), 1 data gradient (ReLU mask + injected diff), 2 forward + fused pool + arg-max map, 3 = 2 without the blob
+extern "C" int st_probe_wino_split_product(int device_id, int K, int M, int H, int W, int iters, int mode, int check, double* avg_ms, double* rel_l2,
+                                           double* loop_cycles, double* clock_mhz, double* pro_cycles, double* epi_cycles)
+{
+    using namespace st2;
+    if (!conv_wino_split_ok(K, M, H, W) || iters <= 0) { snprintf(g_err, sizeof g_err, "shape not supported"); return 1; }
+    WS_TRY(hipSetDevice(device_id));
+    const size_t n_in = (size_t)K * H * W, n_out = (size_t)M * H * W;
+    std::vector<float> w((size_t)M * K * 9), hin(n_in), hb(M);
+    uint32_t st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& x : w) x = rnd() * 0.05f;
+    for (auto& x : hin) x = rnd();
+    for (auto& x : hb) x = rnd() * 0.1f;
+    std::vector<unsigned short> pk(wino_split_pack_elems(K, M), 0);
+    const int want = mode >= 4 ? mode - 4 : 3;      // modes 4 .. 7: data gradient with bit 0 = mask, bit 1 = inject
+    if (mode >= 4) mode = 1;
+    if (mode == 1) pack_wino_split_weights_dgrad(w.data(), K, M, pk.data()); else pack_wino_split_weights_fwd(w.data(), M, K, pk.data());
+    float *din = nullptr, *db = nullptr, *dout = nullptr, *dmask = nullptr, *dinj = nullptr, *dpool = nullptr;
+    unsigned char* damap = nullptr;
+    void* dpk = nullptr;
+    unsigned long long* dst = nullptr;
+    WS_TRY(hipMalloc((void**)&din, n_in * 4)); WS_TRY(hipMalloc((void**)&db, M * 4)); WS_TRY(hipMalloc((void**)&dout, n_out * 4));
+    WS_TRY(hipMalloc(&dpk, pk.size() * 2));
+    WS_TRY(hipMemcpy(din, hin.data(), n_in * 4, hipMemcpyHostToDevice));
+    WS_TRY(hipMemcpy(db, hb.data(), M * 4, hipMemcpyHostToDevice));
+    WS_TRY(hipMemcpy(dpk, pk.data(), pk.size() * 2, hipMemcpyHostToDevice));
+    ConvProblem p{};
+    p.in = din; p.wpack = (const float*)dpk; p.bias = mode == 1 ? nullptr : db; p.out = dout; p.K = K; p.M = M; p.H = H; p.W = W; p.relu = mode == 1 ? 0 : 1;
+    if (mode == 1) {
+        WS_TRY(hipMalloc((void**)&dmask, n_out * 4)); WS_TRY(hipMalloc((void**)&dinj, n_out * 4));
+        for (size_t off = 0; off < n_out; off += n_in) {
+            const size_t n = std::min(n_in, n_out - off);
+            WS_TRY(hipMemcpy(dmask + off, din, n * 4, hipMemcpyDeviceToDevice)); WS_TRY(hipMemcpy(dinj + off, din, n * 4, hipMemcpyDeviceToDevice));
+        }
+        p.mask_src = (want & 1) ? dmask : nullptr; p.inject = (want & 2) ? dinj : nullptr;
+    }
+    if (mode >= 2) {
+        const size_t np = (size_t)M * ((H + 1) / 2) * ((W + 1) / 2);
+        WS_TRY(hipMalloc((void**)&dpool, np * 4)); WS_TRY(hipMalloc((void**)&damap, np));
+        p.pool_out = dpool; p.pool_amap = damap;
+        if (mode == 3) p.out = nullptr;
+    }
+    const int blocks = ((W + 31) / 32) * ((H + 7) / 8) * (M / 64);
+    hipStream_t s;
+    WS_TRY(hipStreamCreate(&s));
+    hipEvent_t e0, e1;
+    WS_TRY(hipEventCreate(&e0)); WS_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) WS_TRY(launch_conv3x3_wino_split(p, s));
+    WS_TRY(hipStreamSynchronize(s));
+    WS_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) (void)launch_conv3x3_wino_split(p, s);
+    WS_TRY(hipEventRecord(e1, s));
+    WS_TRY(hipStreamSynchronize(s));
+    float ms = 0.f;
+    WS_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (avg_ms) *avg_ms = ms / iters;
+    if (rel_l2) *rel_l2 = -1.0;
+    if (check && mode == 0) {
+        std::vector<float> hout(n_out);
+        WS_TRY(hipMemcpy(hout.data(), dout, n_out * 4, hipMemcpyDeviceToHost));
+        double num = 0, den = 0;
+        for (int m = 0; m < M; ++m)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    double s2 = hb[m];
+                    for (int k = 0; k < K; ++k)
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int yy = y + dy - 1;
+                            if (yy < 0 || yy >= H) continue;
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const int xx = x + dx - 1;
+                                if (xx < 0 || xx >= W) continue;
+                                s2 += (double)w[((size_t)m * K + k) * 9 + dy * 3 + dx] * hin[((size_t)k * H + yy) * W + xx];
+                            }
+                        }
+                    if (s2 < 0) s2 = 0;
+                    const double d = (double)hout[((size_t)m * H + y) * W + x] - s2;
+                    num += d * d; den += s2 * s2;
+                }
+        if (rel_l2) *rel_l2 = sqrt(num / std::max(den, 1e-300));
+    }
+    if (check && mode == 1) {      // data gradient: out[m] = (mask > 0 ? sum_k sum_taps w[k][m][8 - tap] in[k] : 0) + inject   (K = Cout, M = Cin of w)
+        std::vector<float> hout(n_out), hm(n_out);
+        WS_TRY(hipMemcpy(hout.data(), dout, n_out * 4, hipMemcpyDeviceToHost));
+        WS_TRY(hipMemcpy(hm.data(), dmask, n_out * 4, hipMemcpyDeviceToHost));
+        double num = 0, den = 0;
+        for (int m = 0; m < M; ++m)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    double s2 = 0;
+                    for (int k = 0; k < K; ++k)
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int yy = y + dy - 1;
+                            if (yy < 0 || yy >= H) continue;
+                            for (int dx = 0; dx < 3; ++dx) {
+                                const int xx = x + dx - 1;
+                                if (xx < 0 || xx >= W) continue;
+                                s2 += (double)w[((size_t)k * M + m) * 9 + (8 - (dy * 3 + dx))] * hin[((size_t)k * H + yy) * W + xx];
+                            }
+                        }
+                    const size_t o = ((size_t)m * H + y) * W + x;
+                    if ((want & 1) && !(hm[o] > 0)) s2 = 0;
+                    if (want & 2) s2 += hm[o];                      // inject = the same data as the mask
+                    const double d = (double)hout[o] - s2;
+                    num += d * d; den += s2 * s2;
+                }
+        if (rel_l2) *rel_l2 = sqrt(num / std::max(den, 1e-300));
+    }
+    if (mode <= 1) {       // stamped launches (one pass, blob written)
+        WS_TRY(hipMalloc((void**)&dst, (size_t)blocks * 64));
+        WS_TRY(hipMemset(dst, 0, (size_t)blocks * 64));
+        p.stamps = dst;
+        for (int i = 0; i < 3; ++i) WS_TRY(launch_conv3x3_wino_split(p, s));
+        WS_TRY(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)blocks * 8);
+        WS_TRY(hipMemcpy(h.data(), dst, (size_t)blocks * 64, hipMemcpyDeviceToHost));
+        std::vector<double> cyc, clk, pro, epi;
+        for (int b = 0; b < blocks; ++b) {
+            const unsigned long long* q = &h[8 * b];
+            if (q[4] > q[2]) { cyc.push_back((double)(q[3] - q[1])); clk.push_back((double)(q[3] - q[1]) / (double)(q[4] - q[2]) * 100.0); pro.push_back((double)(q[1] - q[0])); epi.push_back((double)(q[5] - q[3])); }
+        }
+        auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        if (loop_cycles) *loop_cycles = med(cyc);
+        if (clock_mhz) *clock_mhz = med(clk);
+        if (pro_cycles) *pro_cycles = med(pro);
+        if (epi_cycles) *epi_cycles = med(epi);
+    }
+    (void)hipFree(din); (void)hipFree(db); (void)hipFree(dout); (void)hipFree(dpk); (void)hipFree(dst); (void)hipFree(dmask); (void)hipFree(dinj); (void)hipFree(dpool); (void)hipFree(damap);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(s);
+    return 0;
+}
