@@ -21,7 +21,8 @@ const char* const kProfNames[P_COUNT] = {"conv3x3_fwd_mfma_f32", "conv3x3_dgrad_
                                           "gram_partial_mfma_f32", "gram_reduce", "style_grad_mfma_f32", "layer_elem",
                                           "image_pass", "finalize", "vector_ops", "misc", "conv3x3_fwd_wino_f32", "conv3x3_dgrad_wino_f32",
                                           "conv3x3_fwd_mfma_bf16", "conv3x3_dgrad_mfma_bf16", "tile_comm",
-                                          "gram_partial_mfma_bf16", "style_grad_mfma_bf16", "conv3x3_fwd_wino_split_bf16x6", "conv3x3_dgrad_wino_split_bf16x6"};
+                                          "gram_partial_mfma_bf16", "style_grad_mfma_bf16", "conv3x3_fwd_wino_split_bf16x6", "conv3x3_dgrad_wino_split_bf16x6",
+                                          "style_grad_fused_in_conv_dgrad_bf16"};
 
 static const struct { int kind; const char* name; int cin, cout; } kVgg19[] = {
     {0, "conv1_1", 3, 64}, {0, "conv1_2", 64, 64}, {1, "pool1", 0, 0},
@@ -395,7 +396,8 @@ int backward_chain(st_ctx* c, int top, const float* top_diff, const std::vector<
                 if (lean && below16) p.out = nullptr;
                 p.K = L.cout; p.M = L.cin; p.MPad = conv_mpad(L.cin); p.H = a.h[i]; p.W = a.w[i]; p.relu = 0;
                 p.unpool_amap = pending_unpool; pending_unpool = nullptr;      // cur16 is the POOLED diff then (3/4 byte per pooled channel value more, 1.5 less per full one)
-                ProfScope ps(c, P_CONV_DGRAD_BF16, 2.0 * 9 * L.cin * L.cout * px + (fused ? 2.0 * L.cin * L.cin * px : 0.0),
+                if (fused) prof_note(c, P_STYLE_FUSED_BF16, 2.0 * L.cin * L.cin * px);      // (extra K chunks of the launch below; its own flops stay SURVEY 8(d)'s)
+                ProfScope ps(c, P_CONV_DGRAD_BF16, 2.0 * 9 * L.cin * L.cout * px,
                              px * ((p.unpool_amap ? 0.75 : 2.0) * L.cout + (fused ? 2.0 : 0.0) * L.cin + (p.out ? 4.0 : 0.0) * L.cin + (p.out16 ? 2.0 : 0.0) * L.cin + (mask_src ? (p.mask_bits ? 0.125 : p.mask16 ? 2.0 : 4.0) : 0.0) * L.cin));
                 HIP_TRY(launch_conv3x3_bf16(p, c->stream));
                 cur16 = below16 ? dst16 : nullptr;

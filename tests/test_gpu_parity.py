@@ -472,8 +472,8 @@ def test_full_size_1024_properties():
 def test_config1_golden_gate_starry_night_256px_adam_iters():
     """configs[0]: examples/golden_gate.jpg + starry_night.jpg resized by the reference's resize_to_fit to
     fit 256 (192x256 content, 160x256 style; fixture tests/golden/config1_inputs.npz), VGG19 (seeded
-    synthetic weights), initial_weights.yaml losses, Adam step 10: HIP engine vs CPU oracle, the first 30 of the 50 iterations
-    (`bench.py --examples` runs all 50 with the oracle timed beside the device and compares the final images).
+    synthetic weights), initial_weights.yaml losses, Adam step 10: HIP engine vs CPU oracle, all 50 iterations (round 5; 30 until
+    round 4; `bench.py --examples` runs them with the oracle timed beside the device).
     Tight bar on the per-step loss while the trajectories coincide, loose image bar (Adam is sign-like)."""
     g = np.load(__import__('os').path.join(__import__('helpers').GOLDEN, 'config1_inputs.npz'))
     content, style = g['golden_gate'], g['starry_night']
@@ -483,7 +483,7 @@ def test_config1_golden_gate_starry_night_256px_adam_iters():
     weights = {'content': {'conv4_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1, 'conv4_1': 1},
                'deepdream': {}}
     params4 = {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2}
-    # the oracle's 30 iterations are stored (tests/golden/make_trajectories.py: oracle.TransferOracle on these very inputs;
+    # the oracle's 50 iterations are stored (tests/golden/make_trajectories.py: oracle.TransferOracle on these very inputs;
     # tests/test_oracle_golden.py re-runs the first ones on the CPU)
     traj = __import__('helpers').load('oracle_trajectories.npz')
     lc, ic = list(traj['config1_losses']), traj['config1_final']
@@ -494,7 +494,8 @@ def test_config1_golden_gate_starry_night_256px_adam_iters():
     dev.optimizer_cls = st2.AdamOptimizer; dev.set_step_size(10); dev.reset()
     assert dev.start()
     ld = []
-    for i in range(30):
+    assert len(lc) == 50
+    for i in range(50):
         idv, td = dev.step()
         ld.append(td['loss'])
         if i == 0:

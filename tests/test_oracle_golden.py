@@ -158,4 +158,8 @@ def test_stored_oracle_trajectories_are_what_the_oracle_computes():
     for k, v in zip(keys, vals):
         if k != 'time':
             assert np.isclose(v, stored[k], rtol=1e-6), (k, v, stored[k])
-    assert len(g['drift_losses_fp32']) == 11 and len(g['config1_losses']) == 30 and g['drift_final_bf16'].shape == (192, 256, 3)
+    assert len(g['drift_losses_fp32']) == 11 and len(g['config1_losses']) == 50 and g['drift_final_bf16'].shape == (192, 256, 3)
+    # the 768 x 1024 part (round 5): its first L-BFGS step (two objective evaluations at size, ~25 s here)
+    ls, _ = mk.drift_run('fp32', 1, fit=1024)
+    assert np.allclose(ls, g['size_losses_fp32'][:1], rtol=1e-6, atol=0), (ls, g['size_losses_fp32'][:1])
+    assert len(g['size_losses_fp32']) == 5 and len(g['size_losses_bf16']) == 3 and g['size_final_fp32_sub4'].shape == (192, 256, 3)
