@@ -232,8 +232,9 @@ int st_tile_plan(st_ctx* ctx, int phase, int n_peers, const st_tile_peer* peers)
  * apply s = -step * H g to the tile -> apron refresh exchange -> the evaluation above with the combined gradient in place of the Adam
  * update -> ONE all-reduce of this step's 2 (2 k + 3) new inner products -> the s.y > 1e-10 gate, eviction and the next coefficients,
  * identically on every rank.  The first step after a reset evaluates twice (optimizers.py:64-65).
- * trace: st_trace_len(ctx) values, the layout of st_step's; NULL: nothing is read back, the call does not wait for the GPU, and the
- * all-reduce that only the trace needs (the image-space sums) is not issued -- every rank must then pass NULL for that iteration. */
+ * trace: st_trace_len(ctx) values, the layout of st_step's; NULL: nothing is read back and the call does not wait for the GPU.  The
+ * collective sequence is the same either way (round 5: the few KB of image-space sums that only the trace reads are reduced on every
+ * call), so ranks may choose NULL independently of each other. */
 int st_tile_step(st_ctx* ctx, double* trace);
 int st_tile_get_tile(st_ctx* ctx, float* out_hwc);                           /* this rank's tile of the current iterate, (th, tw, 3) deprocessed */
 

@@ -397,10 +397,13 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     const unsigned bits_bytes = (unsigned)(a.M >> 5) * plane * 4u;
     const __amdgpu_buffer_rsrc_t rs_mb = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask_bits, 0, has_bits ? bits_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ob = __builtin_amdgcn_make_buffer_rsrc((void*)a.bits_out, 0, bits_out ? bits_bytes : 0u, 0x00020000);
-    auto load_bits = [&](int i, unsigned (&mb)[TN]) {            // word j: bit 8 h + e keeps acc[i][j][8 h + e]  (a padding group reads out of range: 0)
+    // (the group offset travels in the SCALAR offset, which the hardware's range check leaves out: a padding group -- M % 64 == 32 --
+    // must be kept off the buffer explicitly, or its accesses land `plane * 4` bytes past the map; wave-uniform test)
+    const unsigned n_groups = (unsigned)a.M >> 5;
+    auto load_bits = [&](int i, unsigned (&mb)[TN]) {            // word j: bit 8 h + e keeps acc[i][j][8 h + e]  (a padding group: 0)
         const unsigned blk = (unsigned)(m0 + wave_m * (TM * 32) + i * 32) >> 5;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mb[j] = __builtin_amdgcn_raw_buffer_load_b16(rs_mb, pixj[j] * 4u + 2u * khalf, blk * plane * 4u, 0);
+        for (int j = 0; j < TN; ++j) mb[j] = blk < n_groups ? __builtin_amdgcn_raw_buffer_load_b16(rs_mb, pixj[j] * 4u + 2u * khalf, blk * plane * 4u, 0) : 0u;
     };
     if (fuse_style) {
         // ---- fused style gradient (worker.py:262-269 behind the ranged backward of :100-106): this launch's output is the diff of a
@@ -641,8 +644,9 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                     }
                 }
             }
-            if (bits_out) {                                      // (M % 32 == 0 on this path: the 32-channel group is whole or padding -- out of range, dropped)
-                const unsigned blk = (unsigned)(m0 + wave_m * (TM * 32) + i * 32) >> 5;
+            const unsigned blk_o = (unsigned)(m0 + wave_m * (TM * 32) + i * 32) >> 5;
+            if (bits_out && blk_o < n_groups) {                   // (M % 32 == 0 on this path: the 32-channel group is whole, or padding and skipped)
+                const unsigned blk = blk_o;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {                   // lane ^ 32 holds the other 16-bit word of the same pixel: one dword store per pixel
                     const auto sw = __builtin_amdgcn_permlane32_swap(obits[j], obits[j], false, false);

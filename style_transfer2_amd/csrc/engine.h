@@ -203,6 +203,8 @@ struct st_ctx {
         bool self_via_rccl = false;                // test hook (ST2_COMM_SELF_VIA_RCCL=1): copies to the own rank travel through RCCL too
         float* ring = nullptr; size_t ring_cap = 0;
         long long steps = 0;
+        std::vector<float> h1, h2, h3, hd, hn;     // host side of a traced step (sized once: no allocation per step)
+        float *tile_chw = nullptr, *tile_hwc = nullptr; size_t tile_cap = 0;      // st_tile_get_tile's staging (kept across calls)
     } comm;
     // profiling
     bool prof_on = false;

@@ -64,6 +64,7 @@ void comm_free(st_ctx* c)
         plan.clear();
     }
     dfree(m.ring); m.ring_cap = 0;
+    dfree(m.tile_chw); dfree(m.tile_hwc); m.tile_cap = 0;
     if (m.comm && g_rccl.destroy) (void)g_rccl.destroy(m.comm);
     m.comm = nullptr;
     m.ar = nullptr; m.ex = nullptr; m.user = nullptr;
@@ -241,7 +242,13 @@ int st_comm_init(st_ctx* c, const char id[ST_COMM_ID_BYTES], int rank, int world
                 int ok = 1;
                 if (d != c->device && hipDeviceCanAccessPeer(&ok, c->device, d) == hipSuccess && !ok) ++unreachable;
             }
-            if (unreachable) fprintf(stderr, "st_comm_init: device %d has no direct peer access to %d of the %d visible devices (RCCL will stage through host memory)\n", c->device, unreachable, ndev - 1);
+            if (unreachable) {
+                // ST2_REQUIRE_PEER_ACCESS=1: a job that must not run through host staging fails here, on every rank that sees it, before the
+                // first collective (default: a line on stderr -- the job is correct either way)
+                const char* req = getenv("ST2_REQUIRE_PEER_ACCESS");
+                if (req && *req == '1') { (void)hipGetLastError(); return fail(ST_ERR_STATE, "device %d has no direct peer access to %d of the %d visible devices and ST2_REQUIRE_PEER_ACCESS=1", c->device, unreachable, ndev - 1); }
+                fprintf(stderr, "st_comm_init: device %d has no direct peer access to %d of the %d visible devices (RCCL will stage through host memory)\n", c->device, unreachable, ndev - 1);
+            }
         }
         (void)hipGetLastError();
     }
@@ -348,9 +355,12 @@ static int tile_evaluate(st_ctx* c, bool adam, TileEval& e, bool want_trace)
     ST_TRY(comm_exchange(c, ST_TILE_PLAN_RING, c->x[c->cur], wh, ww, c->comm.ring, th + 2, tw + 2, false));
     if (adam) ST_TRY(st_tile_update(c, c->comm.ring, &e.p3, &e.n3));            // phase 4: TV / p-norm / Adam on the tile
     else ST_TRY(st_tile_gradient(c, c->comm.ring, &e.p3, &e.n3));               //          or the combined gradient only
-    // the image-space sums (and, in steady state, the style-gradient sums) feed the TRACE only: a caller that reads nothing back
-    // (st_tile_step(ctx, NULL), the device loop of a headless job) saves this collective -- one all-reduce per Adam iteration remains
-    if (want_trace) ST_TRY(comm_allreduce(c, e.p3, e.n3));
+    // the image-space sums (and, in steady state, the style-gradient sums) feed the TRACE only.  They are reduced on EVERY call all the
+    // same (a few KB; until round 4 a caller that passed trace == NULL skipped this collective: ranks that disagreed on NULL for one
+    // iteration then desynchronised the collective sequence and RCCL hung instead of failing) -- trace == NULL now only means that
+    // nothing is read back and nothing waits for the GPU
+    (void)want_trace;
+    ST_TRY(comm_allreduce(c, e.p3, e.n3));
     return ST_OK;
 }
 
@@ -359,7 +369,10 @@ static int tile_read_trace(st_ctx* c, const TileEval& e, double* trace)
 {
     int n_style = 0;
     for (const ActiveLayer& al : c->active) n_style += al.s;
-    std::vector<float> h1(std::max(e.n1, 1)), h2(std::max(n_style, 1)), h3(6 + kMaxTraceLayers), hd(std::max(n_style, 1)), hn((size_t)c->nb * 3);
+    std::vector<float> &h1 = c->comm.h1, &h2 = c->comm.h2, &h3 = c->comm.h3, &hd = c->comm.hd, &hn = c->comm.hn;      // (kept in the context: grown, never shrunk)
+    auto room = [](std::vector<float>& v, size_t n) { if (v.size() < n) v.resize(n); };
+    room(h1, (size_t)std::max(e.n1, 1)); room(h2, (size_t)std::max(std::max(n_style, e.n2), 1)); room(h3, (size_t)std::max(6 + kMaxTraceLayers, e.n3));
+    room(hd, (size_t)std::max(n_style, 1)); room(hn, (size_t)c->nb * 3);
     if (e.n1) HIP_TRY(hipMemcpyAsync(h1.data(), e.p1, (size_t)e.n1 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     if (e.n2) HIP_TRY(hipMemcpyAsync(h2.data(), e.p2, (size_t)e.n2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(h3.data(), e.p3, (size_t)e.n3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -464,17 +477,21 @@ int st_tile_get_tile(st_ctx* c, float* out_hwc)
     const st_ctx::Tile& t = c->tile;
     const int th = t.ty1 - t.ty0, tw = t.tx1 - t.tx0;
     const size_t n = (size_t)3 * th * tw;
-    float *chw = nullptr, *hwc = nullptr;
-    ST_TRY(dmalloc(&chw, n));
-    int rc = dmalloc(&hwc, n);
-    if (rc == ST_OK) {
+    if (n > c->comm.tile_cap) {          // staging kept in the context (two device allocations per call until round 4)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dfree(c->comm.tile_chw); dfree(c->comm.tile_hwc); c->comm.tile_cap = 0;
+        ST_TRY(dmalloc(&c->comm.tile_chw, n)); ST_TRY(dmalloc(&c->comm.tile_hwc, n));
+        c->comm.tile_cap = n;
+    }
+    float *chw = c->comm.tile_chw, *hwc = c->comm.tile_hwc;
+    int rc = ST_OK;
+    {
         std::vector<int> rect = {t.ty0 - t.wy0, t.tx0 - t.wx0, th, tw};
         rc = strips(c, c->x[c->cur], 3, c->H, c->W, rect, chw, 0);
     }
     if (rc == ST_OK && launch_deprocess(chw, hwc, th, tw, c->stream) != hipSuccess) rc = fail(ST_ERR_HIP, "deprocess launch failed");
     if (rc == ST_OK && hipMemcpyAsync(out_hwc, hwc, n * sizeof(float), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail(ST_ERR_HIP, "tile copy failed");
     if (hipStreamSynchronize(c->stream) != hipSuccess && rc == ST_OK) rc = fail(ST_ERR_HIP, "tile copy failed");
-    dfree(chw); dfree(hwc);
     return rc;
 }
 

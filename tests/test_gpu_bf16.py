@@ -373,6 +373,32 @@ def test_sign_map_relu_masks_equal_the_bf16_copy_masks_bit_for_bit(size, conv16_
         assert la == lb and np.array_equal(ia, ib)
 
 
+@pytest.mark.parametrize('size', [(96, 128), (75, 100)])
+def test_sign_maps_of_layers_whose_width_is_32_mod_64_stay_inside_their_buffer(size, monkeypatch):
+    """Channel counts of 32 and 96 (M % 64 == 32: the 64-channel tile's second 32-channel group is padding).  The sign-map store and load
+    put the group offset in the buffer instruction's SCALAR offset, which the hardware's range check leaves out: until round 5 the
+    padding group wrote / read H * W * 4 bytes past the map (advisor finding r4; VGG19's widths are multiples of 64, so nothing showed).
+    Guarded now (conv3x3_mfma_bf16.hip: n_groups); this holds the ST2_MASK_BITS=1 / =0 flows to the same bits on such a topology, which
+    they were not guaranteed to be while the padding group's stray load could pick up a neighbour's bytes."""
+    topo = (('conv', 'conv1_1', 3, 32), ('conv', 'conv1_2', 32, 96), ('pool', 'pool1'), ('conv', 'conv2_1', 96, 96), ('conv', 'conv2_2', 96, 32),
+            ('pool', 'pool2'), ('conv', 'conv3_1', 32, 64))
+    params = oracle.he_init_weights(topo, seed=2, bias_std=0.2)
+    weights = {'content': {'conv2_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1}, 'deepdream': {}}
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('ST2_MASK_BITS', flag)
+        job = _bf16_job('bf16', size, weights, 'adam', topo=topo, params=params)
+        first = job.opfunc()
+        second = job.opfunc()
+        steps = [job.step() for _ in range(2)]
+        out[flag] = (first[0], first[1].copy(), second[0], second[1].copy(), [(t['loss'], i.copy()) for i, t in steps])
+    a, b = out['1'], out['0']
+    assert np.isfinite(a[0]) and a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and np.array_equal(a[3], b[3])
+    for (la, ia), (lb, ib) in zip(a[4], b[4]):
+        assert la == lb and np.array_equal(ia, ib)
+
+
 @pytest.mark.parametrize('size', [(512, 512), (75, 100), (131, 380), (40, 127)])
 def test_strip_walking_first_layer_data_gradient_equals_the_tile_kernel_bit_for_bit(size, monkeypatch):
     """conv1_1's data gradient on the bf16 path (64 -> 3 channels: Z = A @ dy on the matrix cores, then 27 shifted adds): the strip
