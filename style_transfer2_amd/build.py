@@ -46,6 +46,12 @@ def _hipcc():
     return path
 
 
+def _experiment_flags(src):
+    """ST2_WS_VAR=n: the what-bounds-the-loop variants of conv3x3_wino_split.hip (development only; results are wrong)."""
+    v = os.environ.get('ST2_WS_VAR')
+    return ['-DWS_VAR=' + v] if (v and src == 'conv3x3_wino_split.hip') else []
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -66,7 +72,7 @@ def build_lib(force=False, verbose=False):
         objs.append(o)
         if force or _stale(o, [s] + headers + [os.path.abspath(__file__)]):
             cmd = [hipcc, '-O3', '-std=c++17', '--offload-arch=' + ARCH, '-fPIC',
-                   '-Wall', '-Wno-unused-result'] + list(extra) + ['-c', s, '-o', o]
+                   '-Wall', '-Wno-unused-result'] + list(extra) + _experiment_flags(src) + ['-c', s, '-o', o]
             jobs.append(cmd)
 
     def run(cmd):

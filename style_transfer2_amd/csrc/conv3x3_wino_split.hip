@@ -97,6 +97,14 @@ __device__ __forceinline__ void ws_dma16(const ws_i32x4& rsrc, unsigned lds_addr
 {
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
+// ... with an instruction offset, which the hardware adds to the memory address AND to the LDS address: the pieces of one ring slot
+// differ by 1 KiB on both sides, so one M0 / scalar-offset pair serves four of them
+template <int OFF>
+__device__ __forceinline__ void ws_dma16_at(const ws_i32x4& rsrc, unsigned lds_addr, unsigned voff, unsigned soff)
+{
+    static_assert(OFF >= 0 && OFF < 4096, "12-bit instruction offset");
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen offset:%4 lds" :: "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF) : "memory");
+}
 __device__ __forceinline__ ws_i32x4 ws_rsrc(const void* p, unsigned bytes)
 {
     const unsigned long long a = (unsigned long long)p;
@@ -109,6 +117,11 @@ template <int I> __device__ __forceinline__ void ws_set(uint4& v, unsigned x)
     if constexpr (I == 0) v.x = x; else if constexpr (I == 1) v.y = x; else if constexpr (I == 2) v.z = x; else v.w = x;
 }
 #define WS_INL __attribute__((always_inline))
+// what-bounds-the-loop experiments (results wrong; never in a committed build): 1 = no U refills / A fetches in the loop, 2 = no B builds,
+// 4 = no raw reads / row transform.  Built by hand: hipcc -DWS_VAR=n (tools/probes/wino_split_var.sh)
+#ifndef WS_VAR
+#define WS_VAR 0
+#endif
 template <int N> using WsI = std::integral_constant<int, N>;
 
 // NOOUT: forward launches with the fused pool AND its arg-max map that do not write the full-resolution blob (conv3x3_winograd.hip)
@@ -174,20 +187,40 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
 
     const unsigned u_lane = (unsigned)lane * 16u;
     const unsigned u_base = (unsigned)(((mt * a.nch + c_first) * 16 + 4 * wave) * 6 * 64 * 16);      // wave-uniform
-    auto dma_u_one = [&](int c, int j, int q) WS_INL {           // piece q of position j of chunk c -> slot j
-        ws_dma16(rs_u, lds_u + (unsigned)(((j * 4 + wave) * 6 + q) * 1024), u_lane, u_base + (unsigned)(((c * 16 + j) * 6 + q) * 1024));
+    // piece q of position j of chunk c -> slot j: M0 = the slot's LDS address (+ 4 KiB for pieces 4, 5), scalar offset = the fragment's
+    // place in the pack, both wave-uniform; the piece index travels in the instruction offset
+    auto dma_u_one = [&](int c, int j, auto q_t) WS_INL {
+        constexpr int q = decltype(q_t)::value;
+        const unsigned dst = lds_u + (unsigned)((j * 4 + wave) * 6 * 1024), so = u_base + (unsigned)((c * 16 + j) * 6 * 1024);
+        ws_dma16_at<(q & 3) * 1024>(rs_u, dst + (q >> 2) * 4096, u_lane, so + (q >> 2) * 4096);
     };
     uint4 aop[2][6];                     // A operands of the current / next position: [m group * 3 + split]
-    auto a_fetch_one = [&](int j, int set, int q) WS_INL { aop[set][q] = u_s[((j * 4 + wave) * 6 + q) * 64 + lane]; };
+    // (one LDS base per ring slot, the piece in the instruction's offset: no address arithmetic in the loop)
+    const uint4* ubase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ubase[j] = u_s + (j * 4 + wave) * 6 * 64 + lane;
+    auto a_fetch_one = [&](int j, int set, int q) WS_INL { aop[set][q] = ubase[j][q * 64]; };
 
     float wv[8][4][2];                   // row i of B^T d of this lane's two tiles: [channel][column][tile group]
     const float sgn = wave == 1 ? 1.f : -1.f;
     ws_f32x2 tx_[2][4], ty_[2][4];       // raw values of two channels in flight: [channel parity][tile group * 2 + column pair]
-    auto w_read = [&](int ch, int buf, int part) WS_INL {         // part 0: the X rows, 1: the Y rows (one ds_read2_b64 per tile group)
-        const float* src = (part == 0 ? pX : pY) + buf * WS_RAWBUF + ch * WS_IW;
+    // LDS byte addresses of the X / Y rows of tile group 0 / 1 in the raw buffer being transformed (set once per chunk and made opaque:
+    // the compiler otherwise keeps two of the four and re-derives the others with a v_add per channel; the channel is an immediate)
+    typedef const __attribute__((address_space(3))) ws_f32x2* ws_l2ptr_t;
+    unsigned wb[4];
+    const unsigned lds_x = (unsigned)(size_t)(ws_lptr_t)pX, lds_y = (unsigned)(size_t)(ws_lptr_t)pY;
+    auto w_bases = [&](int buf) WS_INL {
 #pragma unroll
         for (int tg = 0; tg < 2; ++tg) {
-            const ws_f32x2* q = reinterpret_cast<const ws_f32x2*>(__builtin_assume_aligned(src + tg * 4 * WS_ROW, 8));
+            wb[tg] = lds_x + (unsigned)(buf * WS_RAWBUF + tg * 4 * WS_ROW) * 4u;
+            wb[2 + tg] = lds_y + (unsigned)(buf * WS_RAWBUF + tg * 4 * WS_ROW) * 4u;
+        }
+        asm volatile("" : "+v"(wb[0]), "+v"(wb[1]), "+v"(wb[2]), "+v"(wb[3]));
+    };
+    auto w_read = [&](int ch, int part) WS_INL {                  // part 0: the X rows, 1: the Y rows (one ds_read2_b64 per tile group)
+#pragma unroll
+        for (int tg = 0; tg < 2; ++tg) {
+            const ws_l2ptr_t q = (ws_l2ptr_t)(size_t)(wb[2 * part + tg] + (unsigned)(ch * WS_IW * 4));
             if (part == 0) { tx_[ch & 1][tg * 2] = q[0]; tx_[ch & 1][tg * 2 + 1] = q[1]; }
             else { ty_[ch & 1][tg * 2] = q[0]; ty_[ch & 1][tg * 2 + 1] = q[1]; }
         }
@@ -255,16 +288,16 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
     dma_raw(0, 0);
     if (nch > 1) dma_raw(1, 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 6; ++q) dma_u_one(0, j, q);
-    __builtin_amdgcn_s_waitcnt(0);       // everything landed (prologue only)
-    __syncthreads();
+    for (int j = 0; j < 4; ++j) { dma_u_one(0, j, WsI<0>{}); dma_u_one(0, j, WsI<1>{}); dma_u_one(0, j, WsI<2>{}); dma_u_one(0, j, WsI<3>{}); dma_u_one(0, j, WsI<4>{}); dma_u_one(0, j, WsI<5>{}); }
+    // (the ring slots of positions 1 .. 3 -- the 18 newest DMAs -- are not waited for here: the steps' own counted waits cover them)
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");       // both raw images and slot 0 have landed in every wave
 #pragma unroll
     for (int q = 0; q < 6; ++q) a_fetch_one(0, 0, q);
 #pragma unroll
     for (int ch = 0; ch < 8; ++ch) {
-        w_read(ch, 0, 0); w_read(ch, 0, 1);
+        if (ch == 0) w_bases(0);
+        w_read(ch, 0); w_read(ch, 1);
 #pragma unroll
         for (int col = 0; col < 4; ++col) w_fma(ch, col);
     }
@@ -288,7 +321,7 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
     //   steps 2 and 3   the next chunk's row transform, channel by channel, behind the last use of the old values (channel pair g of the old
     //                   chunk is last read in slot 6 g of step 2, of the new one first in slot 6 g of step 3): step 2 channels 0 .. 4
     //                   (starting in slots 1, 5, 9, 13, 17), step 3 channels 5 .. 7 (slots 0, 4, 8); a channel's X rows are read in its
-    //                   first slot, its Y rows in the second, its four columns are combined in slots +3 .. +6
+    //                   first slot, its Y rows in the second, its four columns are combined in slots +4 .. +7
     auto step = [&](const int c, auto j_t, auto more_t) WS_INL {
         constexpr int j = decltype(j_t)::value;
         constexpr bool MORE = decltype(more_t)::value;
@@ -297,34 +330,37 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
         const int nbuf = (c + 1) & 1;
         auto aux = [&](auto k_t) WS_INL {
             constexpr int k = decltype(k_t)::value;
-            if constexpr (MORE && k < 6) {
+            if constexpr (MORE && k < 6 && !(WS_VAR & 1)) {
                 if constexpr (k == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                dma_u_one(c + 1, j, k);
+                dma_u_one(c + 1, j, k_t);
             }
-            if constexpr (k == 6) {
+            if constexpr (k == 6 && !(WS_VAR & 1)) {
                 if (MORE) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
                 else if (j == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
                 else if (j == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else if (j == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if constexpr (k >= 6 && k < 12 && (MORE || j < 3)) a_fetch_one((j + 1) & 3, set ^ 1, k - 6);
-            if constexpr (MORE && (j == 2 || j == 3)) {
+            if constexpr (k >= 6 && k < 12 && (MORE || j < 3) && !(WS_VAR & 1)) a_fetch_one((j + 1) & 3, set ^ 1, k - 6);
+            if constexpr (MORE && (j == 2 || j == 3) && !(WS_VAR & 4)) {
                 constexpr int first = j == 2 ? 0 : 5, count = j == 2 ? 5 : 3, s0 = j == 2 ? 1 : 0;
+                if constexpr (j == 2 && k == 0) w_bases(nbuf);
 #pragma unroll
                 for (int n = 0; n < count; ++n) {
                     const int s = s0 + 4 * n;
-                    if (k == s) w_read(first + n, nbuf, 0);
-                    if (k == s + 1) w_read(first + n, nbuf, 1);
-                    if (k >= s + 3 && k <= s + 6) w_fma(first + n, k - s - 3);
+                    if (k == s) w_read(first + n, 0);
+                    if (k == s + 1) w_read(first + n, 1);
+#pragma unroll
+                    for (int col = 0; col < 4; ++col)
+                        if (k == (s + 4 + col < 23 ? s + 4 + col : 23)) w_fma(first + n, col);      // three slots behind the reads and more
                 }
             }
-            if constexpr (MORE || j < 3) build_part(JN{}, WsI<k / 6>{}, WsI<k % 6>{}, set ^ 1);
+            if constexpr ((MORE || j < 3) && !(WS_VAR & 2)) build_part(JN{}, WsI<k / 6>{}, WsI<k % 6>{}, set ^ 1);
         };
         auto slots = [&](auto k_t, auto&& self) WS_INL {
             constexpr int k = decltype(k_t)::value;
             if constexpr (k < 24) {
                 constexpr int p = k >> 2, mg = (k >> 1) & 1, tg = k & 1;
-                acc[j * 4 + mg * 2 + tg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws_bf(aop[set][mg * 3 + PA[p]]), ws_bf(bop[set][tg * 3 + PB[p]]),
+                acc[j * 4 + mg * 2 + tg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ws_bf(aop[(WS_VAR & 1) ? 0 : set][mg * 3 + PA[p]]), ws_bf(bop[(WS_VAR & 2) ? 0 : set][tg * 3 + PB[p]]),
                                                                                  acc[j * 4 + mg * 2 + tg], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 aux(k_t);

@@ -64,7 +64,12 @@ void dfree16(unsigned short*& p)
 // does the data gradient of conv layer L at this size run on the split-operand Winograd kernel?
 static bool dgrad_takes_split(const st_ctx* c, const Layer& L, int h, int w)
 {
-    return c->wino && c->wino_split && !c->bf16 && L.us_bwd && conv_wino_split_ok(L.cout, L.cin, h, w);
+    if (!(c->wino && c->wino_split && !c->bf16 && L.us_bwd && conv_wino_split_ok(L.cout, L.cin, h, w))) return false;
+    // K = 64 (conv1_2's data gradient: four 16-channel chunks per workgroup, half its time prologue and epilogue) where the fp32 kernel
+    // can unpool in its input transform: measured 403.7 us + 59.6 us of maxpool_bwd_amap_k against 428.7 us for the fp32 launch alone
+    // (profiles/r05_k_split_per_layer.txt, r04_z_per_layer.txt) -- that one stays on the fp32 matrix cores
+    if (L.cout <= 64 && L.u_bwd && conv_wino_can_unpool(L.cout, L.cin, h, w)) return false;
+    return true;
 }
 
 int wino_scratch(st_ctx* c, ConvProblem& p, bool split_kernel)
