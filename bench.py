@@ -587,10 +587,14 @@ def extra_configs(args, device):
         cmd = [sys.executable, os.path.join(HERE, 'tools', 'bench_tiled_one_gpu.py'), '--size', '8192', '--grid', '2x4', '--steps', '3',
                '--warmup', '1', '--need-free-gib', '230']
         t0 = time.perf_counter()
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
+        try:
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+        except subprocess.TimeoutExpired as err:        # (the child is killed with GPU work in flight: say so, with what it printed)
+            return {'error': 'tools/bench_tiled_one_gpu.py did not finish within 240 s and was killed',
+                    'stderr_tail': (err.stderr or b'').decode(errors='replace')[-1500:]}
         lines = [ln for ln in res.stdout.decode().splitlines() if ln.startswith('{')]
         if res.returncode != 0 or not lines:
-            return {'error': 'tools/bench_tiled_one_gpu.py exited with %d' % res.returncode}
+            return {'error': 'tools/bench_tiled_one_gpu.py exited with %d' % res.returncode, 'stderr_tail': res.stderr.decode(errors='replace')[-1500:]}
         leg = json.loads(lines[-1])
         leg['leg_seconds'] = time.perf_counter() - t0
         leg['note'] = 'configs[4] asks for 8 GPUs; this is the same job with its eight ranks resident on ONE GPU (in-process transport): unmeasured on a multi-GPU node'
@@ -602,7 +606,10 @@ def extra_configs(args, device):
         free = ctypes.c_size_t()
         total = ctypes.c_size_t()
         hip = ctypes.CDLL('libamdhip64.so')
-        if hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0 and free.value < 200 * 2 ** 30:
+        rc = hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+        if rc != 0:
+            return {'skipped': 'hipMemGetInfo failed (%d): the free HBM is unknown, the 175 GB job is not started' % rc}
+        if free.value < 200 * 2 ** 30:
             return {'skipped': 'only %.0f GiB of HBM free, the un-sharded 8192 x 8192 job needs 175' % (free.value / 2 ** 30)}
         rs = np.random.RandomState
         content = rs(1).randint(0, 256, (8192, 8192, 3)).astype(np.uint8)

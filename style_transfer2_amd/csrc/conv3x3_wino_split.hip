@@ -124,8 +124,12 @@ template <int I> __device__ __forceinline__ void ws_set(uint4& v, unsigned x)
 #endif
 template <int N> using WsI = std::integral_constant<int, N>;
 
-// NOOUT: forward launches with the fused pool AND its arg-max map that do not write the full-resolution blob (conv3x3_winograd.hip)
-template <bool NOOUT, int DIAG>
+// POOL: forward launches that also write the 2x2 max-pool of their output (and its arg-max map, when asked for);
+// NOOUT: POOL launches with the map that do not write the full-resolution blob (conv3x3_winograd.hip);
+// DG: data-gradient launches (1: injected diff at most, 2: ReLU mask of the blob below as well; no bias, ReLU or pool).
+// One epilogue per kind: with the options as run-time flags the epilogue was 135 instructions per accumulator row, most of them
+// control flow and 64-bit address arithmetic around stores that a launch does not have.
+template <bool NOOUT, int DG, bool POOL, int DIAG>
 __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
 {
     // raw[2] during the main loop + the U ring; the row exchange of the epilogue afterwards ([src wave][combo][e 8][lane] float2 = 64 KiB)
@@ -279,25 +283,27 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
     };
 
     ws_f32x16 acc[16];                   // [position j][m group][tile group]
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
 
     // ---- prologue: raw chunks 0 and 1, the four ring slots of chunk 0, the row transform and position 0 of chunk 0 ----
     dma_raw(0, 0);
     if (nch > 1) dma_raw(1, 1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { dma_u_one(0, j, WsI<0>{}); dma_u_one(0, j, WsI<1>{}); dma_u_one(0, j, WsI<2>{}); dma_u_one(0, j, WsI<3>{}); dma_u_one(0, j, WsI<4>{}); dma_u_one(0, j, WsI<5>{}); }
+    __builtin_amdgcn_sched_barrier(0);       // (the 256 accumulator writes below run under the DMAs' latency, not in front of their issue)
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
     // (the ring slots of positions 1 .. 3 -- the 18 newest DMAs -- are not waited for here: the steps' own counted waits cover them)
     asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");       // both raw images and slot 0 have landed in every wave
 #pragma unroll
     for (int q = 0; q < 6; ++q) a_fetch_one(0, 0, q);
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch) {
-        if (ch == 0) w_bases(0);
-        w_read(ch, 0); w_read(ch, 1);
+    for (int ch = 0; ch < 8; ++ch) {           // (the next channel's reads are in flight while this one's columns are combined)
+        if (ch == 0) { w_bases(0); w_read(0, 0); w_read(0, 1); }
+        if (ch + 1 < 8) { w_read(ch + 1, 0); w_read(ch + 1, 1); }
 #pragma unroll
         for (int col = 0; col < 4; ++col) w_fma(ch, col);
     }
@@ -391,10 +397,12 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
     // ---- epilogue.  Output transform of accumulator element e: y = A^T M A with M = the 4x4 transform-domain tile, row i in wave i:
     // each wave reduces its row to t = (M0 + M1 + M2, M1 - M2 - M3), the waves exchange the t of the three combos they do not finish
     // through LDS, and wave q finishes combo q = (m group, tile group): y0. = t(0) + t(1) + t(2), y1. = t(1) - t(2) - t(3).
+    // Every global access is a buffer access: "no mask" / "no inject" / "no bias" are zero-size resources, "lane outside the image" an
+    // out-of-range offset -- no branch, no 64-bit address.
     float2* const xch = reinterpret_cast<float2*>(lds);             // [src wave 4][combo 4][e 8][lane 64] (the raw images and 12 KiB of the ring are dead)
     const int mg_f = wave >> 1, tg_f = wave & 1;
-    // (the lane-dependent values of the epilogue are derived from an lane index re-derived HERE: computed from `lane` they
-    // are hoisted above the main loop and, at 250 registers in there, spilled across it)
+    // (the lane-dependent values of the epilogue are derived from a lane index re-derived HERE: computed from `lane` they are hoisted
+    // above the main loop and, at 250 registers in there, spilled across it)
     int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // = lane, from the exec mask: nothing lives across the loop
     asm volatile("" : "+v"(lane_e));
     const int t31 = lane_e & 31, kq = lane_e >> 5;
@@ -402,41 +410,51 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
     const int gy = y0 + 4 * tg_f + 2 * (t31 >> 4) + odd;            // this lane's row after the swap
     const int gx4 = x0 + 2 * (t31 & 14);                            // first of the lane pair's 4 pixels (16-byte aligned)
     const bool part = a.splits > 1;
-    const bool has_bias = !part && a.bias != nullptr, has_mask = !part && a.mask_src != nullptr, has_inj = !part && a.inject != nullptr;
-    const bool relu = !part && a.relu;
+    const bool has_bias = !part && a.bias != nullptr, has_mask = DG == 2 && !part && a.mask_src != nullptr, has_inj = !part && a.inject != nullptr;
+    const float floor_v = (!part && a.relu) ? 0.f : -__builtin_inff();      // ReLU as max(., floor)
     float* const outp = part ? a.scratch + (size_t)split * a.M * plane : a.out;
     const bool live = gx4 < a.W && gy < a.H;
     const int mw = mt * 64 + mg_f * 32 + 4 * kq;
-    const unsigned pix = live ? (unsigned)gy * a.W + gx4 : 0u;
-    // the ReLU-mask / injected-diff quads of a half's 8 accumulator rows are requested before its exchange round (the loop's registers are
-    // dead): their latency runs under the LDS traffic and the barriers.  Buffer loads, so that "no mask" / "no inject" / "no bias" / "lane
-    // outside the image" are zero-size resources and out-of-range offsets instead of branches (the branches cost phis of 64 registers: spills)
     typedef unsigned ws_u32x4 __attribute__((ext_vector_type(4)));
-    const unsigned out_bytes = (unsigned)a.M * plane * 4u;
+    const unsigned out_bytes = (unsigned)a.M * plane * 4u, plane4 = plane * 4u;
+    const unsigned off0 = live ? ((unsigned)mw * plane + (unsigned)gy * a.W + gx4) * 4u : kWsOOB;
+    auto off_of = [&](int e) WS_INL { return live ? off0 + (unsigned)(8 * (e >> 2) + (e & 3)) * plane4 : kWsOOB; };
     const __amdgpu_buffer_rsrc_t rs_mk = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask_src, 0, has_mask ? out_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ij = __builtin_amdgcn_make_buffer_rsrc((void*)a.inject, 0, has_inj ? out_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_bs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, has_bias ? (unsigned)a.M * 4u : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)outp, 0, NOOUT ? 0u : out_bytes, 0x00020000);
+    // the fused pool (Caffe MAX 2x2/2, ceil mode): the lane's 2x2 tile IS one pooling window (tile origins are even); bias and ReLU
+    // commute with max.  A window clipped by the bottom edge keeps its first row only.
+    const int ty2 = y0 + 4 * tg_f + 2 * (t31 >> 4), tx2 = x0 + 2 * (t31 & 15);
+    const bool plive = POOL && tx2 < a.W && ty2 < a.H, prow1 = ty2 + 1 < a.H;
+    const unsigned pplane = POOL ? (unsigned)a.pool_h * a.pool_w : 0u;
+    const unsigned po0 = plive ? (unsigned)mw * pplane + (unsigned)(ty2 >> 1) * a.pool_w + (tx2 >> 1) : 0u;
+    const __amdgpu_buffer_rsrc_t rs_po = __builtin_amdgcn_make_buffer_rsrc((void*)a.pool_out, 0, POOL ? (unsigned)a.M * pplane * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_pa = __builtin_amdgcn_make_buffer_rsrc((void*)a.pool_amap, 0, (POOL && a.pool_amap) ? (unsigned)a.M * pplane : 0u, 0x00020000);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        unsigned off[8];
-        float mk[8][4], ij[8][4];
-        float bs[8];
+        // the bias / ReLU-mask / injected-diff values of this half's 8 accumulator rows are requested before its exchange round (the
+        // loop's registers are dead): their latency runs under the LDS traffic and the barriers
+        float mk[DG == 2 ? 8 : 1][4], ij[DG ? 8 : 1][4], bs[DG ? 1 : 8];
+        if constexpr (DG == 2) {
 #pragma unroll
-        for (int el = 0; el < 8; ++el) {
-            const int e = 8 * half + el, m = mw + 8 * (e >> 2) + (e & 3);
-            off[el] = live ? ((unsigned)m * plane + pix) * 4u : kWsOOB;
-            bs[el] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bs, m * 4, 0, 0));
+            for (int el = 0; el < 8; ++el) {
+                const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_mk, off_of(8 * half + el), 0, 0));
+                mk[el][0] = __builtin_bit_cast(float, v.x); mk[el][1] = __builtin_bit_cast(float, v.y); mk[el][2] = __builtin_bit_cast(float, v.z); mk[el][3] = __builtin_bit_cast(float, v.w);
+            }
         }
+        if constexpr (DG != 0) {
 #pragma unroll
-        for (int el = 0; el < 8; ++el) {
-            const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_mk, off[el], 0, 0));
-            mk[el][0] = __builtin_bit_cast(float, v.x); mk[el][1] = __builtin_bit_cast(float, v.y); mk[el][2] = __builtin_bit_cast(float, v.z); mk[el][3] = __builtin_bit_cast(float, v.w);
-        }
+            for (int el = 0; el < 8; ++el) {
+                const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_ij, off_of(8 * half + el), 0, 0));
+                ij[el][0] = __builtin_bit_cast(float, v.x); ij[el][1] = __builtin_bit_cast(float, v.y); ij[el][2] = __builtin_bit_cast(float, v.z); ij[el][3] = __builtin_bit_cast(float, v.w);
+            }
+        } else {
 #pragma unroll
-        for (int el = 0; el < 8; ++el) {
-            const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_ij, off[el], 0, 0));
-            ij[el][0] = __builtin_bit_cast(float, v.x); ij[el][1] = __builtin_bit_cast(float, v.y); ij[el][2] = __builtin_bit_cast(float, v.z); ij[el][3] = __builtin_bit_cast(float, v.w);
+            for (int el = 0; el < 8; ++el) {
+                const int e = 8 * half + el;
+                bs[el] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bs, (mw + 8 * (e >> 2) + (e & 3)) * 4, 0, 0));
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();                                            // the images / the previous half's exchange are dead
@@ -447,36 +465,27 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
                 const int e = 8 * half + el;
                 const float m0 = acc[0 * 4 + qq][e], m1 = acc[1 * 4 + qq][e], m2 = acc[2 * 4 + qq][e], m3 = acc[3 * 4 + qq][e];
                 xch[((wave * 4 + qq) * 8 + el) * 64 + lane_e] = make_float2(m0 + m1 + m2, m1 - m2 - m3);
-                if (el == 3 || el == 7) __builtin_amdgcn_sched_barrier(0);      // (keeps the accumulator reads from being hoisted en bloc: they would spill the quads above)
+                if (el == 3 || el == 7) __builtin_amdgcn_sched_barrier(0);      // (keeps the accumulator reads from being hoisted en bloc: they would spill the values above)
             }
         __syncthreads();
 #pragma unroll
         for (int el = 0; el < 8; ++el) {
             const int e = 8 * half + el;
-            const int m = mw + 8 * (e >> 2) + (e & 3);
             const float2 s0 = xch[((0 * 4 + wave) * 8 + el) * 64 + lane_e], s1 = xch[((1 * 4 + wave) * 8 + el) * 64 + lane_e];
             const float2 s2 = xch[((2 * 4 + wave) * 8 + el) * 64 + lane_e], s3 = xch[((3 * 4 + wave) * 8 + el) * 64 + lane_e];
             const float y00 = s0.x + s1.x + s2.x, y01 = s0.y + s1.y + s2.y;
             const float y10 = s1.x - s2.x - s3.x, y11 = s1.y - s2.y - s3.y;
-            if (a.pool_out) {
-                // fused max-pool (Caffe MAX 2x2/2, ceil mode): the lane's 2x2 tile IS one pooling window (tile origins are even); bias
-                // and ReLU commute with max.  A window clipped by the bottom edge keeps its first row only.
-                const int ty2 = y0 + 4 * tg_f + 2 * (t31 >> 4), tx2 = x0 + 2 * (t31 & 15);
-                if (tx2 < a.W && ty2 < a.H) {
-                    const size_t po = ((size_t)m * a.pool_h + (ty2 >> 1)) * a.pool_w + (tx2 >> 1);
-                    float pm = y00 > y01 ? y00 : y01;
-                    if (ty2 + 1 < a.H) { const float p1 = y10 > y11 ? y10 : y11; pm = pm > p1 ? pm : p1; }
-                    if (a.pool_amap) {
-                        // WHERE the maximum is (first one of a row-major scan) and whether it is positive after the bias -- compared AFTER
-                        // the bias, as the stored blob the reference's pooling layer scans is (conv3x3_winograd.hip)
-                        const float qb = pm + bs[el];
-                        const unsigned slot = y00 + bs[el] == qb ? 0u : (y01 + bs[el] == qb ? 1u : (y10 + bs[el] == qb ? 2u : 3u));
-                        a.pool_amap[po] = (unsigned char)(slot | (qb > 0.f ? 4u : 0u));
-                    }
-                    pm += bs[el];
-                    if (relu) pm = pm > 0.f ? pm : 0.f;
-                    a.pool_out[po] = pm;
-                }
+            if constexpr (POOL) {
+                const float b = bs[DG ? 0 : el];
+                const float p0 = y00 > y01 ? y00 : y01, p1 = y10 > y11 ? y10 : y11;
+                const float pm = prow1 ? (p0 > p1 ? p0 : p1) : p0;
+                // WHERE the maximum is (first one of a row-major scan) and whether it is positive after the bias -- compared AFTER the
+                // bias, as the stored blob the reference's pooling layer scans is (conv3x3_winograd.hip)
+                const float qb = pm + b;
+                const unsigned slot = y00 + b == qb ? 0u : (y01 + b == qb ? 1u : (y10 + b == qb ? 2u : 3u));
+                const unsigned po = plive ? po0 + (unsigned)(8 * (e >> 2) + (e & 3)) * pplane : kWsOOB;       // (kWsOOB * 4 wraps to an offset that is out of range too)
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(slot | (qb > 0.f ? 4u : 0u)), rs_pa, po, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_fmaxf(qb, floor_v)), rs_po, plive ? po * 4u : kWsOOB, 0, 0);
             }
             if constexpr (NOOUT) continue;
             // give away the row this lane does not keep, receive the partner's part of the row it keeps (quad_perm 1,0,3,2)
@@ -485,21 +494,20 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
             const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, g1), 0xB1, 0xf, 0xf, true));
             float o[4];
             o[0] = odd ? q0 : y00; o[1] = odd ? q1 : y01; o[2] = odd ? y10 : q0; o[3] = odd ? y11 : q1;
+            if constexpr (DG) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                o[jj] += bs[el];
-                if (relu) o[jj] = o[jj] > 0.f ? o[jj] : 0.f;
-            }
+                for (int jj = 0; jj < 4; ++jj) {
+                    if constexpr (DG == 2) o[jj] = mk[el][jj] > 0.f ? o[jj] : 0.f;
+                    o[jj] += ij[el][jj];
+                }
+            } else {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const float mv = has_mask ? mk[el][jj] : 1.f;
-                o[jj] = mv > 0.f ? o[jj] : 0.f;
-                o[jj] += ij[el][jj];
+                for (int jj = 0; jj < 4; ++jj) o[jj] = __builtin_fmaxf(o[jj] + bs[DG ? 0 : el], floor_v);
             }
             ws_u32x4 ov;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) ov[jj] = __builtin_bit_cast(unsigned, o[jj]);
-            __builtin_amdgcn_raw_buffer_store_b128(ov, rs_o, off[el], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rs_o, off_of(e), 0, 0);
         }
     }
     if (DIAG && threadIdx.x == 0 && a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); a.stamps[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memtime(); }
@@ -507,9 +515,13 @@ __device__ __forceinline__ void conv3x3_wino_split_body(const WsKArgs& a)
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256(const WsKArgs a) { conv3x3_wino_split_body<false, 0>(a); }
-__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256_noout(const WsKArgs a) { conv3x3_wino_split_body<true, 0>(a); }
-__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256_stamped(const WsKArgs a) { conv3x3_wino_split_body<false, 1>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256(const WsKArgs a) { conv3x3_wino_split_body<false, 0, false, 0>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256_pool(const WsKArgs a) { conv3x3_wino_split_body<false, 0, true, 0>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256_noout(const WsKArgs a) { conv3x3_wino_split_body<true, 0, true, 0>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256_dgrad(const WsKArgs a) { conv3x3_wino_split_body<false, 1, false, 0>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256_dgrad_masked(const WsKArgs a) { conv3x3_wino_split_body<false, 2, false, 0>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256_stamped(const WsKArgs a) { conv3x3_wino_split_body<false, 0, false, 1>(a); }
+__global__ __launch_bounds__(256, 1) void conv3x3_wino_split_64x256_dgrad_stamped(const WsKArgs a) { conv3x3_wino_split_body<false, 2, false, 1>(a); }
 
 // ---- host side ----
 static unsigned short ws_f2bf(float f)             // round to nearest even (finite input)
@@ -604,8 +616,18 @@ hipError_t launch_conv3x3_wino_split(const ConvProblem& p, hipStream_t s)
     const bool noout = !p.out;
     if (noout && (!k.pool_out || !k.pool_amap || k.splits > 1 || p.mask_src || p.inject)) return hipErrorInvalidValue;
     const dim3 g((unsigned)(nblk * k.splits)), b(256);
-    if (p.stamps) { if (noout) return hipErrorInvalidValue; conv3x3_wino_split_64x256_stamped<<<g, b, 0, s>>>(k); }
+    // data-gradient epilogue (mask / inject), forward epilogue (bias / ReLU) with or without the pool; a split-K launch writes raw partial
+    // sums: the plain forward build
+    const bool dg = k.splits == 1 && (p.mask_src || p.inject);
+    if (dg && (p.bias || p.relu || p.pool_out)) return hipErrorInvalidValue;
+    if (p.stamps) {
+        if (noout || k.pool_out) return hipErrorInvalidValue;
+        if (dg) conv3x3_wino_split_64x256_dgrad_stamped<<<g, b, 0, s>>>(k); else conv3x3_wino_split_64x256_stamped<<<g, b, 0, s>>>(k);
+    }
     else if (noout) conv3x3_wino_split_64x256_noout<<<g, b, 0, s>>>(k);
+    else if (k.pool_out) conv3x3_wino_split_64x256_pool<<<g, b, 0, s>>>(k);
+    else if (dg && p.mask_src) conv3x3_wino_split_64x256_dgrad_masked<<<g, b, 0, s>>>(k);
+    else if (dg) conv3x3_wino_split_64x256_dgrad<<<g, b, 0, s>>>(k);
     else conv3x3_wino_split_64x256<<<g, b, 0, s>>>(k);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || k.splits == 1) return e;

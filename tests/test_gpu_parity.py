@@ -916,9 +916,11 @@ class _QuietFirst:
 @pytest.mark.parametrize('optimizer', ['adam', 'lbfgs'])
 @pytest.mark.parametrize('cols', [1, 2])
 def test_fused_tile_step_without_a_trace_reads_nothing_back_and_changes_nothing(optimizer, cols):
-    """st_tile_step(ctx, NULL): the device loop of a headless sharded job -- no trace, no host synchronisation, and the all-reduce that
-    only the trace needs is not issued (every rank skips it together).  Three iterations of which the first two are trace-less must
-    leave the same tiles and the same third trace, bit for bit, as three iterations with their traces -- one rank and two."""
+    """st_tile_step(ctx, NULL): the device loop of a headless sharded job -- no trace, no host synchronisation.  Three iterations of
+    which the first two are trace-less must leave the same tiles and the same third trace, bit for bit, as three iterations with their
+    traces -- one rank and two.  The collective sequence is the SAME with and without a trace (round 5: until then a trace-less call
+    skipped the all-reduce of the image-space sums, and ranks that disagreed on NULL for one iteration hung in RCCL instead of failing:
+    ADVICE r4); the mixed case -- one rank asks for a trace, the other does not -- is the test below."""
     from style_transfer2_amd import tiled, tiling
     from style_transfer2_amd.tile_backend import HipTileBackend
     h, w = 64, 96
@@ -943,7 +945,30 @@ def test_fused_tile_step_without_a_trace_reads_nothing_back_and_changes_nothing(
     for r in range(cols):
         assert np.array_equal(results[0][r][0], results[1][r][0]) and np.array_equal(results[0][r][1], results[1][r][1]), r
     if cols > 1:
-        assert reduces[0] == reduces[1] - 2, reduces          # the two trace-less iterations saved one all-reduce each
+        assert reduces[0] == reduces[1], reduces              # same collectives either way
+
+
+def test_ranks_may_disagree_on_asking_for_a_trace():
+    """One rank of two passes trace == NULL for an iteration, the other does not: the iteration completes on both (same collectives)
+    and leaves the tiles it leaves when both ask -- until round 5 this desynchronised the collective sequence."""
+    from style_transfer2_amd import tiled, tiling
+    from style_transfer2_amd.tile_backend import HipTileBackend
+    h, w = 64, 96
+    content, style, init = _tiled_images(h, w)
+    params = oracle.he_init_weights(TILED_TOPO, 0, 0.1)
+    grid = tiling.TileGrid(h, w, 1, 2, TILED_TOPO, 5)
+    results = []
+    for quiet in ((1, 0), (0, 0)):
+        fabric = ThreadFabric(2)
+        ranks = []
+        for r in range(2):
+            backend = HipTileBackend(params, grid, r, content, style, init, TILED_WEIGHTS, TILED_PARAMS, step_size=10, topology=TILED_TOPO)
+            backend.comm_init_local(r, 2, fabric)
+            ranks.append(_QuietFirst(tiled.FusedTiledTransfer(grid, r, backend), quiet[r]))
+        out = _run_ranks_as_threads(ranks, 2, fabric)
+        results.append([(out[r][-1][0], np.asarray(out[r][-1][1])) for r in range(2)])
+    for r in range(2):
+        assert np.array_equal(results[0][r][0], results[1][r][0]) and np.array_equal(results[0][r][1], results[1][r][1]), r
 
 
 @pytest.mark.parametrize('rows,cols', [(1, 2), (2, 4)])

@@ -266,3 +266,34 @@ def test_async_sender_close_is_bounded_when_nothing_is_taken(monkeypatch):
     blocker.join(5.0)
     assert not blocker.is_alive() and not sender.thread.is_alive()
     assert time.time() - t0 < 5.0 and sender.dropped >= 2 and socks.sent == []
+
+
+def test_a_stored_sender_error_does_not_keep_the_context_alive(monkeypatch):
+    """when the sender thread has stored an error, `send_pyobj(Shutdown())` in run()'s finally raises it again, and
+    so does `sender.close()` -- Worker.close() must still reach ctx.destroy(0) (an undestroyed context blocks interpreter exit in zmq
+    term with the default LINGER: the hang the bounded shutdown was written to remove), and run() must not die in its finally."""
+    monkeypatch.setattr(worker_mod, 'SEND_SLICE_S', 0.02)
+    monkeypatch.setattr(worker_mod, 'SHUTDOWN_GRACE_S', 0.3)
+
+    class BrokenOut(StallingSockets):
+        def send_pyobj(self, obj):
+            if isinstance(obj, messages.Iterate):
+                raise OSError('transport gone')
+            super().send_pyobj(obj)
+
+    class Ctx:
+        destroyed = 0
+
+        def destroy(self, linger):
+            Ctx.destroyed += 1
+    img = np.zeros((4, 4, 3), np.uint8)
+    socks = BrokenOut([messages.SetImages(None, img, img, img, True), messages.StartIteration(), messages.Shutdown()], alive=100)
+    wk = worker_mod.Worker({'async_iterate': '1', 'zero_copy_iterate': '0'}, sock_in=socks, sock_out=socks, transfer=FakeFramedTransfer(4))
+    wk._ctx = Ctx()
+    wk.run()                               # the stored OSError surfaces at a later send; the finally block must swallow it and go on
+    with pytest.raises(OSError):
+        # (whether close() re-raises the stored error is not the point -- the context is)
+        wk.sock_out = worker_mod.AsyncSender(socks, depth=1, grace=0.2)
+        wk.sock_out.error = OSError('transport gone')
+        wk.close()
+    assert Ctx.destroyed == 1

@@ -286,11 +286,15 @@ class Worker:
             raise
 
     def close(self):
-        if isinstance(self.sock_out, AsyncSender):
-            sender, self.sock_out = self.sock_out, self._raw_out
-            sender.close()
-        if self._ctx is not None:
-            self._ctx.destroy(0)
+        # ctx.destroy(0) must be reached whatever the sender thread has stored (an error of its own is raised again by its close()):
+        # an undestroyed context blocks the interpreter's exit in zmq term with the default LINGER
+        try:
+            if isinstance(self.sock_out, AsyncSender):
+                sender, self.sock_out = self.sock_out, self._raw_out
+                sender.close()
+        finally:
+            if self._ctx is not None:
+                self._ctx.destroy(0)
 
     def _collect_and_send(self):
         """The oldest iteration in flight: wait for it, send its Iterate."""
@@ -329,10 +333,16 @@ class Worker:
                 self._flush_pending()
             except Exception:                 # the reference always reaches Shutdown (worker.py:396-398)
                 logger.exception('could not collect the iterations in flight')
-            self.sock_out.send_pyobj(Shutdown())
+            try:
+                self.sock_out.send_pyobj(Shutdown())
+            except Exception:                 # an error the sender thread stored earlier is raised by this send: the peer is gone or the
+                logger.exception('Shutdown could not be queued')      # transport failed -- close() below still runs, the exit stays bounded
             if isinstance(self.sock_out, AsyncSender):       # Shutdown is the last thing on the wire
                 sender, self.sock_out = self.sock_out, self._raw_out
-                sender.close()
+                try:
+                    sender.close()
+                except Exception:
+                    logger.exception('sender thread ended with an error')
 
     def _drain_then_step(self):
         """Handle everything queued without blocking, then do exactly one iteration."""
