@@ -142,10 +142,20 @@ __device__ __forceinline__ float f4c(const float4& v, int i) { return i == 0 ? v
 //                the layer is pooled and carries no weight (the next conv reads the pooled blob, the pool's backward the map with the ReLU
 //                sign in it): the row exchange, bias / ReLU of the four pixels and the 16-byte store of every accumulator row are gone.
 //                A build of its own because the 512-register kernels have no register for a run-time flag (it spilled).
+// EPI != 0 (round 5; QUAD, one pass, tensors below 4 GiB, the 128-channel and the half-tile builds): an epilogue per launch KIND instead of
+//                one epilogue with every option as a run-time flag -- 1 forward (bias + ReLU), 2 forward + fused pool (+ arg-max map; with
+//                NOOUT: the pooled blob only), 3 data gradient with the ReLU mask of the blob below, 4 data gradient without one (injected
+//                diff optional in both).  Every global access is a buffer access ("absent" = a zero-size resource, "outside the image or
+//                the channel range" = an out-of-range offset): no branch around a load or store, no 64-bit address arithmetic.  The
+//                arithmetic is the generic epilogue's, operation for operation: results are the same bits.  Measured on the split-operand
+//                kernel first (conv3x3_wino_split.hip: 135 -> ~50 instructions per accumulator row, 12.9 k -> 6.9 k cycles); here the
+//                generic epilogue was ~3 200 instructions per wave after the last MFMA for ~900 of essential work.
 template <int WM, int TG, int DIAG = 0, bool QUAD = true, bool PS = false, bool W8 = false, bool H4 = false, bool UNPOOL = false, bool BIG = false,
-          bool NOOUT = false>
+          bool NOOUT = false, int EPI = 0>
 __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
 {
+    static_assert(EPI == 0 || (QUAD && TG == 1 && !PS && !W8 && !BIG && DIAG == 0), "specialised epilogues: aligned widths, one tile group, four waves, below 4 GiB");
+    static_assert(!NOOUT || EPI == 0 || EPI == 2, "no-output builds pool");
     static_assert(!NOOUT || (QUAD && TG == 1 && !PS && !W8 && !UNPOOL && !BIG && DIAG == 0), "no-output builds: the builds that write the arg-max map");
     static_assert(!BIG || (QUAD && TG == 1 && !PS && !W8 && DIAG == 0), "big tensors: aligned widths, one tile group, four waves");
     static_assert(!UNPOOL || (QUAD && TG == 1 && !PS && !W8), "unpool: aligned widths, one tile group, four waves");
@@ -597,6 +607,98 @@ __device__ __forceinline__ void conv3x3_wino_body(const WinoKArgs& a)
             }
         }
     }
+  } else if constexpr (EPI != 0) {
+    // ---- specialised epilogues (see EPI above): the generic one below, kind by kind, through buffer accesses
+    constexpr bool E_FWD = EPI == 1 || EPI == 2, E_POOL = EPI == 2, E_MASK = EPI == 3;
+    typedef unsigned wn_u32x4 __attribute__((ext_vector_type(4)));
+    const int t31 = lane & 31, khalf = lane >> 5;
+    const int odd = lane & 1;
+    const int gy = y0 + 4 * wave_g + 2 * (t31 >> 4) + odd;          // this lane's row after the swap
+    const int gx4 = x0 + 2 * (t31 & 14);                            // first of the pair's 4 pixels (16-byte aligned)
+    const bool live = gx4 < a.W && gy < a.H;
+    const int mw = mt * BM + wave_m * 32 + 4 * khalf;
+    const unsigned pix = live ? (unsigned)gy * a.W + gx4 : 0u;
+    const unsigned out_bytes = (unsigned)a.M * plane * 4u;
+    const bool has_inj = a.inject != nullptr;
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)a.out, 0, NOOUT ? 0u : out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_mk = __builtin_amdgcn_make_buffer_rsrc((void*)a.mask_src, 0, E_MASK ? out_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ij = __builtin_amdgcn_make_buffer_rsrc((void*)a.inject, 0, (!E_FWD && has_inj) ? out_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, E_FWD ? (unsigned)a.M * 4u : 0u, 0x00020000);
+    // the fused pool: the lane's 2x2 tile IS one pooling window; a window clipped by the bottom edge keeps its first row only
+    const int ty2 = y0 + 4 * wave_g + 2 * (t31 >> 4), tx2 = x0 + 2 * (t31 & 15);
+    const bool plive = E_POOL && tx2 < a.W && ty2 < a.H, prow1 = ty2 + 1 < a.H;
+    const unsigned pplane = E_POOL ? (unsigned)a.pool_h * a.pool_w : 0u;
+    const unsigned ppix = plive ? (unsigned)(ty2 >> 1) * a.pool_w + (tx2 >> 1) : 0u;
+    const __amdgpu_buffer_rsrc_t rs_po = __builtin_amdgcn_make_buffer_rsrc((void*)a.pool_out, 0, E_POOL ? (unsigned)a.M * pplane * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_pa = __builtin_amdgcn_make_buffer_rsrc((void*)a.pool_amap, 0, (E_POOL && a.pool_amap) ? (unsigned)a.M * pplane : 0u, 0x00020000);
+    constexpr int NEB = RS ? 2 : 4;                         // H4: this wave finishes accumulator rows 8 ph .. 8 ph + 7
+#pragma unroll
+    for (int ebl = 0; ebl < NEB; ++ebl) {
+        const int eb = RS ? 2 * ph + ebl : ebl;
+        const int mb = mw + 8 * eb;                         // rows mb .. mb+3 (e = 4 eb + 0..3)
+        unsigned off[4];
+        float mk[E_MASK ? 4 : 1][4], ij[E_FWD ? 1 : 4][4], bs[E_FWD ? 4 : 1];
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            off[ee] = (live && mb + ee < a.M) ? ((unsigned)(mb + ee) * plane + pix) * 4u : kOOB;
+            if constexpr (E_FWD) bs[ee] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_bs, (mb + ee) * 4, 0, 0));      // (beyond M: out of range, 0)
+        }
+        if constexpr (E_MASK) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_mk, off[ee], 0, 0));
+                mk[ee][0] = __builtin_bit_cast(float, v.x); mk[ee][1] = __builtin_bit_cast(float, v.y); mk[ee][2] = __builtin_bit_cast(float, v.z); mk[ee][3] = __builtin_bit_cast(float, v.w);
+            }
+        }
+        if constexpr (!E_FWD) {
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee) {
+                const uint4 v = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_ij, off[ee], 0, 0));
+                ij[ee][0] = __builtin_bit_cast(float, v.x); ij[ee][1] = __builtin_bit_cast(float, v.y); ij[ee][2] = __builtin_bit_cast(float, v.z); ij[ee][3] = __builtin_bit_cast(float, v.w);
+            }
+        }
+#pragma unroll
+        for (int ee = 0; ee < 4; ++ee) {
+            const int e = 4 * ebl + ee;                     // compile-time (H4: row within this wave's half)
+            float y00, y01, y10, y11;
+            out_xf(e, y00, y01, y10, y11);
+            if constexpr (E_POOL) {
+                const float b = bs[E_FWD ? ee : 0];
+                float pm = y00 > y01 ? y00 : y01;
+                const float p1 = y10 > y11 ? y10 : y11, pm2 = pm > p1 ? pm : p1;
+                pm = prow1 ? pm2 : pm;
+                const float qb = pm + b;
+                const unsigned slot = y00 + b == qb ? 0u : (y01 + b == qb ? 1u : (y10 + b == qb ? 2u : 3u));
+                const unsigned po = (plive && mb + ee < a.M) ? (unsigned)(mb + ee) * pplane + ppix : kOOB;
+                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(slot | (qb > 0.f ? 4u : 0u)), rs_pa, po, 0, 0);
+                pm += b;
+                pm = pm > 0.f ? pm : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pm), rs_po, po == kOOB ? kOOB : po * 4u, 0, 0);
+            }
+            if constexpr (NOOUT) continue;
+            // give away the row this lane does not keep, receive the partner's part of the row it keeps (quad_perm 1,0,3,2)
+            const float s0 = odd ? y00 : y10, s1 = odd ? y01 : y11;
+            const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xf, 0xf, true));
+            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xf, 0xf, true));
+            float o[4];
+            o[0] = odd ? r0 : y00; o[1] = odd ? r1 : y01; o[2] = odd ? y10 : r0; o[3] = odd ? y11 : r1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (E_FWD) {
+                    o[j] += bs[E_FWD ? ee : 0];
+                    o[j] = o[j] > 0.f ? o[j] : 0.f;
+                } else {
+                    if constexpr (E_MASK) o[j] = mk[E_MASK ? ee : 0][j] > 0.f ? o[j] : 0.f;
+                    const float oi = o[j] + ij[E_FWD ? 0 : ee][j];
+                    o[j] = has_inj ? oi : o[j];
+                }
+            }
+            wn_u32x4 ov;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ov[j] = __builtin_bit_cast(unsigned, o[j]);
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rs_o, off[ee], 0, 0);
+        }
+    }
   } else {
     // ---- epilogue: output transform (in-lane), then bias / ReLU / mask / inject.
     // A lane holds the 2x2 outputs of one tile; tiles of neighbouring lanes are neighbours in x.  Each lane PAIR swaps
@@ -715,6 +817,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_unpool(cons
 // forward launches that write only the pooled blob and its arg-max map
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_noout(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, false, false, false, false, true>(a); }
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_noout(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true, false, false, true>(a); }
+// specialised epilogues of the six hot builds (EPI: 1 forward, 2 forward + pool, 3 masked data gradient, 4 unmasked data gradient)
+#define ST2_WINO_EPI(NAME, BOUNDS, ...) __global__ __launch_bounds__(256, BOUNDS) void NAME(const WinoKArgs a) { conv3x3_wino_body<__VA_ARGS__>(a); }
+ST2_WINO_EPI(conv3x3_wino_f32_128x128_fwd, 1, 4, 1, 0, true, false, false, false, false, false, false, 1)
+ST2_WINO_EPI(conv3x3_wino_f32_128x128_pool, 1, 4, 1, 0, true, false, false, false, false, false, false, 2)
+ST2_WINO_EPI(conv3x3_wino_f32_128x128_poolonly, 1, 4, 1, 0, true, false, false, false, false, false, true, 2)
+ST2_WINO_EPI(conv3x3_wino_f32_128x128_dgm, 1, 4, 1, 0, true, false, false, false, false, false, false, 3)
+ST2_WINO_EPI(conv3x3_wino_f32_128x128_dg, 1, 4, 1, 0, true, false, false, false, false, false, false, 4)
+ST2_WINO_EPI(conv3x3_wino_f32_128x128_unpool_dgm, 1, 4, 1, 0, true, false, false, false, true, false, false, 3)
+ST2_WINO_EPI(conv3x3_wino_f32_h4_64x128_fwd, 2, 2, 1, 0, true, false, false, true, false, false, false, 1)
+ST2_WINO_EPI(conv3x3_wino_f32_h4_64x128_pool, 2, 2, 1, 0, true, false, false, true, false, false, false, 2)
+ST2_WINO_EPI(conv3x3_wino_f32_h4_64x128_poolonly, 2, 2, 1, 0, true, false, false, true, false, false, true, 2)
+ST2_WINO_EPI(conv3x3_wino_f32_h4_64x128_dgm, 2, 2, 1, 0, true, false, false, true, false, false, false, 3)
+ST2_WINO_EPI(conv3x3_wino_f32_h4_64x128_dg, 2, 2, 1, 0, true, false, false, true, false, false, false, 4)
+ST2_WINO_EPI(conv3x3_wino_f32_h4_64x128_unpool_dgm, 2, 2, 1, 0, true, false, false, true, true, false, false, 3)
+#undef ST2_WINO_EPI
 // tensors of 4 GiB and more (per-chunk buffer resources): the 128-channel and the half-tile kernel, plain and unpooling
 __global__ __launch_bounds__(256, 1) void conv3x3_wino_f32_128x128_big(const WinoKArgs a) { conv3x3_wino_body<4, 1, 0, true, false, false, false, false, true>(a); }
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_h4_64x128_big(const WinoKArgs a) { conv3x3_wino_body<2, 1, 0, true, false, false, true, false, true>(a); }
@@ -909,6 +1026,25 @@ hipError_t launch_conv3x3_wino_cfg(const ConvProblem& p, int variant, hipStream_
     if (noout && (!k.pool_out || !k.pool_amap || k.splits > 1 || !quad || p.mask_src || p.inject || big || unpool || !(variant == 0 || variant == 8)))
         return hipErrorInvalidValue;
     const dim3 g((unsigned)(nblk * k.splits)), b(256);
+    {   // the epilogue specialised for this launch's kind, where there is one (ST2_WINO_EPI=0: the generic epilogue; read per launch: the
+        // tests compare both bit for bit)
+        const char* ee = getenv("ST2_WINO_EPI");
+        const bool fwd = p.bias && p.relu && !p.mask_src && !p.inject, dgr = !p.bias && !p.relu && !p.pool_out;
+        if (!(ee && *ee == '0') && (variant == 0 || variant == 8) && quad && !big && k.splits == 1 && (fwd || dgr) && (!k.pool_out || k.pool_amap || !p.pool_amap)) {
+            const bool v0 = variant == 0;
+            bool done = true;
+            if (noout) { if (v0) conv3x3_wino_f32_128x128_poolonly<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128_poolonly<<<g, b, 0, s>>>(k); }
+            else if (unpool) {
+                if (dgr && p.mask_src) { if (v0) conv3x3_wino_f32_128x128_unpool_dgm<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128_unpool_dgm<<<g, b, 0, s>>>(k); }
+                else done = false;
+            }
+            else if (fwd && k.pool_out) { if (v0) conv3x3_wino_f32_128x128_pool<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128_pool<<<g, b, 0, s>>>(k); }
+            else if (fwd) { if (v0) conv3x3_wino_f32_128x128_fwd<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128_fwd<<<g, b, 0, s>>>(k); }
+            else if (p.mask_src) { if (v0) conv3x3_wino_f32_128x128_dgm<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128_dgm<<<g, b, 0, s>>>(k); }
+            else { if (v0) conv3x3_wino_f32_128x128_dg<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_h4_64x128_dg<<<g, b, 0, s>>>(k); }
+            if (done) return hipGetLastError();
+        }
+    }
     switch (variant) {
     case 0: if (noout) conv3x3_wino_f32_128x128_noout<<<g, b, 0, s>>>(k);
             else if (big) { if (unpool) conv3x3_wino_f32_128x128_unpool_big<<<g, b, 0, s>>>(k); else conv3x3_wino_f32_128x128_big<<<g, b, 0, s>>>(k); }

@@ -65,10 +65,11 @@ void dfree16(unsigned short*& p)
 static bool dgrad_takes_split(const st_ctx* c, const Layer& L, int h, int w)
 {
     if (!(c->wino && c->wino_split && !c->bf16 && L.us_bwd && conv_wino_split_ok(L.cout, L.cin, h, w))) return false;
-    // K = 64 (conv1_2's data gradient: four 16-channel chunks per workgroup, half its time prologue and epilogue) where the fp32 kernel
-    // can unpool in its input transform: measured 403.7 us + 59.6 us of maxpool_bwd_amap_k against 428.7 us for the fp32 launch alone
-    // (profiles/r05_k_split_per_layer.txt, r04_z_per_layer.txt) -- that one stays on the fp32 matrix cores
-    if (L.cout <= 64 && L.u_bwd && conv_wino_can_unpool(L.cout, L.cin, h, w)) return false;
+    // ST2_WS_DGRAD64=0: K <= 64 launches that the fp32 kernel could unpool (conv1_2's data gradient) stay on the fp32 matrix cores.  With
+    // the first split epilogue that was the faster route (404 + 60 us of maxpool_bwd_amap_k against 429 us); since the branch-free
+    // epilogue it is not (same-box A/B, profiles/r05_s_ab_split.txt: 177.4 against 176.1 it/s) -- kept as a switch for the A/B only
+    { const char* e = getenv("ST2_WS_DGRAD64");
+      if (e && *e == '0' && L.cout <= 64 && L.u_bwd && conv_wino_can_unpool(L.cout, L.cin, h, w)) return false; }
     return true;
 }
 

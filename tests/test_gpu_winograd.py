@@ -193,3 +193,55 @@ def test_lean_fp32_iterations_skip_dead_blobs_and_change_nothing(optimizer, weig
         for k in ta:
             if k != 'time':
                 assert ta[k] == tb[k] or (np.isnan(ta[k]) and np.isnan(tb[k])), k
+
+
+@pytest.mark.parametrize('h,w', [(64, 96), (66, 100), (70, 256), (8, 32), (17, 72)])
+def test_specialised_epilogues_equal_the_generic_epilogue_bit_for_bit(h, w, monkeypatch):
+    """Round 5: the 128-channel and the half-tile build have an epilogue per launch KIND (forward, forward + pool, pooled blob only,
+    data gradient with / without the ReLU mask, unpooling data gradient) -- buffer accesses with zero-size resources and out-of-range
+    offsets instead of run-time flags, branches and 64-bit addresses; ST2_WINO_EPI=0 keeps the generic epilogue.  The arithmetic is
+    the same, operation for operation: forward blobs (fused pools and their arg-max maps included: the pooled blobs and the gradient
+    through the maps), the image gradient with diffs injected at conv blobs with and without a mask below them, and lean iterations
+    (pooled-blob-only builds) must be the same bits."""
+    topo = oracle.VGG19_TOPOLOGY[:7]                    # conv1_1 conv1_2 pool1 conv2_1 conv2_2 pool2 conv3_1
+    params = oracle.he_init_weights(topo, seed=3, bias_std=0.3)
+    rng = np.random.RandomState(h + w)
+    x = (rng.randn(1, 3, h, w) * 40).astype(F32)
+    out = {}
+    for epi in ('1', '0'):
+        monkeypatch.setenv('ST2_WINO_EPI', epi)
+        gpu = st2.HipModel(params, topology=topo)
+        f = gpu.forward(x, ['conv1_1', 'conv1_2', 'pool1', 'conv2_1', 'conv2_2', 'pool2', 'conv3_1'])
+        r2 = np.random.RandomState(7)
+        grads = [gpu.backward({n: r2.randn(*f[n].shape).astype(F32) for n in names})
+                 for names in (('conv3_1', 'conv2_1'), ('pool2',), ('conv3_1', 'conv2_2', 'conv2_1', 'pool1', 'conv1_2', 'conv1_1'), ('conv2_2',))]
+        out[epi] = (f, grads)
+    for n in out['1'][0]:
+        assert np.array_equal(out['1'][0][n], out['0'][0][n]), n
+    for ga, gb in zip(out['1'][1], out['0'][1]):
+        assert np.array_equal(ga, gb)
+    assert float(np.abs(out['1'][1][0]).max()) > 0
+
+
+def test_specialised_epilogues_in_lean_iterations_change_nothing(monkeypatch):
+    """... and inside iterations (the pooled-blob-only builds, fused Adam): iterates and traces of three steps, bit for bit."""
+    topo = oracle.VGG19_TOPOLOGY[:10]
+    params = oracle.he_init_weights(topo, seed=3, bias_std=0.2)
+    rs = np.random.RandomState
+    content, style, init = (rs(1).randint(0, 256, (256, 512, 3)).astype(np.uint8), rs(2).randint(0, 256, (40, 36, 3)).astype(np.uint8),
+                            rs(3).randint(0, 256, (256, 512, 3)).astype(np.uint8))
+    weights = {'content': {'conv3_2': 0.08}, 'style': {'conv1_1': 1, 'conv2_1': 1, 'conv3_1': 1}, 'deepdream': {}}
+    runs = {}
+    for epi in ('1', '0'):
+        monkeypatch.setenv('ST2_WINO_EPI', epi)
+        dev = st2.StyleTransfer(st2.HipModel(params, topology=topo))
+        dev.set_input(init); dev.set_content(content); dev.set_style(style); dev.reset()
+        dev.set_weights(weights, {'p': 50, 'p_power': 6, 'tv': 5, 'tv_power': 2})
+        dev.optimizer_cls = st2.AdamOptimizer; dev.set_step_size(10); dev.reset()
+        assert dev.start()
+        runs[epi] = [(np.asarray(i).copy(), dict(t)) for i, t in (dev.step() for _ in range(3))]
+    for (ia, ta), (ib, tb) in zip(runs['1'], runs['0']):
+        assert np.array_equal(ia, ib)
+        for k in ta:
+            if k != 'time':
+                assert ta[k] == tb[k] or (np.isnan(ta[k]) and np.isnan(tb[k])), k
