@@ -34,6 +34,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 constexpr int NT = 256;
 constexpr int PXW = 34;                       // staged pixels per row: x0-1 .. x0+32
 constexpr unsigned kOOB16 = 0xffffffffu;
+// A 16-byte buffer store whose soffset is an SGPR must not be followed by a VALU write of its data registers: measured on gfx950 (round 5),
+// buffer_store_dwordx4 v[80:83], v116, s[20:23], s35 offen  followed by  v_pk_add_f32 v[80:81], ...  stored the NEW v81 in lanes 12 .. 15 of
+// every 16 -- the hazard of the ISA manual's wait-state table (store data of more than 64 bits), which hipcc (ROCm 7.2) guards only when
+// soffset is NOT a register.  So the per-launch-kind epilogues add the wave-uniform part of the offset into the vector offset and pass
+// soffset = 0 (the guarded form; one v_add per store).  The "do not write" offset of such a store is 2 GiB: above every bf16 buffer of a
+// launch (their fp32 twin is checked to be < 4 GiB) and, unlike kOOB16, still out of range after the uniform part is added.
+constexpr unsigned kOOBStore = 0x80000000u;
 
 static unsigned short f2bf(float f)           // round-to-nearest-even, host side
 {
@@ -115,7 +122,9 @@ __device__ __forceinline__ unsigned nonzero_halves16(uint2 u0, uint2 u1)
 //   DG = true,  "data gradient":  ReLU mask of the blob below (mask_src / mask16 / mask_bits), inject, fp32 / bf16 outputs, the fused style term
 // (a launch with none of these options runs on the forward build)
 // MB (data-gradient builds): the ReLU mask comes as a sign map (mask_bits) -- the other two forms have their own build, for the same reason
-template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false, bool UNPOOL = false, bool DG = UNPOOL, bool MB = false, bool DIAG = false>
+// EPI (round 5): 0 = the epilogue with every option of its direction behind run-time flags; 1 .. 3 = the epilogue of ONE launch kind of
+// the lean flow (see "one epilogue per launch kind" below) -- at K = 64 the general epilogue ran as long as the main loop
+template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false, bool UNPOOL = false, bool DG = UNPOOL, bool MB = false, bool DIAG = false, int EPI = 0>
 __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 {
     unsigned long long t_start = 0, t_first = 0, t_loop = 0, c_first = 0, c_loop = 0;      // 100 MHz ticks / shader cycles
@@ -655,7 +664,160 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             }
         }
     };
-    if (full_m) tile_out(std::true_type{}); else tile_out(std::false_type{});
+    if constexpr (EPI != 0) {
+        // ---- one epilogue per launch kind (round 5).  The lean flow launches four kinds over and over, none of which writes fp32:
+        //   EPI 1  forward build:        (bias, ReLU) -> bf16 copy (+ sign map)         -- also the data gradients with no option at all
+        //   EPI 2  forward build:        (bias, ReLU) -> 2x2 max-pool -> pooled bf16 copy + arg-max map (whole windows: H, W even)
+        //   EPI 3  data-gradient build:  sign-map ReLU mask (here, or before the fused style chunks) -> bf16 copy
+        // every tile whole in M (M % BM == 0, checked at launch).  Same arithmetic on every value as the general epilogue below (the
+        // tests compare bit for bit, ST2_CONV16_EPI=0 selects the general one), but every global access is a buffer access -- a
+        // wave-uniform scalar offset per 16-channel row group, one vector offset per pixel row, out-of-range for what must not be
+        // written -- so the per-element 64-bit addresses, bounds tests and run-time option branches are gone: ~40 instructions per
+        // (16 channels x 32 pixels) instead of ~300.  ReLU is an integer maximum of the bit pattern with 0 (off: with INT_MIN): v > 0 ? v : +0
+        // for every v that is not a NaN.
+        static_assert(!DIAG && (EPI == 3) == (DG && MB) && (EPI != 2 || TN % 2 == 0), "launch kinds");
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const unsigned mrow0 = (unsigned)(m0 + wave_m * (TM * 32));
+        const int floor_i = (!DG && a.relu) ? 0 : (int)0x80000000;
+        const __amdgpu_buffer_rsrc_t rs_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, (!DG && a.bias) ? (unsigned)a.MPad * 4u : 0u, 0x00020000);
+        auto finish8 = [&](int i, int j, int h, const float (&bs)[8], float (&v)[8]) __attribute__((always_inline)) {      // bias + ReLU of 8 accumulators
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float s = acc[i][j][8 * h + e] + bs[e];
+                const int b = __builtin_bit_cast(int, s);
+                v[e] = __builtin_bit_cast(float, __builtin_elementwise_max(b, floor_i));
+            }
+        };
+        auto load_bias = [&](int i, int h, float (&bs)[8]) __attribute__((always_inline)) {      // channels mbase .. +3 and mbase + 8 .. + 11 (zeros without a bias)
+            const unsigned so = (mrow0 + i * 32 + 16 * h) * 4u;
+            // (through HIP's uint4: the builtin's result assigned to an ext_vector_type is narrowed to ONE dword by this compiler)
+            const uint4 b0 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, 16u * khalf, so, 0));
+            const uint4 b1 = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs_bias, 16u * khalf + 32u, so, 0));
+            bs[0] = __builtin_bit_cast(float, b0.x); bs[1] = __builtin_bit_cast(float, b0.y); bs[2] = __builtin_bit_cast(float, b0.z); bs[3] = __builtin_bit_cast(float, b0.w);
+            bs[4] = __builtin_bit_cast(float, b1.x); bs[5] = __builtin_bit_cast(float, b1.y); bs[6] = __builtin_bit_cast(float, b1.z); bs[7] = __builtin_bit_cast(float, b1.w);
+        };
+        auto pack8 = [&](const float (&v)[8], uint2& u0, uint2& u1) __attribute__((always_inline)) {
+            bf16x4 pk0, pk1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { pk0[e] = (__bf16)v[e]; pk1[e] = (__bf16)v[4 + e]; }
+            u0 = __builtin_bit_cast(uint2, pk0); u1 = __builtin_bit_cast(uint2, pk1);
+        };
+        if constexpr (EPI == 1 || EPI == 3) {
+            const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)a.out16, 0, (unsigned)a.M * plane * 2u, 0x00020000);
+            unsigned vo[TN];                                     // this lane's quad (lanes 32 .. 63: the second quad of the 16 channels) of pixel j
+#pragma unroll
+            for (int j = 0; j < TN; ++j) vo[j] = livej[j] ? ((unsigned)khalf * plane + pixj[j]) * 16u : kOOBStore;
+            // eight bf16 values in four words -> one byte, bit e = value e is non-zero (nonzero_halves16 without a condition register)
+            auto nz8 = [&](uint2 u0, uint2 u1) __attribute__((always_inline)) -> unsigned {
+                // min(half, 1) per 16-bit half.  The 1s pass through an EMPTY asm so that the compiler cannot turn the minimum back into two
+                // compares + selects per word; the instruction itself must stay visible to it (v_pk_min_u16 inside an asm statement, where its
+                // hazard recogniser does not look: the second v_permlane32_swap behind it came out wrong in lanes 12 .. 15 / 28 .. 31)
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                unsigned ones = 0x00010001u;
+                asm("" : "+v"(ones));
+                auto one = [&](unsigned w) __attribute__((always_inline)) {
+                    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), __builtin_bit_cast(u16x2, ones)));
+                };
+                const unsigned x = one(u0.x) | (one(u0.y) << 2), y = one(u1.x) | (one(u1.y) << 2);
+                const unsigned z = x | (y << 4);                 // low halves at bits 0 2 4 6, high halves at 16 18 20 22
+                return (z & 0x55u) | ((z >> 15) & 0xaau);
+            };
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                unsigned mbits[TN];
+                if constexpr (EPI == 3) { if (!fuse_style) load_bits(i, mbits); }
+                unsigned obits[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) obits[j] = 0u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float bs[8];
+                    if constexpr (EPI == 1) load_bias(i, h, bs);
+                    const unsigned so = ((mrow0 + i * 32 + 16 * h) >> 3) * plane * 16u;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float v[8];
+                        if constexpr (EPI == 1) finish8(i, j, h, bs, v);
+                        else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * h + e];
+                            if (!fuse_style) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] = keep_if_bit(v[e], mbits[j], 8 * h + e);
+                            }
+                        }
+                        uint2 u0, u1;
+                        pack8(v, u0, u1);
+                        if (EPI == 1 && bits_out) obits[j] |= nz8(u0, u1) << (8 * h);
+                        const auto sx = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){sx[0], sy[0], sx[1], sy[1]}, rs_o, vo[j] + so, 0, 0);      // (no SGPR offset: see kOOBStore)
+                    }
+                }
+                if (EPI == 1 && bits_out) {                      // (M % BM == 0: no padding group on this path)
+                    const unsigned blk = (mrow0 + i * 32) >> 5;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(obits[j], obits[j], false, false);
+                        __builtin_amdgcn_raw_buffer_store_b32(obits[j] | (sw[1] << 16), rs_ob, (livej[j] && !khalf) ? pixj[j] * 4u : kOOB16, blk * plane * 4u, 0);
+                    }
+                }
+            }
+        } else {
+            // Caffe MAX 2x2/2 on whole windows: a pair of this wave's rows is one row of windows, lane pairs (even gx, gx + 1) its columns;
+            // first maximum of the row-major scan, strictly greater (oracle.caffe_net.maxpool_forward) -- the general epilogue's scan
+            const unsigned pplane = (unsigned)a.pool_h * a.pool_w;
+            const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pool16, 0, (unsigned)a.M * pplane * 2u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.amap, 0, (unsigned)a.M * pplane, 0x00020000);
+            unsigned vq[TN / 2];                                 // quad index of this lane's window of row pair jp (writers: even columns inside the image)
+#pragma unroll
+            for (int jp = 0; jp < TN; jp += 2) {
+                const int gy0 = y0 + wave_n * TN + jp;
+                const bool writer = !(l31 & 1) && colv && gy0 < a.H;
+                vq[jp / 2] = writer ? (unsigned)khalf * pplane + (unsigned)(gy0 >> 1) * a.pool_w + (gx >> 1) : (kOOBStore >> 4);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float bs[8];
+                    load_bias(i, h, bs);
+                    const unsigned sq = ((mrow0 + i * 32 + 16 * h) >> 3) * pplane;
+                    float v[TN][8];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) finish8(i, j, h, bs, v[j]);
+#pragma unroll
+                    for (int jp = 0; jp < TN; jp += 2) {
+                        float best[8];
+                        unsigned code[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float p0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[jp][e]), 0xB1, 0xf, 0xf, true));
+                            const float p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[jp + 1][e]), 0xB1, 0xf, 0xf, true));
+                            float bb = v[jp][e];
+                            unsigned sl = 0;
+                            if (p0 > bb) { bb = p0; sl = 1; }
+                            if (v[jp + 1][e] > bb) { bb = v[jp + 1][e]; sl = 2; }
+                            if (p1 > bb) { bb = p1; sl = 3; }
+                            best[e] = bb;
+                            code[e] = sl | (bb > 0.0f ? 4u : 0u);
+                        }
+                        uint2 u0, u1;
+                        pack8(best, u0, u1);
+                        const unsigned c0 = code[0] | (code[1] << 8) | (code[2] << 16) | (code[3] << 24);
+                        const unsigned c1 = code[4] | (code[5] << 8) | (code[6] << 16) | (code[7] << 24);
+                        const auto sx = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
+                        const auto sc = __builtin_amdgcn_permlane32_swap(c0, c1, false, false);
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){sx[0], sy[0], sx[1], sy[1]}, rs_p, (vq[jp / 2] + sq) * 16u, 0, 0);      // (no SGPR offset: see kOOBStore)
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){sc[0], sc[1]}, rs_a, vq[jp / 2] * 8u, sq * 8u, 0);
+                    }
+                }
+        }
+    } else {
+        if (full_m) tile_out(std::true_type{}); else tile_out(std::false_type{});
+    }
     if constexpr (DIAG) {
         if (a.stamps && threadIdx.x == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the stores are out of the wave's queue
@@ -688,6 +850,16 @@ __global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb_dg(const Co
 __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_diag(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, false, false, false, true>(a); }
 __global__ __launch_bounds__(NT, 3) void conv3x3_mfma_bf16_64x256_sb_diag(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, false, false, true>(a); }
 __global__ __launch_bounds__(NT, SB_WPE) void conv3x3_mfma_bf16_64x256_sb_dgb(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, true, true>(a); }
+
+// one epilogue per launch kind (conv16_body, EPI): the tiles and kinds the lean 2048^2 flow launches
+__global__ __launch_bounds__(NT, SB_WPE) void conv3x3_mfma_bf16_64x256_sb_f16(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, false, false, false, 1>(a); }
+__global__ __launch_bounds__(NT, SB_WPE) void conv3x3_mfma_bf16_64x256_sb_pool(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, true, false, false, false, false, 2>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_f16(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, false, false, false, false, 1>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_pool(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, false, false, false, false, 2>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_dgb16(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, false, true, true, false, 3>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_unpool_b16(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, true, true, true, false, 3>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_f16(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, false, false, false, false, 1>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_dgb16(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, false, true, true, false, 3>(a); }
 
 static int conv16_pick_cfg(const Conv16Problem& p)
 {
@@ -782,6 +954,22 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     }
     const bool mb = p.mask_bits != nullptr;
     if (mb && (p.mask_src || p.mask16)) return hipErrorInvalidValue;            // one form of the mask per launch
+    // one epilogue per launch kind (conv16_body, EPI) where the launch is one of those kinds; ST2_CONV16_EPI=0: the general epilogue (read per launch: tests)
+    int epi = 0;
+    {
+        const char* ee = getenv("ST2_CONV16_EPI");
+        const bool lean16 = !(ee && *ee == '0') && p.M % BM == 0 && !p.out && !p.mask_src && !p.mask16 && !p.inject && !p.pool32;
+        if (lean16 && !dg && p.out16 && !pools) epi = 1;
+        else if (lean16 && !dg && pools && p.pool16 && p.amap && !p.out16 && !p.bits_out && p.H % 2 == 0 && p.W % 2 == 0) epi = 2;
+        else if (lean16 && dg && mb && p.out16) epi = 3;
+        const char* ek = getenv("ST2_CONV16_EPI_KINDS");     // bit (kind - 1): that kind may run (default: all three)
+        if (epi && ek && *ek && !((atoi(ek) >> (epi - 1)) & 1)) epi = 0;
+    }
+    if (epi && cfg == 0 && sb && !dg) { if (epi == 1) conv3x3_mfma_bf16_64x256_sb_f16<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x256_sb_pool<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
+    if (epi && cfg == 3 && !dg) { if (epi == 1) conv3x3_mfma_bf16_64x512_f16<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x512_pool<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
+    if (epi == 3 && cfg == 3) { if (unpool) conv3x3_mfma_bf16_64x512_unpool_b16<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x512_dgb16<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
+    if (epi == 1 && cfg == 0 && !sb) { conv3x3_mfma_bf16_64x256_f16<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
+    if (epi == 3 && cfg == 0 && !sb && !unpool) { conv3x3_mfma_bf16_64x256_dgb16<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
 #define ST2_CONV16_LAUNCH3(NAME) do { if (mb) NAME##_dgb<<<grid, block, 0, s>>>(k); else if (dg) NAME##_dg<<<grid, block, 0, s>>>(k); else NAME<<<grid, block, 0, s>>>(k); } while (0)
     if (cfg == 0 && sb) ST2_CONV16_LAUNCH3(conv3x3_mfma_bf16_64x256_sb);
     else if (cfg == 3 && unpool) { if (mb) conv3x3_mfma_bf16_64x512_unpool_b<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x512_unpool<<<grid, block, 0, s>>>(k); }

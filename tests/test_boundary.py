@@ -415,6 +415,34 @@ def test_no_product_kernel_uses_scratch():
     assert not [k for k in kernels if 'probe' in k], 'development probes belong to tools/probes/, not the product library'
 
 
+def test_no_product_kernel_stores_16_bytes_at_an_sgpr_offset():
+    """A buffer store of more than 64 bits whose soffset is an SGPR may be followed at once by a VALU write of its data registers
+    (hipcc guards that hazard only for a constant soffset), and gfx950 then stores the NEW value in some lanes -- measured in round 5
+    (conv3x3_mfma_bf16.hip, kOOBStore).  The kernels fold the wave-uniform offset into the vector offset instead; this keeps it so."""
+    llvm = '/opt/rocm/lib/llvm/bin'
+    if not os.path.exists(os.path.join(llvm, 'llvm-objdump')):
+        pytest.skip('ROCm llvm tools absent')
+    import shutil
+    import tempfile
+    wide, bad = 0, []
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = shutil.copy(capi.lib_path(), tmp)
+        subprocess.run([os.path.join(llvm, 'llvm-objdump'), '--offloading', copy], check=True, capture_output=True)
+        for f in sorted(os.listdir(tmp)):
+            if 'amdgcn' not in f:
+                continue
+            asm = subprocess.run([os.path.join(llvm, 'llvm-objdump'), '-d', '--no-show-raw-insn', os.path.join(tmp, f)], check=True,
+                                 capture_output=True, text=True).stdout
+            for line in asm.splitlines():
+                m = re.search(r'buffer_store_dwordx[34]\s+v\[\d+:\d+\],\s*(?:v\d+|off),\s*s\[\d+:\d+\],\s*(\S+)', line)
+                if m:
+                    wide += 1
+                    if re.match(r'(s\d+|m0|ttmp\d+)', m.group(1)):
+                        bad.append(line.strip())
+    assert wide >= 100, wide                      # (the pattern still matches this disassembler's output)
+    assert not bad, bad[:5]
+
+
 # --------------------------------------------------------------------------- host-side mirrors
 def test_package_weight_table_matches_pandas_vectors():
     for name, case in load_json('weight_order.json').items():

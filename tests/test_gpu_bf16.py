@@ -435,3 +435,28 @@ def test_single_buffer_pipeline_of_the_short_reductions_changes_no_bit(size, mon
         assert a[2] == b[2] and np.array_equal(a[3], b[3]), flag
         for (la, ia), (lb, ib) in zip(a[4], b[4]):
             assert la == lb and np.array_equal(ia, ib), flag
+
+
+@pytest.mark.parametrize('size', [(512, 512), (160, 224), (96, 132)])
+def test_one_epilogue_per_launch_kind_changes_no_bit(size, conv16_cfg, monkeypatch):
+    """Round 5: the launch kinds the lean flow repeats -- (bias, ReLU) -> bf16 copy + sign map, (bias, ReLU) -> fused pool -> pooled bf16
+    copy + arg-max map, sign-map mask (in the store epilogue or before the fused style chunks) -> bf16 copy, with or without the
+    unpooling input -- have an epilogue of their own on the 64x512 and 64x256 pixel tiles (conv16_body, EPI: buffer accesses, no
+    run-time option flags); ST2_CONV16_EPI=0 keeps the general epilogue.  Same arithmetic on every value: objective, gradient and
+    trajectories are the same bits (first evaluation: masks in the store epilogue; later ones: style term fused), clipped tiles at
+    the right and bottom edge included (160x224, 96x132)."""
+    if conv16_cfg in ('1', '2'):
+        pytest.skip('the 128x128 and 64x128 pixel tiles have the general epilogue only')
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('ST2_CONV16_EPI', flag)
+        job = _bf16_job('bf16', size, LEAN_WEIGHTS, 'adam')
+        first = job.opfunc()
+        second = job.opfunc()
+        steps = [job.step() for _ in range(2)]
+        out[flag] = (first[0], first[1].copy(), second[0], second[1].copy(), [(t['loss'], i.copy()) for i, t in steps])
+    a, b = out['1'], out['0']
+    assert np.isfinite(a[0]) and a[0] == b[0] and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and np.array_equal(a[3], b[3])
+    for (la, ia), (lb, ib) in zip(a[4], b[4]):
+        assert la == lb and np.array_equal(ia, ib)
