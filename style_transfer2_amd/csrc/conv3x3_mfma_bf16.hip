@@ -24,6 +24,10 @@
 #include <string.h>
 #include <type_traits>
 
+#ifndef CONV16_BR
+#define CONV16_BR 1          // 0: every tile on the tap-by-tap loop (development A/B: build a second library, ST2_HIP_LIB)
+#endif
+
 namespace st2 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -127,6 +131,9 @@ __device__ __forceinline__ unsigned nonzero_halves16(uint2 u0, uint2 u1)
 template <int BM, int ROWS, int WAVES_M, int WAVES_N, bool SB = false, bool UNPOOL = false, bool DG = UNPOOL, bool MB = false, bool DIAG = false, int EPI = 0>
 __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 {
+    // BR (round 5): the four-rows-per-wave tile walks a chunk column by column of the 3x3 stencil and keeps the activation fragments of its
+    // six input rows in registers -- see "activation fragments reused" at the main loop
+    constexpr bool BR = CONV16_BR && !SB && !UNPOOL && ROWS / WAVES_N == 4 && BM / WAVES_M / 32 == 2;
     unsigned long long t_start = 0, t_first = 0, t_loop = 0, c_first = 0, c_loop = 0;      // 100 MHz ticks / shader cycles
     if constexpr (DIAG) {
         if (a.diag_stagger > 0 && blockIdx.x < 2 * 256) {       // does a convoy of co-resident workgroups cost anything?  offset their phases once
@@ -278,7 +285,10 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     const int a_off = khalf * BM + wave_m * (TM * 32) + l31;                                   // + tap*2*BM + i*32
     const int b_off = W_QUADS + khalf * IN_ROWS * PXW + (wave_n * TN) * PXW + l31;             // + (j+dy)*PXW + dx
 
-    bf16x8 av[3][TM], bv[3][TN];
+    // Every build adds the nine taps of a chunk in the SAME order -- column by column of the stencil (dx = 0: dy = 0, 1, 2; dx = 1: ...) --
+    // so that the tile configurations stay bit-identical to each other (the tests compare them): step s of a chunk is tap 3 (s % 3) + s / 3
+    auto tap_of = [](int s2) { return (s2 % 3) * 3 + s2 / 3; };
+    bf16x8 av[BR ? 1 : 3][TM], bv[BR ? 1 : 3][TN];
     auto fetch = [&](const uint4* base, int tap, bf16x8 (&ao)[TM], bf16x8 (&bo)[TN]) {
         const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
@@ -294,7 +304,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                         // chunk ch has landed
         if constexpr (DIAG) { if (ch == 0) { t_first = __builtin_amdgcn_s_memrealtime(); c_first = __builtin_amdgcn_s_memtime(); } }
-        fetch(smem, 0, av[0], bv[0]);
+        fetch(smem, tap_of(0), av[0], bv[0]);
 #pragma unroll
         for (int s2 = 0; s2 < NSTEP; ++s2) {
 #pragma unroll
@@ -303,7 +313,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s2 % 3][i], bv[s2 % 3][j], acc[i][j], 0, 0, 0);
                 if (ij == 0 && s2 + 1 < NSTEP) {
                     __builtin_amdgcn_sched_barrier(0);
-                    fetch(smem, s2 + 1, av[(s2 + 1) % 3], bv[(s2 + 1) % 3]);
+                    fetch(smem, tap_of(s2 + 1), av[(s2 + 1) % 3], bv[(s2 + 1) % 3]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -315,6 +325,58 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             for (int t = 0; t < NPIECE; ++t) if (!(DIAG && a.diag_nodma)) dma_piece(t, ch + 1, 0);
         }
     }
+  } else if constexpr (BR) {
+    // ---- activation fragments reused (round 5).  The tap-by-tap loop reads TM + TN fragments from LDS per TM * TN MFMAs -- 0.75 ds_read_b128
+    // per MFMA on this tile, and a wave's ds_read_b128 holds the CU's LDS pipe for 8 clocks: four waves keep it busy 3/4 of the time their
+    // MFMAs take, which is what held the deep layers at ~0.57 of the matrix-core peak.  But tap (dy, dx) of output row j reads input row
+    // j + dy: a wave's four output rows touch six input rows, 18 (row, dx) fragments per chunk instead of 36 (tap, row).  So a chunk runs
+    // as three phases, one per stencil COLUMN dx: the six row fragments of that column live in registers (bfr), group r of a phase issues
+    // every MFMA that reads row r -- (dy, j = r - dy) for the dy that give a valid j, both 32-channel groups -- and then refills bfr[r]
+    // with the next phase's fragment (its next use is a whole phase away).  The weight fragments of a phase (3 dy x TM) are loaded one
+    // per group during the phase before, into the next of three register sets (three phases per chunk: the set index is static).
+    // 12 reads per 24 MFMAs: 0.5.  Per accumulator the taps arrive as (dx, dy ascending) -- tap_of()'s order.  The chunk barrier sits
+    // after group 0 of the last phase; every read of the next chunk's buffer comes behind it.
+    static_assert(TN + 2 == 3 * TM, "one weight fragment and one activation fragment per group");
+    bf16x8 afr[3][3][TM], bfr[TN + 2];
+    auto load_a = [&](const uint4* base, int dx, int idx, bf16x8 (&ao)[3][TM]) __attribute__((always_inline)) {
+        const int dy = idx / TM, i = idx % TM;
+        ao[dy][i] = __builtin_bit_cast(bf16x8, base[a_off + (dy * 3 + dx) * 2 * BM + i * 32]);
+    };
+    auto load_b = [&](const uint4* base, int r, int dx) __attribute__((always_inline)) { bfr[r] = __builtin_bit_cast(bf16x8, base[b_off + r * PXW + dx]); };
+    __syncthreads();
+    if constexpr (DIAG) { t_first = __builtin_amdgcn_s_memrealtime(); c_first = __builtin_amdgcn_s_memtime(); }
+#pragma unroll
+    for (int r = 0; r < TN + 2; ++r) { load_a(smem, 0, r, afr[0]); load_b(smem, r, 0); }
+    for (int ch = 0; ch < a.nch; ++ch) {
+        const int cur = ch & 1;
+        const bool more = ch + 1 < a.nch;
+        const uint4* base = smem + cur * BUF_Q;
+        const uint4* next = smem + (cur ^ 1) * BUF_Q;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+#pragma unroll
+            for (int r = 0; r < TN + 2; ++r) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int j = r - dy;
+                    if (j < 0 || j >= TN) continue;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afr[dx][dy][i], bfr[r], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (dx < 2) {
+                    load_b(base, r, dx + 1);
+                    load_a(base, dx + 1, r, afr[dx + 1]);
+                    if (more && !(DIAG && a.diag_nodma) && dx * (TN + 2) + r < NPIECE) dma_piece(dx * (TN + 2) + r, ch + 1, cur ^ 1);
+                } else if (more) {
+                    if (r == 0) __syncthreads();                 // chunk ch + 1 has landed; every wave has issued its last reads of chunk ch
+                    else { load_b(next, r - 1, 0); load_a(next, 0, r - 1, afr[0]); }
+                    if (r == TN + 1) { load_b(next, r, 0); load_a(next, 0, r, afr[0]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
   } else {
     if constexpr (UNPOOL) {
         unpool_prefetch(0); unpool_landed();
@@ -323,7 +385,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
     }
     __syncthreads();
     if constexpr (DIAG) { t_first = __builtin_amdgcn_s_memrealtime(); c_first = __builtin_amdgcn_s_memtime(); }
-    fetch(smem, 0, av[0], bv[0]);
+    fetch(smem, tap_of(0), av[0], bv[0]);
     for (int ch = 0; ch < a.nch; ++ch) {
         const int cur = ch & 1;
         const bool more = ch + 1 < a.nch;
@@ -338,7 +400,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                 if (ij == 0) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (s2 + 1 < NSTEP) {
-                        fetch(base, s2 + 1, av[(s2 + 1) % 3], bv[(s2 + 1) % 3]);
+                        fetch(base, tap_of(s2 + 1), av[(s2 + 1) % 3], bv[(s2 + 1) % 3]);
                         if (more && !(DIAG && a.diag_nodma)) {
 #pragma unroll
                             for (int pp = 0; pp < PPS; ++pp)
@@ -352,7 +414,7 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                             for (int u = 0; u < I_PER_WAVE; ++u) unpool_quad(u, cur ^ 1);
                         }
                         __syncthreads();
-                        fetch(next, 0, av[0], bv[0]);            // 9 % 3 == 0: the next chunk starts on set 0 again
+                        fetch(next, tap_of(0), av[0], bv[0]);    // 9 % 3 == 0: the next chunk starts on set 0 again
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
