@@ -482,6 +482,51 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         // chunks accumulate D' @ F on top: A = D' = D scaled, as hi + lo bf16 terms (slab [hl][k half][BM] per 16 channels, packed by
         // style16_pack_d_scaled_k), B = the blob's own bf16 copy, staged as the conv's activation tile (its centre tap is the pixel).
         // Saves the separate style-gradient kernel, its fp32 output and this epilogue's read of it.
+        // Round 5: a style chunk is 2 MFMAs per accumulator behind a full staging step, so the chunks ran at one DMA latency each (conv2_2's
+        // data gradient at 2048^2: 14 of a workgroup's 44 us).  The double-buffered builds now stage a style chunk COMPACTLY -- the D' slab +
+        // the blob's 16 channels of exactly this tile's pixels, [k half][row][32 px], no halo: 20 KiB instead of 38 -- into a ring of three
+        // slots over the main loop's two buffers, two chunks in flight behind the one being multiplied (waits counted by hand), the first two
+        // issued before the mask is applied to the accumulators.
+        constexpr int SW_QUADS = 4 * BM;                         // [hl][k half][BM]
+        constexpr int SW_INSTR = SW_QUADS / 64;
+        static_assert(SW_QUADS <= W_QUADS, "the style slab fits the weight region");
+        constexpr int S_ACT = 2 * ROWS * 32, S_SLOT = SW_QUADS + S_ACT, SA_INSTR = S_ACT / 64;
+        constexpr int S_PW = SW_INSTR / 4 + SA_INSTR / 4;        // LDS-DMA instructions per wave and chunk
+        static_assert(SB || (3 * S_SLOT <= 2 * BUF_Q && SW_INSTR % 4 == 0 && SA_INSTR % 4 == 0), "three compact style chunks fit the two staging buffers");
+        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.s_wpack, 0, a.s_w_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)a.s_in16, 0, a.s_in_bytes, 0x00020000);
+        int ln = lane;
+        if constexpr (UNPOOL) asm volatile("" : "+v"(ln));      // computed HERE: hoisted above the main loop they would live through it in scratch
+        unsigned soff2[SB ? 1 : SA_INSTR / 4];
+        if constexpr (!SB) {
+#pragma unroll
+            for (int t = 0; t < SA_INSTR / 4; ++t) {
+                const int q = (wave + 4 * t) * 64 + ln;          // quad of the compact tile: [k half][row][px]
+                const int h = q / (ROWS * 32), rem = q - h * (ROWS * 32);
+                const int gy = y0 + (rem >> 5), gx2 = x0 + (rem & 31);
+                soff2[t] = (gy < a.H && gx2 < a.W) ? ((unsigned)h * plane + (unsigned)gy * a.W + gx2) * 16u : kOOB16;
+            }
+        }
+        auto s_dma3 = [&](int ch, int slot) __attribute__((always_inline)) {
+            uint4* dst = smem + slot * S_SLOT;
+#pragma unroll
+            for (int t = 0; t < SW_INSTR / 4; ++t) {
+                const int i = wave + 4 * t;
+                const int q = i * 64 + ln, r = q / BM, m = q - r * BM;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_d, (lptr_t)(dst + i * 64), 16, ((unsigned)(ch * 4 + r) * a.MPad + m0 + m) * 16u, 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < SA_INSTR / 4; ++t) {
+                const unsigned coff = (unsigned)ch * 2u * plane * 16u;
+                const unsigned vo = soff2[t] == kOOB16 ? kOOB16 : soff2[t] + coff;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_s, (lptr_t)(dst + SW_QUADS + (wave + 4 * t) * 64), 16, vo, 0, 0, 0);
+            }
+        };
+        if constexpr (!SB) {
+            __syncthreads();                                     // every wave has left the main loop's buffers
+            s_dma3(0, 0);
+            if (a.s_nch > 1) s_dma3(1, 1);
+        }
         if (has_bits) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -518,18 +563,12 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                         }
                 }
         }
-        constexpr int SW_QUADS = 4 * BM;                         // [hl][k half][BM]
-        constexpr int SW_INSTR = SW_QUADS / 64;
-        static_assert(SW_QUADS <= W_QUADS, "the style slab fits the weight region");
-        const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc((void*)a.s_wpack, 0, a.s_w_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void*)a.s_in16, 0, a.s_in_bytes, 0x00020000);
-        unsigned soff[I_PER_WAVE];                               // the blob's own bf16 copy is full resolution (UNPOOL: ioff addresses the pooled diff)
-        int ln = lane;
-        if constexpr (UNPOOL) asm volatile("" : "+v"(ln));      // computed HERE: hoisted above the main loop they would live through it in scratch
+      if constexpr (SB) {                                      // single staging buffer: one chunk at a time, staged as the conv's own tile
+        unsigned soff[I_PER_WAVE];
 #pragma unroll
-        for (int u = 0; u < I_PER_WAVE; ++u) soff[u] = UNPOOL ? full_res_offset(u, ln) : ioff[u];
-        auto s_dma = [&](int ch, int buf) {
-            uint4* dst = smem + buf * BUF_Q;
+        for (int u = 0; u < I_PER_WAVE; ++u) soff[u] = ioff[u];
+        auto s_dma = [&](int ch) {
+            uint4* dst = smem;
 #pragma unroll
             for (int t = 0; t < (SW_INSTR + 3) / 4; ++t) {
                 const int i = wave + 4 * t;
@@ -548,21 +587,19 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                 }
             }
         };
-        __syncthreads();                                         // every wave has left the main loop's buffers
-        s_dma(0, 0);
+        __syncthreads();                                         // every wave has left the main loop's buffer
+        s_dma(0);
         for (int ch = 0; ch < a.s_nch; ++ch) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                     // chunk ch has landed; the other buffer is free again
-            if (!SB && ch + 1 < a.s_nch) s_dma(ch + 1, (ch + 1) & 1);
-            const uint4* base = smem + (SB ? 0 : (ch & 1)) * BUF_Q;
+            __syncthreads();                                     // chunk ch has landed
             bf16x8 ahi[TM], alo[TM], bq[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                ahi[i] = __builtin_bit_cast(bf16x8, base[khalf * BM + wave_m * (TM * 32) + i * 32 + l31]);
-                alo[i] = __builtin_bit_cast(bf16x8, base[(2 + khalf) * BM + wave_m * (TM * 32) + i * 32 + l31]);
+                ahi[i] = __builtin_bit_cast(bf16x8, smem[khalf * BM + wave_m * (TM * 32) + i * 32 + l31]);
+                alo[i] = __builtin_bit_cast(bf16x8, smem[(2 + khalf) * BM + wave_m * (TM * 32) + i * 32 + l31]);
             }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bq[j] = __builtin_bit_cast(bf16x8, base[b_off + (j + 1) * PXW + 1]);
+            for (int j = 0; j < TN; ++j) bq[j] = __builtin_bit_cast(bf16x8, smem[b_off + (j + 1) * PXW + 1]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -570,11 +607,38 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bq[j], acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bq[j], acc[i][j], 0, 0, 0);
                 }
-            if (SB && ch + 1 < a.s_nch) {
+            if (ch + 1 < a.s_nch) {
                 __syncthreads();                                 // the operands of chunk ch are in registers everywhere
-                s_dma(ch + 1, 0);
+                s_dma(ch + 1);
             }
         }
+      } else {
+        int slot = 0;
+        for (int ch = 0; ch < a.s_nch; ++ch) {
+            // chunk ch has landed when all but the newer chunk's loads are back (this wave's; the barrier makes it every wave's)
+            if (ch + 1 < a.s_nch) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(S_PW) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                        // ... and every wave has read chunk ch - 1: its slot takes chunk ch + 2
+            const int slot2 = slot == 0 ? 2 : slot - 1;
+            if (ch + 2 < a.s_nch) s_dma3(ch + 2, slot2);
+            const uint4* base = smem + slot * S_SLOT;
+            bf16x8 ahi[TM], alo[TM], bq[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ahi[i] = __builtin_bit_cast(bf16x8, base[khalf * BM + wave_m * (TM * 32) + i * 32 + l31]);
+                alo[i] = __builtin_bit_cast(bf16x8, base[(2 + khalf) * BM + wave_m * (TM * 32) + i * 32 + l31]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[j] = __builtin_bit_cast(bf16x8, base[SW_QUADS + khalf * (ROWS * 32) + (wave_n * TN + j) * 32 + l31]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi[i], bq[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo[i], bq[j], acc[i][j], 0, 0, 0);
+                }
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+      }
     }
     if (MK_ALL && has_mask16) {
 #pragma unroll
