@@ -791,17 +791,20 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
         }
     };
     if constexpr (EPI != 0) {
-        // ---- one epilogue per launch kind (round 5).  The lean flow launches four kinds over and over, none of which writes fp32:
+        // ---- one epilogue per launch kind (round 5).  The lean flow launches three kinds over and over, none of which touches fp32:
         //   EPI 1  forward build:        (bias, ReLU) -> bf16 copy (+ sign map)         -- also the data gradients with no option at all
         //   EPI 2  forward build:        (bias, ReLU) -> 2x2 max-pool -> pooled bf16 copy + arg-max map (whole windows: H, W even)
         //   EPI 3  data-gradient build:  sign-map ReLU mask (here, or before the fused style chunks) -> bf16 copy
+        // and two more once per step, at the blob that carries a content / deep-dream term:
+        //   EPI 4  = 1 + the fp32 blob (the loss reads fp32)        EPI 5  = 3 + the injected fp32 diff of that term, added after the mask
         // every tile whole in M (M % BM == 0, checked at launch).  Same arithmetic on every value as the general epilogue below (the
         // tests compare bit for bit, ST2_CONV16_EPI=0 selects the general one), but every global access is a buffer access -- a
         // wave-uniform scalar offset per 16-channel row group, one vector offset per pixel row, out-of-range for what must not be
         // written -- so the per-element 64-bit addresses, bounds tests and run-time option branches are gone: ~40 instructions per
         // (16 channels x 32 pixels) instead of ~300.  ReLU is an integer maximum of the bit pattern with 0 (off: with INT_MIN): v > 0 ? v : +0
         // for every v that is not a NaN.
-        static_assert(!DIAG && (EPI == 3) == (DG && MB) && (EPI != 2 || TN % 2 == 0), "launch kinds");
+        constexpr bool E_F = EPI == 1 || EPI == 4, E_D = EPI == 3 || EPI == 5;
+        static_assert(!DIAG && E_D == (DG && MB) && (EPI != 2 || TN % 2 == 0), "launch kinds");
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
         const unsigned mrow0 = (unsigned)(m0 + wave_m * (TM * 32));
@@ -829,16 +832,23 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
             for (int e = 0; e < 4; ++e) { pk0[e] = (__bf16)v[e]; pk1[e] = (__bf16)v[4 + e]; }
             u0 = __builtin_bit_cast(uint2, pk0); u1 = __builtin_bit_cast(uint2, pk1);
         };
-        if constexpr (EPI == 1 || EPI == 3) {
+        if constexpr (E_F || E_D) {
             const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)a.out16, 0, (unsigned)a.M * plane * 2u, 0x00020000);
             unsigned vo[TN];                                     // this lane's quad (lanes 32 .. 63: the second quad of the 16 channels) of pixel j
 #pragma unroll
             for (int j = 0; j < TN; ++j) vo[j] = livej[j] ? ((unsigned)khalf * plane + pixj[j]) * 16u : kOOBStore;
+            // fp32 side of kinds 4 / 5 (NCHW): element e of a lane is channel mbase + (e & 3) + 8 (e >> 2), mbase = row group + 4 k half + 16 h --
+            // the lane's part (pixel, k half) in the vector offset, the rest in the scalar offset (4-byte accesses: no store-data hazard)
+            const __amdgpu_buffer_rsrc_t rs_f32 = __builtin_amdgcn_make_buffer_rsrc((void*)(EPI == 4 ? (const float*)a.out : a.inject), 0, (unsigned)a.M * plane * 4u, 0x00020000);
+            unsigned vf[(EPI == 4 || EPI == 5) ? TN : 1];
+            if constexpr (EPI == 4 || EPI == 5) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) vf[j] = livej[j] ? (4u * khalf * plane + pixj[j]) * 4u : kOOB16;
+            }
             // eight bf16 values in four words -> one byte, bit e = value e is non-zero (nonzero_halves16 without a condition register)
             auto nz8 = [&](uint2 u0, uint2 u1) __attribute__((always_inline)) -> unsigned {
                 // min(half, 1) per 16-bit half.  The 1s pass through an EMPTY asm so that the compiler cannot turn the minimum back into two
-                // compares + selects per word; the instruction itself must stay visible to it (v_pk_min_u16 inside an asm statement, where its
-                // hazard recogniser does not look: the second v_permlane32_swap behind it came out wrong in lanes 12 .. 15 / 28 .. 31)
+                // compares + selects per word (it does when it sees the constant); the instruction itself stays its own to schedule
                 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
                 unsigned ones = 0x00010001u;
                 asm("" : "+v"(ones));
@@ -852,36 +862,51 @@ __device__ __forceinline__ void conv16_body(const Conv16KArgs& a)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 unsigned mbits[TN];
-                if constexpr (EPI == 3) { if (!fuse_style) load_bits(i, mbits); }
+                if constexpr (E_D) { if (!fuse_style) load_bits(i, mbits); }
                 unsigned obits[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) obits[j] = 0u;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     float bs[8];
-                    if constexpr (EPI == 1) load_bias(i, h, bs);
+                    if constexpr (E_F) load_bias(i, h, bs);
                     const unsigned so = ((mrow0 + i * 32 + 16 * h) >> 3) * plane * 16u;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
                         float v[8];
-                        if constexpr (EPI == 1) finish8(i, j, h, bs, v);
+                        if constexpr (E_F) finish8(i, j, h, bs, v);
                         else {
+                            float ij[8];
+                            if constexpr (EPI == 5) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    ij[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_f32, vf[j], (mrow0 + i * 32 + 16 * h + (e & 3) + 8 * (e >> 2)) * plane * 4u, 0));
+                            }
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = acc[i][j][8 * h + e];
                             if (!fuse_style) {
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) v[e] = keep_if_bit(v[e], mbits[j], 8 * h + e);
                             }
+                            if constexpr (EPI == 5) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] += ij[e];
+                            }
+                        }
+                        if constexpr (EPI == 4) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[e]), rs_f32, vf[j], (mrow0 + i * 32 + 16 * h + (e & 3) + 8 * (e >> 2)) * plane * 4u, 0);
                         }
                         uint2 u0, u1;
                         pack8(v, u0, u1);
-                        if (EPI == 1 && bits_out) obits[j] |= nz8(u0, u1) << (8 * h);
+                        if (E_F && bits_out) obits[j] |= nz8(u0, u1) << (8 * h);
                         const auto sx = __builtin_amdgcn_permlane32_swap(u0.x, u1.x, false, false);
                         const auto sy = __builtin_amdgcn_permlane32_swap(u0.y, u1.y, false, false);
                         __builtin_amdgcn_raw_buffer_store_b128((u32x4){sx[0], sy[0], sx[1], sy[1]}, rs_o, vo[j] + so, 0, 0);      // (no SGPR offset: see kOOBStore)
                     }
                 }
-                if (EPI == 1 && bits_out) {                      // (M % BM == 0: no padding group on this path)
+                if (E_F && bits_out) {                          // (M % BM == 0: no padding group on this path)
                     const unsigned blk = (mrow0 + i * 32) >> 5;
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
@@ -984,6 +1009,8 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_f16(const Conv
 __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_pool(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, false, false, false, false, 2>(a); }
 __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_dgb16(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, false, true, true, false, 3>(a); }
 __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_unpool_b16(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, true, true, true, false, 3>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_f16o(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, false, false, false, false, 4>(a); }
+__global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x512_dgb16i(const Conv16KArgs a) { conv16_body<64, 16, 1, 4, false, false, true, true, false, 5>(a); }
 __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_f16(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, false, false, false, false, 1>(a); }
 __global__ __launch_bounds__(NT, 2) void conv3x3_mfma_bf16_64x256_dgb16(const Conv16KArgs a) { conv16_body<64, 8, 1, 4, false, false, true, true, false, 3>(a); }
 
@@ -1084,13 +1111,18 @@ hipError_t launch_conv3x3_bf16(const Conv16Problem& p, hipStream_t s)
     int epi = 0;
     {
         const char* ee = getenv("ST2_CONV16_EPI");
-        const bool lean16 = !(ee && *ee == '0') && p.M % BM == 0 && !p.out && !p.mask_src && !p.mask16 && !p.inject && !p.pool32;
+        const bool kinds = !(ee && *ee == '0') && p.M % BM == 0 && !p.mask_src && !p.mask16 && !p.pool32;
+        const bool lean16 = kinds && !p.out && !p.inject;
         if (lean16 && !dg && p.out16 && !pools) epi = 1;
         else if (lean16 && !dg && pools && p.pool16 && p.amap && !p.out16 && !p.bits_out && p.H % 2 == 0 && p.W % 2 == 0) epi = 2;
         else if (lean16 && dg && mb && p.out16) epi = 3;
-        const char* ek = getenv("ST2_CONV16_EPI_KINDS");     // bit (kind - 1): that kind may run (default: all three)
+        else if (kinds && !dg && p.out && p.out16 && !pools && !p.inject && cfg == 3 && !sb) epi = 4;
+        else if (kinds && dg && mb && p.out16 && !p.out && p.inject && cfg == 3 && !unpool) epi = 5;
+        const char* ek = getenv("ST2_CONV16_EPI_KINDS");     // bit (kind - 1): that kind may run (default: all five)
         if (epi && ek && *ek && !((atoi(ek) >> (epi - 1)) & 1)) epi = 0;
     }
+    if (epi == 4) { conv3x3_mfma_bf16_64x512_f16o<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
+    if (epi == 5) { conv3x3_mfma_bf16_64x512_dgb16i<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
     if (epi && cfg == 0 && sb && !dg) { if (epi == 1) conv3x3_mfma_bf16_64x256_sb_f16<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x256_sb_pool<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
     if (epi && cfg == 3 && !dg) { if (epi == 1) conv3x3_mfma_bf16_64x512_f16<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x512_pool<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
     if (epi == 3 && cfg == 3) { if (unpool) conv3x3_mfma_bf16_64x512_unpool_b16<<<grid, block, 0, s>>>(k); else conv3x3_mfma_bf16_64x512_dgb16<<<grid, block, 0, s>>>(k); return hipGetLastError(); }
